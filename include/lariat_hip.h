@@ -1,0 +1,227 @@
+/* lariat_hip.h — C-ABI of liblariat_hip.so, the MI355X-native replacement for the
+ * per-barcode align loop of 10XGenomics/lariat.
+ *
+ * What it replaces (reference file:line):
+ *   go/src/gobwa/bwa_bridge.h:35-39      the cgo prototypes into BWA (mem_align1_core, mem_chain,
+ *                                        mem_reg2aln, mem_matesw, bns_fetch_seq)
+ *   go/src/gobwa/gobwa.go:128-153        GoBwaLoadReference / GoBwaAllocSettings
+ *   go/src/gobwa/gobwa.go:226-337        GoBwaMemMateSW   (SE align both mates + mate rescue)
+ *   go/src/gobwa/gobwa.go:400-415        GoBwaSmithWaterman (reg -> CIGAR/NM)
+ *   go/src/gobwa/gobwa.go:50-80          GoBwaReference.GetSeq
+ *   go/src/inference/lariat.go:461-547   DoRFAForOneBarcode (GetChains, GetAlignments, tagBestAlignments,
+ *                                        inferMolecules, RFA optimizer, estimateMapQualities, markDuplicates,
+ *                                        CheckSplitReads) — everything up to, not including, DumpToBams
+ *
+ * Design differences from the reference boundary:
+ *   - batched: ONE call per batch of barcodes instead of thousands of cgo calls per barcode;
+ *   - plain fixed-width arrays (SoA), no struct aliasing across the boundary, no pointers retained;
+ *   - int status codes + lh_last_error(); the library never abort()s;
+ *   - results live in a library-owned arena released by lh_result_free.
+ *
+ * Threading: an lh_index is immutable after load; one lh_context per host thread / HIP stream.
+ */
+#ifndef LARIAT_HIP_H
+#define LARIAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_ABI_VERSION 1
+
+/* status codes */
+#define LH_OK 0
+#define LH_E_ARG 1       /* bad argument */
+#define LH_E_IO 2        /* index files unreadable / inconsistent (reference: gobwa.go:132-135 only logs) */
+#define LH_E_HIP 3       /* HIP runtime error (message in lh_last_error) */
+#define LH_E_CAPACITY 4  /* a workspace pool overflowed: split the batch and retry */
+#define LH_E_NODEVICE 5  /* no HIP device / extension not usable: there is NO CPU fallback */
+#define LH_E_LIMIT 6     /* input outside documented limits (read length > LH_MAX_READ_LEN ...) */
+
+#define LH_MAX_READ_LEN 250 /* bases per read after trimming (u8 mate-rescue path needs l*a < 250, as upstream) */
+
+typedef struct lh_index lh_index;     /* FM-index + 2-bit reference resident in HBM */
+typedef struct lh_context lh_context; /* per-stream workspace */
+
+/* mem_opt_t defaults (mem_opt_init, gobwa.go:149-153) + the lariat knobs of the hot path
+ * (main.go:10 improper_pair_penalty; lariat.go:475-476 score_delta 25 / aln delta 17; lariat.go:885 genome length). */
+typedef struct lh_opts {
+    int32_t abi_version;
+    int32_t a, b, o_del, e_del, o_ins, e_ins;
+    int32_t pen_unpaired, pen_clip5, pen_clip3;
+    int32_t w, zdrop, T;
+    int32_t min_seed_len, min_chain_weight, max_chain_extend;
+    float split_factor;
+    int32_t split_width, max_occ, max_chain_gap, max_ins;
+    float mask_level, drop_ratio, XA_drop_ratio, mask_level_redun;
+    float mapQ_coef_len;
+    int32_t max_mem_intv, max_matesw;
+    /* mate-rescue window: gobwa.go:229-237 (orientation FR only) */
+    int32_t pes_low, pes_high;
+    /* lariat */
+    int32_t rescue_score_delta; /* 25, lariat.go:475 */
+    int32_t rescue_max_hits;    /* 50, gobwa.go:287,311 */
+    int32_t aln_score_delta;    /* 17, lariat.go:476 */
+    double improper_pair_penalty; /* -4.0, main.go:10 */
+    double genome_length;         /* 3.2e9, lariat.go:885 */
+    int32_t run_inference;        /* 0: stop after candidate generation (GetChains+GetAlignments) */
+    int32_t reserved;
+} lh_opts;
+
+/* one batch of barcodes.  Reads are post-trim (reader.go trims read1) nt4 bytes: A0 C1 G2 T3 other 4
+ * (SequenceConvert, gobwa.go:159).  read index r = 2*pair + mate (lariat.go:1720-1721,1758-1759). */
+typedef struct lh_batch {
+    int32_t n_barcodes;
+    int32_t n_pairs;
+    const int32_t* bc_pair_off; /* [n_barcodes+1] pair range of each barcode (one WorkUnit, lariat.go:211) */
+    const uint8_t* bc_do_rfa;   /* [n_barcodes] worthRunningRFA (lariat.go:1088): >=5 pairs, barcode has '-', complete barcode */
+    const int64_t* seq_off;     /* [2*n_pairs+1] byte offsets into seq */
+    const uint8_t* seq;         /* nt4 bases */
+    const uint64_t* name_seed;  /* [n_pairs] LE u64 of md5(read name)[0:8] (lariat.go:1483-1484) */
+    /* centromeres (lariat.go:392-420), per contig, -1/-1 if none */
+    const int64_t* cen_start;   /* [n_contigs] or NULL */
+    const int64_t* cen_end;
+} lh_batch;
+
+/* Result arena.  Candidate order per read = BWA reg order after rescue (gobwa.go:330-336) = lariat's `full`
+ * list (lariat.go:1697); a read without hits has ONE placeholder candidate (rid -1, pos -1; lariat.go:1737,1773).
+ * All per-candidate arrays have n_cand entries, per-read arrays n_reads entries. */
+typedef struct lh_result {
+    int32_t abi_version;
+    int32_t n_reads;
+    int64_t n_cand;
+    const int64_t* cand_off;  /* [n_reads+1] */
+    /* --- candidate generation (Alignment fields set at lariat.go:1655-1696) --- */
+    const int32_t* rid;       /* contig id, -1 for placeholder */
+    const int64_t* pos;       /* Alignment.pos  (lariat.go:1645-1650) */
+    const int64_t* aend;      /* Alignment.aend */
+    const int64_t* rb;        /* mem_alnreg_t.rb/re in fwd||rev coordinates (-1 placeholder) */
+    const int64_t* re;
+    const uint8_t* reversed;
+    const int32_t* score;     /* mem_alnreg_t.score */
+    const int32_t* qb;        /* readmap_s */
+    const int32_t* qe;        /* readmap_e */
+    const int32_t* nm;        /* EditDistance (gobwa.go:482) */
+    const int32_t* matches;
+    const int32_t* mismatches;
+    const int32_t* indels;
+    const int32_t* soft_clipped;
+    const int32_t* soft_clipped_length;
+    const uint8_t* in_filtered;   /* member of `alignments` (score >= best-17, lariat.go:1698) */
+    const int64_t* cigar_off;     /* [n_cand+1] */
+    const uint32_t* cigar;        /* BAM encoding len<<4|op, MIDSH=01234 (forward-strand order, as mem_reg2aln) */
+    const int64_t* mm_off;        /* [n_cand+1] */
+    const int32_t* mm_ref_loc;    /* mismatchLocs (lariat.go:1609-1611) */
+    const int32_t* mm_read_loc;   /* mismatchReadLocs */
+    const double* log_alignment_probability;
+    /* --- inference (per candidate) --- */
+    const uint8_t* active;
+    const uint8_t* is_proper;
+    const uint8_t* bwa_pick;
+    const uint8_t* active_molecule;
+    const uint8_t* duplicate;
+    const int32_t* molecule_id;
+    const int32_t* mapq;
+    const double* molecule_difference;
+    const double* molecule_confidence;
+    const double* sum_move_probability_change;
+    const int64_t* mate_idx;      /* Alignment.mate_alignment as candidate index, -1 if nil */
+    /* --- per read --- */
+    const int64_t* active_idx;        /* the active candidate */
+    const int64_t* second_best_idx;   /* mapq_data.second_best, -1 if nil */
+    const double* second_best_score;  /* XS */
+    const double* as_score;           /* AS: mapq_data.score */
+    const int64_t* split_idx;         /* Alignment.secondary (split.go:142-158), -1 if none */
+    const int32_t* split_mapq;
+    const double* split_second_best;
+    const double* split_score;
+    /* --- telemetry: device-side counters of the algorithmic work (roofline accounting) --- */
+    uint64_t n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells;
+    void* arena_; /* private */
+} lh_result;
+
+/* stage dumps for parity tests (one array set per stage; freed with lh_result_free-like lh_dump_free) */
+typedef struct lh_stage_dump {
+    int32_t n_reads;
+    /* SMEM intervals after the three passes + sort (mem_collect_intv) */
+    const int64_t* intv_off; /* [n_reads+1] */
+    const uint64_t* intv;    /* 4 u64 per interval: x0 x1 x2 info */
+    /* seeds in mem_chain order: rbeg, qbeg, len, rid(-1/-2 dropped) */
+    const int64_t* seed_off;
+    const int64_t* seed_rbeg;
+    const int32_t* seed_qbeg;
+    const int32_t* seed_len;
+    const int32_t* seed_rid;
+    /* chains after mem_chain_flt: per chain n_seeds, rid, w, kept, first seed rbeg */
+    const int64_t* chain_off;
+    const int32_t* chain_nseeds;
+    const int32_t* chain_rid;
+    const int32_t* chain_w;
+    const int32_t* chain_kept;
+    const int64_t* chain_pos;
+    /* regs after mem_align1_core (before rescue): 12 ints per reg */
+    const int64_t* reg_off;
+    const int64_t* reg_rb;
+    const int64_t* reg_re;
+    const int32_t* reg_qb;
+    const int32_t* reg_qe;
+    const int32_t* reg_rid;
+    const int32_t* reg_score;
+    const int32_t* reg_truesc;
+    const int32_t* reg_w;
+    const int32_t* reg_seedcov;
+    const int32_t* reg_seedlen0;
+    const int32_t* reg_csub;
+    const int32_t* reg_secondary;
+    void* arena_;
+} lh_stage_dump;
+
+const char* lh_last_error(void);
+int lh_device_count(void);
+
+void lh_opts_init(lh_opts* o); /* replaces mem_opt_init + lariat flag defaults */
+
+/* replaces bwa_idx_load(path, BWA_IDX_ALL) (gobwa.go:130): reads <prefix>.bwt/.sa/.pac/.ann/.amb and uploads to `device` */
+int lh_index_load(const char* prefix, int device, lh_index** out);
+/* same, from in-memory images laid out exactly like the BWA files (used by the index builder / synthetic genomes) */
+int lh_index_from_arrays(int device, uint64_t primary, const uint64_t L2[5], const uint32_t* bwt, uint64_t bwt_words,
+                         int32_t sa_intv, const uint64_t* sa, uint64_t n_sa, const uint8_t* pac, int64_t l_pac,
+                         int32_t n_contigs, const int64_t* contig_off, const int32_t* contig_len, const char* const* contig_name,
+                         lh_index** out);
+/* GetReferenceContigsInfo (gobwa.go:26) */
+int lh_index_contigs(const lh_index* idx, int32_t* n, const char* const** names, const int64_t** lens, const int64_t** offsets);
+int64_t lh_index_l_pac(const lh_index* idx);
+void lh_index_free(lh_index* idx);
+
+/* FM-index construction: text = fwd || revcomp of the 2-bit contigs, BWA-byte-compatible output.
+ * Host-side (multi-threaded suffix sorting); writes <prefix>.bwt/.sa/.pac/.ann/.amb. */
+int lh_index_build(const char* prefix, int32_t n_contigs, const char* const* names, const uint8_t* const* nt4, const int64_t* lens, int32_t threads);
+
+int lh_context_create(lh_index* idx, int64_t max_pairs_per_batch, lh_context** out);
+void lh_context_free(lh_context* ctx);
+
+/* THE hot path: DoRFAForOneBarcode for every barcode of the batch (lariat.go:461-547), minus DumpToBams.
+ * Inputs are host buffers; lh_align_barcodes = upload + lh_align_resident + download. */
+int lh_align_barcodes(lh_context* ctx, const lh_opts* opts, const lh_batch* batch, lh_result** out);
+/* split form used by bench.py: inputs resident in HBM when the timed region starts */
+int lh_batch_upload(lh_context* ctx, const lh_batch* batch);
+int lh_align_resident(lh_context* ctx, const lh_opts* opts);            /* enqueue all kernels + sync */
+int lh_result_download(lh_context* ctx, lh_result** out);
+void lh_result_free(lh_result* r);
+
+/* per-kernel timing of the last lh_align_resident (HIP events on the context's stream), ms; names are static strings */
+int lh_last_timings(lh_context* ctx, int32_t* n, const char* const** names, const float** ms);
+
+/* stage dump of the candidate-generation front end (mem_align1_core) for the resident batch: parity tests only */
+int lh_stage_dump_resident(lh_context* ctx, const lh_opts* opts, lh_stage_dump** out);
+void lh_stage_dump_free(lh_stage_dump* d);
+
+/* GetSeq (gobwa.go:50-80): forward-coordinate slice [start,end) of contig rid as ASCII, reverse-complemented if reversed */
+int lh_get_seq(const lh_index* idx, int32_t rid, int64_t start, int64_t end, int32_t reversed, char* out /* end-start bytes */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LARIAT_HIP_H */

@@ -1,0 +1,259 @@
+"""ctypes mirror of include/lariat_hip.h.
+
+Plumbing only: struct layouts, numpy views over result arenas, and the loader of
+``liblariat_hip.so``.  The product is the shared library; there is NO CPU fallback here —
+if the HIP library is missing or no device is present every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "liblariat_hip.so")
+
+LH_OK = 0
+LH_ABI_VERSION = 1
+LH_MAX_READ_LEN = 250
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+c_u32p = C.POINTER(C.c_uint32)
+c_u64p = C.POINTER(C.c_uint64)
+c_f64p = C.POINTER(C.c_double)
+
+
+class LhOpts(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("a", C.c_int32), ("b", C.c_int32), ("o_del", C.c_int32), ("e_del", C.c_int32), ("o_ins", C.c_int32), ("e_ins", C.c_int32),
+        ("pen_unpaired", C.c_int32), ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32),
+        ("w", C.c_int32), ("zdrop", C.c_int32), ("T", C.c_int32),
+        ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
+        ("split_factor", C.c_float),
+        ("split_width", C.c_int32), ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("max_ins", C.c_int32),
+        ("mask_level", C.c_float), ("drop_ratio", C.c_float), ("XA_drop_ratio", C.c_float), ("mask_level_redun", C.c_float),
+        ("mapQ_coef_len", C.c_float),
+        ("max_mem_intv", C.c_int32), ("max_matesw", C.c_int32),
+        ("pes_low", C.c_int32), ("pes_high", C.c_int32),
+        ("rescue_score_delta", C.c_int32), ("rescue_max_hits", C.c_int32), ("aln_score_delta", C.c_int32),
+        ("improper_pair_penalty", C.c_double), ("genome_length", C.c_double),
+        ("run_inference", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class LhBatch(C.Structure):
+    _fields_ = [
+        ("n_barcodes", C.c_int32), ("n_pairs", C.c_int32),
+        ("bc_pair_off", c_i32p), ("bc_do_rfa", c_u8p),
+        ("seq_off", c_i64p), ("seq", c_u8p), ("name_seed", c_u64p),
+        ("cen_start", c_i64p), ("cen_end", c_i64p),
+    ]
+
+
+_RESULT_CAND_FIELDS = [  # (name, ctype pointer, numpy dtype) — one entry per candidate
+    ("rid", c_i32p, np.int32), ("pos", c_i64p, np.int64), ("aend", c_i64p, np.int64), ("rb", c_i64p, np.int64), ("re", c_i64p, np.int64),
+    ("reversed", c_u8p, np.uint8), ("score", c_i32p, np.int32), ("qb", c_i32p, np.int32), ("qe", c_i32p, np.int32), ("nm", c_i32p, np.int32),
+    ("matches", c_i32p, np.int32), ("mismatches", c_i32p, np.int32), ("indels", c_i32p, np.int32),
+    ("soft_clipped", c_i32p, np.int32), ("soft_clipped_length", c_i32p, np.int32), ("in_filtered", c_u8p, np.uint8),
+]
+_RESULT_INF_FIELDS = [
+    ("active", c_u8p, np.uint8), ("is_proper", c_u8p, np.uint8), ("bwa_pick", c_u8p, np.uint8), ("active_molecule", c_u8p, np.uint8),
+    ("duplicate", c_u8p, np.uint8), ("molecule_id", c_i32p, np.int32), ("mapq", c_i32p, np.int32),
+    ("molecule_difference", c_f64p, np.float64), ("molecule_confidence", c_f64p, np.float64),
+    ("sum_move_probability_change", c_f64p, np.float64), ("mate_idx", c_i64p, np.int64),
+]
+_RESULT_READ_FIELDS = [
+    ("active_idx", c_i64p, np.int64), ("second_best_idx", c_i64p, np.int64), ("second_best_score", c_f64p, np.float64),
+    ("as_score", c_f64p, np.float64), ("split_idx", c_i64p, np.int64), ("split_mapq", c_i32p, np.int32),
+    ("split_second_best", c_f64p, np.float64), ("split_score", c_f64p, np.float64),
+]
+_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"]
+
+
+class LhResult(C.Structure):
+    _fields_ = (
+        [("abi_version", C.c_int32), ("n_reads", C.c_int32), ("n_cand", C.c_int64), ("cand_off", c_i64p)]
+        + [(n, t) for n, t, _ in _RESULT_CAND_FIELDS]
+        + [("cigar_off", c_i64p), ("cigar", c_u32p), ("mm_off", c_i64p), ("mm_ref_loc", c_i32p), ("mm_read_loc", c_i32p),
+           ("log_alignment_probability", c_f64p)]
+        + [(n, t) for n, t, _ in _RESULT_INF_FIELDS]
+        + [(n, t) for n, t, _ in _RESULT_READ_FIELDS]
+        + [(n, C.c_uint64) for n in _COUNTERS]
+        + [("arena_", C.c_void_p)]
+    )
+
+
+_DUMP_FIELDS = [
+    ("intv_off", c_i64p, np.int64, "reads1"), ("intv", c_u64p, np.uint64, "intv4"),
+    ("seed_off", c_i64p, np.int64, "reads1"), ("seed_rbeg", c_i64p, np.int64, "seed"), ("seed_qbeg", c_i32p, np.int32, "seed"),
+    ("seed_len", c_i32p, np.int32, "seed"), ("seed_rid", c_i32p, np.int32, "seed"),
+    ("chain_off", c_i64p, np.int64, "reads1"), ("chain_nseeds", c_i32p, np.int32, "chain"), ("chain_rid", c_i32p, np.int32, "chain"),
+    ("chain_w", c_i32p, np.int32, "chain"), ("chain_kept", c_i32p, np.int32, "chain"), ("chain_pos", c_i64p, np.int64, "chain"),
+    ("reg_off", c_i64p, np.int64, "reads1"), ("reg_rb", c_i64p, np.int64, "reg"), ("reg_re", c_i64p, np.int64, "reg"),
+    ("reg_qb", c_i32p, np.int32, "reg"), ("reg_qe", c_i32p, np.int32, "reg"), ("reg_rid", c_i32p, np.int32, "reg"),
+    ("reg_score", c_i32p, np.int32, "reg"), ("reg_truesc", c_i32p, np.int32, "reg"), ("reg_w", c_i32p, np.int32, "reg"),
+    ("reg_seedcov", c_i32p, np.int32, "reg"), ("reg_seedlen0", c_i32p, np.int32, "reg"), ("reg_csub", c_i32p, np.int32, "reg"),
+    ("reg_secondary", c_i32p, np.int32, "reg"),
+]
+
+
+class LhStageDump(C.Structure):
+    _fields_ = [("n_reads", C.c_int32)] + [(n, t) for n, t, _, _ in _DUMP_FIELDS] + [("arena_", C.c_void_p)]
+
+
+def _view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).astype(dtype, copy=True)
+
+
+class Result:
+    """Owned numpy copy of an lh_result (so the arena can be freed immediately)."""
+
+    def __init__(self, r: LhResult):
+        self.n_reads = int(r.n_reads)
+        self.n_cand = int(r.n_cand)
+        self.cand_off = _view(r.cand_off, self.n_reads + 1, np.int64)
+        for n, _, dt in _RESULT_CAND_FIELDS + _RESULT_INF_FIELDS:
+            setattr(self, n, _view(getattr(r, n), self.n_cand, dt))
+        self.log_alignment_probability = _view(r.log_alignment_probability, self.n_cand, np.float64)
+        self.cigar_off = _view(r.cigar_off, self.n_cand + 1, np.int64)
+        self.cigar = _view(r.cigar, self.cigar_off[-1] if self.n_cand else 0, np.uint32)
+        self.mm_off = _view(r.mm_off, self.n_cand + 1, np.int64)
+        nmm = self.mm_off[-1] if self.n_cand else 0
+        self.mm_ref_loc = _view(r.mm_ref_loc, nmm, np.int32)
+        self.mm_read_loc = _view(r.mm_read_loc, nmm, np.int32)
+        for n, _, dt in _RESULT_READ_FIELDS:
+            setattr(self, n, _view(getattr(r, n), self.n_reads, dt))
+        self.counters = {n: int(getattr(r, n)) for n in _COUNTERS}
+
+    def cigar_of(self, i):
+        return self.cigar[self.cigar_off[i]:self.cigar_off[i + 1]]
+
+    def cigar_str(self, i):
+        return "".join("%d%s" % (c >> 4, "MIDSH"[c & 0xF]) for c in self.cigar_of(i))
+
+    def cands_of_read(self, r):
+        return range(int(self.cand_off[r]), int(self.cand_off[r + 1]))
+
+
+class StageDump:
+    def __init__(self, d: LhStageDump):
+        self.n_reads = int(d.n_reads)
+        offs = {}
+        for n, _, dt, kind in _DUMP_FIELDS:
+            if kind == "reads1":
+                offs[n] = _view(getattr(d, n), self.n_reads + 1, np.int64)
+                setattr(self, n, offs[n])
+        sizes = {"intv4": int(offs["intv_off"][-1]) * 4, "seed": int(offs["seed_off"][-1]), "chain": int(offs["chain_off"][-1]),
+                 "reg": int(offs["reg_off"][-1])}
+        for n, _, dt, kind in _DUMP_FIELDS:
+            if kind != "reads1":
+                setattr(self, n, _view(getattr(d, n), sizes[kind], dt))
+        self.intv = self.intv.reshape(-1, 4)
+
+
+class Batch:
+    """Host-side packing of barcode-grouped read pairs into an lh_batch (keeps the numpy buffers alive)."""
+
+    def __init__(self, reads_nt4, bc_pair_off, name_seed=None, bc_do_rfa=None, cen_start=None, cen_end=None):
+        # reads_nt4: list of 2*n_pairs uint8 arrays (R1,R2,R1,R2...) already nt4-coded and trimmed
+        n_reads = len(reads_nt4)
+        assert n_reads % 2 == 0
+        self.n_pairs = n_reads // 2
+        lens = np.fromiter((len(x) for x in reads_nt4), dtype=np.int64, count=n_reads)
+        self.seq_off = np.zeros(n_reads + 1, dtype=np.int64)
+        np.cumsum(lens, out=self.seq_off[1:])
+        self.seq = np.concatenate([np.asarray(x, dtype=np.uint8) for x in reads_nt4]) if n_reads else np.zeros(0, np.uint8)
+        if self.seq.size == 0:
+            self.seq = np.zeros(1, np.uint8)
+        self._init_rest(bc_pair_off, name_seed, bc_do_rfa, cen_start, cen_end)
+
+    @classmethod
+    def from_arrays(cls, seq, seq_off, bc_pair_off, name_seed=None, bc_do_rfa=None, cen_start=None, cen_end=None):
+        self = cls.__new__(cls)
+        self.seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self.seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        self.n_pairs = (len(self.seq_off) - 1) // 2
+        self._init_rest(bc_pair_off, name_seed, bc_do_rfa, cen_start, cen_end)
+        return self
+
+    def _init_rest(self, bc_pair_off, name_seed, bc_do_rfa, cen_start, cen_end):
+        self.bc_pair_off = np.ascontiguousarray(bc_pair_off, dtype=np.int32)
+        self.n_barcodes = len(self.bc_pair_off) - 1
+        assert self.bc_pair_off[0] == 0 and self.bc_pair_off[-1] == self.n_pairs
+        self.name_seed = np.ascontiguousarray(name_seed if name_seed is not None else np.arange(1, self.n_pairs + 1), dtype=np.uint64)
+        self.bc_do_rfa = np.ascontiguousarray(bc_do_rfa if bc_do_rfa is not None else np.ones(self.n_barcodes), dtype=np.uint8)
+        self.cen_start = None if cen_start is None else np.ascontiguousarray(cen_start, dtype=np.int64)
+        self.cen_end = None if cen_end is None else np.ascontiguousarray(cen_end, dtype=np.int64)
+        b = LhBatch()
+        b.n_barcodes = self.n_barcodes
+        b.n_pairs = self.n_pairs
+        b.bc_pair_off = self.bc_pair_off.ctypes.data_as(c_i32p)
+        b.bc_do_rfa = self.bc_do_rfa.ctypes.data_as(c_u8p)
+        b.seq_off = self.seq_off.ctypes.data_as(c_i64p)
+        b.seq = self.seq.ctypes.data_as(c_u8p)
+        b.name_seed = self.name_seed.ctypes.data_as(c_u64p)
+        b.cen_start = self.cen_start.ctypes.data_as(c_i64p) if self.cen_start is not None else None
+        b.cen_end = self.cen_end.ctypes.data_as(c_i64p) if self.cen_end is not None else None
+        self.c = b
+
+
+_NT4 = np.full(256, 4, dtype=np.uint8)
+for _i, _ch in enumerate("ACGT"):
+    _NT4[ord(_ch)] = _i
+    _NT4[ord(_ch.lower())] = _i
+
+
+def sequence_convert(seq):
+    """SequenceConvert (gobwa.go:159-167): ASCII -> nt4."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    return _NT4[np.frombuffer(seq, dtype=np.uint8)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load liblariat_hip.so and declare prototypes.  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("liblariat_hip.so not built (%s): run __graft_entry__.build(); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    L.lh_last_error.restype = C.c_char_p
+    L.lh_device_count.restype = C.c_int
+    L.lh_opts_init.argtypes = [C.POINTER(LhOpts)]
+    L.lh_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.lh_index_from_arrays.argtypes = [C.c_int, C.c_uint64, c_u64p, c_u32p, C.c_uint64, C.c_int32, c_u64p, C.c_uint64, c_u8p, C.c_int64,
+                                       C.c_int32, c_i64p, c_i32p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+    L.lh_index_contigs.argtypes = [C.c_void_p, c_i32p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(c_i64p), C.POINTER(c_i64p)]
+    L.lh_index_l_pac.argtypes = [C.c_void_p]
+    L.lh_index_l_pac.restype = C.c_int64
+    L.lh_index_free.argtypes = [C.c_void_p]
+    L.lh_index_build.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(c_u8p), c_i64p, C.c_int32]
+    L.lh_context_create.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.lh_context_free.argtypes = [C.c_void_p]
+    L.lh_align_barcodes.argtypes = [C.c_void_p, C.POINTER(LhOpts), C.POINTER(LhBatch), C.POINTER(C.POINTER(LhResult))]
+    L.lh_batch_upload.argtypes = [C.c_void_p, C.POINTER(LhBatch)]
+    L.lh_align_resident.argtypes = [C.c_void_p, C.POINTER(LhOpts)]
+    L.lh_result_download.argtypes = [C.c_void_p, C.POINTER(C.POINTER(LhResult))]
+    L.lh_result_free.argtypes = [C.POINTER(LhResult)]
+    L.lh_last_timings.argtypes = [C.c_void_p, c_i32p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float))]
+    L.lh_stage_dump_resident.argtypes = [C.c_void_p, C.POINTER(LhOpts), C.POINTER(C.POINTER(LhStageDump))]
+    L.lh_stage_dump_free.argtypes = [C.POINTER(LhStageDump)]
+    L.lh_get_seq.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_char_p]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "lh_last_error", "lh_device_count", "lh_opts_init", "lh_index_load", "lh_index_from_arrays", "lh_index_contigs", "lh_index_l_pac",
+    "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
+    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq",
+]
