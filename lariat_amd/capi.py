@@ -214,18 +214,7 @@ def sequence_convert(seq):
     return _NT4[np.frombuffer(seq, dtype=np.uint8)]
 
 
-_lib = None
-
-
-def load_library(path=None):
-    """Load liblariat_hip.so and declare prototypes.  Raises if it is missing: no fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = path or LIB_PATH
-    if not os.path.exists(path):
-        raise RuntimeError("liblariat_hip.so not built (%s): run __graft_entry__.build(); there is no CPU fallback" % path)
-    L = C.CDLL(path)
+def _declare(L):
     L.lh_last_error.restype = C.c_char_p
     L.lh_device_count.restype = C.c_int
     L.lh_opts_init.argtypes = [C.POINTER(LhOpts)]
@@ -248,8 +237,173 @@ def load_library(path=None):
     L.lh_stage_dump_resident.argtypes = [C.c_void_p, C.POINTER(LhOpts), C.POINTER(C.POINTER(LhStageDump))]
     L.lh_stage_dump_free.argtypes = [C.POINTER(LhStageDump)]
     L.lh_get_seq.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_char_p]
-    _lib = L
     return L
+
+
+class LhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("liblariat_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Library:
+    """A loaded C-ABI library (the product liblariat_hip.so; tests may point it at the emulator build)."""
+
+    def __init__(self, path=None):
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError("%s not built: run __graft_entry__.build(); there is no CPU fallback" % path)
+        self.path = path
+        self.L = _declare(C.CDLL(path))
+
+    def check(self, rc):
+        if rc != LH_OK:
+            raise LhError(rc, self.L.lh_last_error().decode(errors="replace"))
+
+    def device_count(self):
+        return self.L.lh_device_count()
+
+    def opts(self, **kw):
+        o = LhOpts()
+        self.L.lh_opts_init(C.byref(o))
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        return o
+
+    def index_load(self, prefix, device=0):
+        h = C.c_void_p()
+        self.check(self.L.lh_index_load(prefix.encode(), device, C.byref(h)))
+        return Index(self, h)
+
+    def index_from_arrays(self, arrs, device=0):
+        """arrs: dict(primary, L2, bwt, sa, sa_intv, pac, l_pac, contigs=[(name,len,off)])"""
+        n = len(arrs["contigs"])
+        names = (C.c_char_p * n)(*[c[0].encode() for c in arrs["contigs"]])
+        lens = np.array([c[1] for c in arrs["contigs"]], dtype=np.int32)
+        offs = np.array([c[2] for c in arrs["contigs"]], dtype=np.int64)
+        L2 = np.ascontiguousarray(arrs["L2"], dtype=np.uint64)
+        bwt = np.ascontiguousarray(arrs["bwt"], dtype=np.uint32)
+        sa = np.ascontiguousarray(arrs["sa"], dtype=np.uint64)
+        pac = np.ascontiguousarray(arrs["pac"], dtype=np.uint8)
+        h = C.c_void_p()
+        self.check(self.L.lh_index_from_arrays(device, int(arrs["primary"]), L2.ctypes.data_as(c_u64p), bwt.ctypes.data_as(c_u32p), len(bwt),
+                                               int(arrs["sa_intv"]), sa.ctypes.data_as(c_u64p), len(sa), pac.ctypes.data_as(c_u8p), int(arrs["l_pac"]),
+                                               n, offs.ctypes.data_as(c_i64p), lens.ctypes.data_as(c_i32p), names, C.byref(h)))
+        return Index(self, h)
+
+    def index_build(self, prefix, names, contigs_nt4, threads=0):
+        n = len(names)
+        seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in contigs_nt4]
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        ptrs = (c_u8p * n)(*[s.ctypes.data_as(c_u8p) for s in seqs])
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        rc = self.L.lh_index_build(prefix.encode(), n, nm, ptrs, lens.ctypes.data_as(c_i64p), threads)
+        if rc:
+            raise LhError(rc, "lh_index_build failed")
+
+
+class Index:
+    def __init__(self, lib, h):
+        self.lib, self.h = lib, h
+
+    def close(self):
+        if self.h:
+            self.lib.L.lh_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def l_pac(self):
+        return self.lib.L.lh_index_l_pac(self.h)
+
+    def contigs(self):
+        n = C.c_int32()
+        names = C.POINTER(C.c_char_p)()
+        lens = c_i64p()
+        offs = c_i64p()
+        self.lib.check(self.lib.L.lh_index_contigs(self.h, C.byref(n), C.byref(names), C.byref(lens), C.byref(offs)))
+        return [(names[i].decode(), int(lens[i]), int(offs[i])) for i in range(n.value)]
+
+    def get_seq(self, rid, start, end, reversed_):
+        buf = C.create_string_buffer(max(1, end - start))
+        self.lib.check(self.lib.L.lh_get_seq(self.h, rid, start, end, int(reversed_), buf))
+        return buf.raw[: end - start]
+
+    def context(self, max_pairs):
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.lh_context_create(self.h, int(max_pairs), C.byref(h)))
+        return Context(self, h)
+
+
+class Context:
+    def __init__(self, index, h):
+        self.index, self.lib, self.h = index, index.lib, h
+
+    def close(self):
+        if self.h:
+            self.lib.L.lh_context_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, batch):
+        self._batch = batch
+        self.lib.check(self.lib.L.lh_batch_upload(self.h, C.byref(batch.c)))
+
+    def align_resident(self, opts):
+        self.lib.check(self.lib.L.lh_align_resident(self.h, C.byref(opts)))
+
+    def download(self):
+        res = C.POINTER(LhResult)()
+        self.lib.check(self.lib.L.lh_result_download(self.h, C.byref(res)))
+        out = Result(res.contents)
+        self.lib.L.lh_result_free(res)
+        return out
+
+    def align_barcodes(self, batch, opts=None):
+        opts = opts or self.lib.opts()
+        self.upload(batch)
+        self.align_resident(opts)
+        return self.download()
+
+    def timings(self):
+        n = C.c_int32()
+        names = C.POINTER(C.c_char_p)()
+        ms = C.POINTER(C.c_float)()
+        self.lib.check(self.lib.L.lh_last_timings(self.h, C.byref(n), C.byref(names), C.byref(ms)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def stage_dump(self, batch=None, opts=None):
+        opts = opts or self.lib.opts()
+        if batch is not None:
+            self.upload(batch)
+        d = C.POINTER(LhStageDump)()
+        self.lib.check(self.lib.L.lh_stage_dump_resident(self.h, C.byref(opts), C.byref(d)))
+        out = StageDump(d.contents)
+        self.lib.L.lh_stage_dump_free(d)
+        return out
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """The product library (singleton).  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is None or (path and _lib.path != path):
+        _lib = Library(path)
+    return _lib
 
 
 EXPORTED_SYMBOLS = [

@@ -1,0 +1,188 @@
+// k_chain.h — K3: seed chaining + chain filtering, one wavefront per read.
+// Replaces the chaining half of BWA's mem_chain (kbtree insert / test_and_merge), mem_chain_weight and mem_chain_flt,
+// reached through mem_align1_core (go/src/gobwa/gobwa.go:244,253).  mem_flt_chained_seeds is a no-op for reads this
+// short.
+//
+// The ordered set of chains (upstream: a B-tree keyed by the first seed's position) is a position-sorted index array in
+// HBM scratch: predecessor search is a wave-uniform binary search, insertion is a lane-parallel shift.  Seeds of a chain
+// form a linked list (append only), flattened at the end.  The unstable introsort by weight and the greedy pairwise
+// filter are order-dependent and run on lane 0.
+#pragma once
+#include "k_seed.h"
+#include "lh_sort.h"
+
+struct DChainTmp {
+    i64 pos, last_rbeg;
+    int32_t first_qbeg, last_qbeg, last_len, rid, n, head, tail, w, kept, first, beg, end;
+};
+struct DChain {
+    i64 pos;
+    int32_t rid, n, seed_start, w, kept, is_alt;
+    float frac_rep;
+    int32_t pad;
+};
+
+__global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
+                                               i64 pool_cap, const DSeed* __restrict__ seeds, const int32_t* __restrict__ s_rid,
+                                               const int32_t* __restrict__ l_rep, int32_t* __restrict__ s_next, DChainTmp* __restrict__ ct,
+                                               int32_t* __restrict__ ord, int32_t* __restrict__ srt, DChain* __restrict__ chains,
+                                               DSeed* __restrict__ cseeds, int32_t* __restrict__ n_chains, int32_t* __restrict__ status) {
+    int r = blockIdx.x, lane = LANE();
+    if (r >= n_reads) return;
+    i64 base = seed_off[r];
+    int S = (int)(seed_off[r + 1] - base);
+    if (seed_off[r + 1] > pool_cap) {   // pool overflow: flag, produce nothing (host retries with a smaller batch)
+        if (lane == 0) { n_chains[r] = 0; status[r] |= LH_ST_POOL_OVERFLOW; }
+        return;
+    }
+    int len = (int)(seq_off[r + 1] - seq_off[r]);
+    const DSeed* sd_ = seeds + base;
+    const int32_t* rid_ = s_rid + base;
+    int32_t* nx = s_next + base;
+    DChainTmp* C = ct + base;
+    int32_t* od = ord + base;
+    int32_t* st = srt + base;
+    int nch = 0;
+    for (int s = 0; s < S; ++s) {
+        int rid = rid_[s];
+        if (rid < 0) continue;   // bridging contigs / the forward-reverse boundary
+        DSeed p = sd_[s];
+        int to_add = 1, lo = 0;
+        if (nch > 0) {
+            int hi = nch;
+            while (lo < hi) { int m = (lo + hi) >> 1; if (C[od[m]].pos <= p.rbeg) lo = m + 1; else hi = m; }
+            if (lo > 0) {
+                int ci = od[lo - 1];
+                DChainTmp c = C[ci];
+                // test_and_merge
+                i64 qend = c.last_qbeg + c.last_len, rend = c.last_rbeg + c.last_len;
+                int res = 0;   // 0: new chain, 1: contained, 2: appended
+                if (rid != c.rid) res = 0;
+                else if (p.qbeg >= c.first_qbeg && p.qbeg + p.len <= qend && p.rbeg >= c.pos && p.rbeg + p.len <= rend) res = 1;
+                else if ((c.last_rbeg < ix.l_pac || c.pos < ix.l_pac) && p.rbeg >= ix.l_pac) res = 0;
+                else {
+                    i64 x = p.qbeg - c.last_qbeg, y = p.rbeg - c.last_rbeg;
+                    if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c.last_len < o.max_chain_gap && y - c.last_len < o.max_chain_gap) res = 2;
+                }
+                if (res == 2 && lane == 0) {
+                    nx[c.tail] = s; nx[s] = -1;
+                    C[ci].tail = s; C[ci].n = c.n + 1; C[ci].last_rbeg = p.rbeg; C[ci].last_qbeg = p.qbeg; C[ci].last_len = p.len;
+                }
+                to_add = (res == 0);
+            }
+        }
+        if (to_add) {
+            // insert chain id nch at sorted position lo: shift od[lo..nch) right by one, lane-parallel, from the top
+            for (int top = nch; top > lo; top -= 64) {
+                int j = top - 1 - lane;
+                int v = j >= lo ? od[j] : 0;
+                WAVE_SYNC();
+                if (j >= lo) od[j + 1] = v;
+                WAVE_SYNC();
+            }
+            if (lane == 0) {
+                od[lo] = nch;
+                DChainTmp c;
+                c.pos = p.rbeg; c.last_rbeg = p.rbeg; c.first_qbeg = p.qbeg; c.last_qbeg = p.qbeg; c.last_len = p.len; c.rid = rid;
+                c.n = 1; c.head = s; c.tail = s; c.w = 0; c.kept = 0; c.first = -1; c.beg = 0; c.end = 0;
+                C[nch] = c;
+                nx[s] = -1;
+            }
+            nch++;
+        }
+        WAVE_SYNC();
+    }
+    // mem_chain_weight for every chain (lane per chain), chn_beg / chn_end
+    for (int k = lane; k < nch; k += 64) {
+        DChainTmp c = C[k];
+        int w = 0;
+        i64 end = 0;
+        for (int s = c.head; s >= 0; s = nx[s]) {
+            DSeed t = sd_[s];
+            if (t.qbeg >= end) w += t.len;
+            else if (t.qbeg + t.len > end) w += t.qbeg + t.len - (int)end;
+            end = end > t.qbeg + t.len ? end : t.qbeg + t.len;
+        }
+        int tmp = w;
+        w = 0; end = 0;
+        for (int s = c.head; s >= 0; s = nx[s]) {
+            DSeed t = sd_[s];
+            if (t.rbeg >= end) w += t.len;
+            else if (t.rbeg + t.len > end) w += (int)(t.rbeg + t.len - end);
+            end = end > t.rbeg + t.len ? end : t.rbeg + t.len;
+        }
+        w = w < tmp ? w : tmp;
+        C[k].w = w < 1 << 30 ? w : (1 << 30) - 1;
+        C[k].beg = c.first_qbeg;
+        C[k].end = c.last_qbeg + c.last_len;
+    }
+    WAVE_SYNC();
+    // mem_chain_flt (order dependent): lane 0
+    if (lane == 0) {
+        int n = 0;
+        for (int k = 0; k < nch; ++k) {   // chains in position order (B-tree traversal), dropping light ones
+            int id = od[k];
+            C[id].first = -1; C[id].kept = 0;
+            if (C[id].w < o.min_chain_weight) continue;
+            st[n++] = id;
+        }
+        int nk = 0;   // kept-chain list reuses od[]
+        if (n > 0) {
+            dev_introsort(n, st, [&](int x, int y) { return C[x].w > C[y].w; });
+            C[st[0]].kept = 3;
+            od[nk++] = 0;
+            for (int i = 1; i < n; ++i) {
+                int large_ovlp = 0, k;
+                DChainTmp ai = C[st[i]];
+                for (k = 0; k < nk; ++k) {
+                    int j = od[k];
+                    DChainTmp aj = C[st[j]];
+                    int b_max = aj.beg > ai.beg ? aj.beg : ai.beg;
+                    int e_min = aj.end < ai.end ? aj.end : ai.end;
+                    if (e_min > b_max) {   // have overlap (no ALT contigs: is_alt == 0)
+                        int li = ai.end - ai.beg, lj = aj.end - aj.beg;
+                        int min_l = li < lj ? li : lj;
+                        if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {   // significant overlap
+                            large_ovlp = 1;
+                            if (aj.first < 0) C[st[j]].first = i;
+                            if (ai.w < aj.w * o.drop_ratio && aj.w - ai.w >= o.min_seed_len << 1) break;
+                        }
+                    }
+                }
+                if (k == nk) { od[nk++] = i; C[st[i]].kept = large_ovlp ? 2 : 3; }
+            }
+            for (int i = 0; i < nk; ++i) {
+                int f = C[st[od[i]]].first;
+                if (f >= 0) C[st[f]].kept = 1;
+            }
+            int i, k;
+            for (i = k = 0; i < n; ++i) {   // don't extend more than max_chain_extend .kept=1/2 chains
+                int kp = C[st[i]].kept;
+                if (kp == 0 || kp == 3) continue;
+                if (++k >= o.max_chain_extend) break;
+            }
+            for (; i < n; ++i)
+                if (C[st[i]].kept < 3) C[st[i]].kept = 0;
+        }
+        // emit kept chains in sorted order
+        int m = 0, sstart = 0;
+        for (int i = 0; i < n; ++i) {
+            DChainTmp c = C[st[i]];
+            if (c.kept == 0) continue;
+            DChain oc;
+            oc.pos = c.pos; oc.rid = c.rid; oc.n = c.n; oc.seed_start = sstart; oc.w = c.w; oc.kept = c.kept; oc.is_alt = 0;
+            oc.frac_rep = (float)l_rep[r] / len; oc.pad = st[i];   // pad carries the tmp id for the flatten step
+            chains[base + m] = oc;
+            sstart += c.n;
+            m++;
+        }
+        n_chains[r] = m;
+    }
+    WAVE_SYNC();
+    int m = n_chains[r];
+    for (int k = lane; k < m; k += 64) {   // flatten each chain's seed list
+        DChain oc = chains[base + k];
+        int s = C[oc.pad].head;
+        for (int t = 0; s >= 0; s = nx[s], ++t) cseeds[base + oc.seed_start + t] = sd_[s];
+    }
+}

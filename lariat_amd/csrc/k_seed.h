@@ -1,0 +1,90 @@
+// k_seed.h — K2: SA lookups (bwt_sa) for every sampled occurrence of every SMEM interval, one LANE per seed,
+// plus the exclusive scan that sizes the seed pool.  Replaces the `bwt_sa` / `bns_intv2rid` part of BWA's mem_chain
+// (reached through mem_align1_core, go/src/gobwa/gobwa.go:244,253).
+// Each lane chases ~sa_intv/2 dependent LF steps, every step one random 64-B occurrence block: pure HBM latency,
+// hidden by running one independent chain per lane.
+#pragma once
+#include "lh_dev.h"
+
+struct DSeed { i64 rbeg; int32_t qbeg, len; };
+
+// single-workgroup exclusive scan: out[i] = sum_{j<i} max(in[j] + add, floor_min); out[n] = total.  256 threads.
+__global__ void __launch_bounds__(256) k_scan_i32_to_i64(int n, const int32_t* __restrict__ in, int add, int at_least, i64* __restrict__ out) {
+    __shared__ i64 part[256];
+    __shared__ i64 carry_s;
+    int t = threadIdx.x;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    const int PER = 8;
+    for (int base = 0; base < n; base += 256 * PER) {
+        i64 loc[PER];
+        i64 sum = 0;
+        for (int u = 0; u < PER; ++u) {
+            int i = base + t * PER + u;
+            i64 v = 0;
+            if (i < n) { v = (i64)in[i] + add; if (v < at_least) v = at_least; }
+            loc[u] = sum;
+            sum += v;
+        }
+        part[t] = sum;
+        __syncthreads();
+        // Hillis-Steele inclusive scan over the 256 partial sums
+        for (int d = 1; d < 256; d <<= 1) {
+            i64 v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        i64 excl = (t ? part[t - 1] : 0) + carry_s;
+        for (int u = 0; u < PER; ++u) {
+            int i = base + t * PER + u;
+            if (i < n) out[i] = excl + loc[u];
+        }
+        __syncthreads();
+        if (t == 255) carry_s += part[255];
+        __syncthreads();
+    }
+    if (t == 0) out[n] = carry_s;
+}
+
+// K2.  one lane per seed; grid-stride over the pool.
+__global__ void __launch_bounds__(256) k_seed(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seed_off, i64 pool_cap,
+                                              const DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv, DSeed* __restrict__ seeds,
+                                              int32_t* __restrict__ s_rid, DCounters* __restrict__ ctr) {
+    i64 total = seed_off[n_reads];
+    if (total > pool_cap) total = pool_cap;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    i64 nrounds = (total + stride - 1) / stride;
+    for (i64 rd = 0; rd < nrounds; ++rd) {
+        i64 g = rd * stride + (i64)blockIdx.x * blockDim.x + threadIdx.x;
+        int nlf = 0, nsa = 0;
+        if (g < total) {
+            int lo = 0, hi = n_reads;   // largest r with seed_off[r] <= g
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (seed_off[mid] <= g) lo = mid; else hi = mid; }
+            int r = lo;
+            i64 u = g - seed_off[r];
+            const DIntv* iv = intv + (size_t)r * LH_MAX_INTV;
+            int n = n_intv[r];
+            u64 x0 = 0, step = 1, info = 0;
+            for (int t = 0; t < n; ++t) {
+                u64 s = iv[t].x2;
+                u64 st = s > (u64)o.max_occ ? s / (u64)o.max_occ : 1;
+                u64 c = (s + st - 1) / st;
+                if (c > (u64)o.max_occ) c = (u64)o.max_occ;
+                if ((u64)u < c) { x0 = iv[t].x0; step = st; info = iv[t].info; break; }
+                u -= (i64)c;
+            }
+            i64 rbeg = (i64)dev_sa(ix, x0 + (u64)u * step, &nlf);
+            nsa = 1;
+            int qbeg = (int)(info >> 32), slen = (int)(uint32_t)info - qbeg;
+            DSeed sd;
+            sd.rbeg = rbeg; sd.qbeg = qbeg; sd.len = slen;
+            seeds[g] = sd;
+            s_rid[g] = dev_intv2rid(ix, rbeg, rbeg + slen);
+        }
+        if (ctr) {
+            int tl = wave_sum_i32(nlf), ts = wave_sum_i32(nsa);
+            if (LANE() == 0 && ts) { atomicAdd(&ctr->n_lf, (u64)tl); atomicAdd(&ctr->n_sa, (u64)ts); }
+        }
+    }
+}

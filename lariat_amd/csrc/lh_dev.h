@@ -1,0 +1,224 @@
+// lh_dev.h — device-side common definitions for the gfx950 kernels.
+//
+// Compiles under hipcc (--offload-arch=gfx950; the product) and, with -DLH_EMU, under g++ against
+// tests/hipemu/hip_emu.h (a TEST-ONLY SPMD emulator used by the CPU test-suite; never shipped).
+//
+// Execution model used by every per-read / per-pair / per-barcode kernel here: ONE 64-lane wavefront per
+// work item, workgroup = 1 wave (blockDim.x == 64).  Control flow is wave-uniform; lanes either cooperate
+// (occurrence-block loads, DP rows, scans, ballots) or redundantly evaluate the same scalar state, and
+// only lane 0 stores scalar results.  WAVE_SYNC() orders lane-0 stores before the wave's later loads.
+#pragma once
+#include <stdint.h>
+
+#ifdef LH_EMU
+#include "hip_emu.h"
+#define LH_LAUNCH(kernel, grid, block, stream, ...) \
+    emu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
+struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
+#else
+#include <hip/hip_runtime.h>
+#define LH_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#endif
+
+#define LH_WAVE 64
+#define LH_MAXLEN 250            // LH_MAX_READ_LEN
+#define LH_MAX_INTV 64           // SMEM intervals kept per read (overflow -> status flag)
+#define LH_MAX_CIGAR 64          // cigar ops per candidate
+#define LH_MAX_MM 64             // mismatch loci per candidate
+#define LH_RESCUE_SLOTS 50       // opt->max_matesw / gobwa.go:287
+
+#define WAVE_SYNC() __syncthreads()
+#define LANE() ((int)(threadIdx.x & 63))
+
+typedef uint64_t u64;
+typedef int64_t i64;
+
+// status bits per read
+#define LH_ST_INTV_OVERFLOW 1
+#define LH_ST_TOO_LONG 2
+#define LH_ST_CIGAR_OVERFLOW 4
+#define LH_ST_MM_OVERFLOW 8
+#define LH_ST_POOL_OVERFLOW 16
+
+struct DIndex {
+    const uint32_t* bwt;     // occ-interleaved BWT exactly as in <prefix>.bwt: per 128 symbols [4 x u64 occ | 8 x u32 symbols]
+    const u64* sa;           // sampled SA, sa[0] = -1
+    const uint8_t* pac;      // 2-bit forward reference, MSB first
+    const i64* contig_off;   // [n_contigs]
+    const int32_t* contig_len;
+    u64 primary, L2[5], seq_len;
+    i64 l_pac;
+    int32_t sa_intv, n_contigs;
+};
+
+struct DOpts {   // mem_opt_t + lariat knobs, POD
+    int32_t a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, pen_clip5, pen_clip3, w, zdrop, T;
+    int32_t min_seed_len, min_chain_weight, max_chain_extend, split_width, max_occ, max_chain_gap, max_ins, max_mem_intv, max_matesw;
+    float split_factor, mask_level, drop_ratio, XA_drop_ratio, mask_level_redun, mapQ_coef_len;
+    int32_t pes_low, pes_high, rescue_score_delta, rescue_max_hits, aln_score_delta, run_inference;
+    double improper_pair_penalty, genome_length;
+    int8_t mat[25];
+};
+
+struct DIntv { u64 x0, x1, x2, info; };   // bwtintv_t
+
+struct DReg {   // mem_alnreg_t
+    i64 rb, re;
+    int32_t qb, qe, rid, score, truesc, sub, csub, w, seedcov, secondary, seedlen0, n_comp, is_alt;
+    float frac_rep;
+};
+
+struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells; };
+
+// ------------------------------------------------------------------ lane helpers
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src); hi = __shfl(hi, src);
+    return (u64)hi << 32 | lo;
+}
+__device__ __forceinline__ i64 shfl_i64(i64 v, int src) { return (i64)shfl_u64((u64)v, src); }
+__device__ __forceinline__ u64 shfl_up_u64(u64 v, int d) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_up(lo, d); hi = __shfl_up(hi, d);
+    return (u64)hi << 32 | lo;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v > o ? v : o; }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v < o ? v : o; }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+// inclusive prefix max over lanes
+__device__ __forceinline__ int wave_scan_max_i32(int v, int lane) {
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d); if (lane >= d) v = v > o ? v : o; }
+    return v;
+}
+__device__ __forceinline__ int lanes_below(u64 mask, int lane) { return __popcll(mask & ((1ull << lane) - 1)); }
+
+// ------------------------------------------------------------------ FM-index primitives (restated from BWA bwt.c)
+// packed per-base counts of the 16 symbols of w under the 2-bit-position mask `valid` (0x55555555 = all 16)
+__device__ __forceinline__ uint32_t occ_word(uint32_t w, uint32_t valid) {
+    uint32_t lo = w & valid, hi = (w >> 1) & valid;
+    uint32_t t = __popc(hi & lo), g = __popc(hi & ~lo), c = __popc(~hi & lo & valid);
+    uint32_t a = __popc(valid) - t - g - c;
+    return a | c << 8 | g << 16 | t << 24;
+}
+
+// bwt_occ4: occurrences of A,C,G,T in BWT[0..k] ($ removed at primary); k == -1 -> 0.  One lane reads one 64-B block.
+__device__ __forceinline__ void dev_occ4(const DIndex& ix, u64 k, u64 cnt[4]) {
+    if (k == (u64)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
+    k -= (k >= ix.primary);
+    const uint4* p = (const uint4*)(ix.bwt + ((k >> 7) << 4));
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    cnt[0] = (u64)a.y << 32 | a.x; cnt[1] = (u64)a.w << 32 | a.z;
+    cnt[2] = (u64)b.y << 32 | b.x; cnt[3] = (u64)b.w << 32 | b.z;
+    int nfull = (int)((k & 127) >> 4);
+    uint32_t pm = 0x55555555u & ~((1u << ((~(uint32_t)k & 15) << 1)) - 1);   // symbols 0..(k&15) of the partial word (MSB first)
+    uint32_t x = 0;
+#define LH_OCCW(t, wv) x += (t) < nfull ? occ_word(wv, 0x55555555u) : ((t) == nfull ? occ_word(wv, pm) : 0u)
+    LH_OCCW(0, c.x); LH_OCCW(1, c.y); LH_OCCW(2, c.z); LH_OCCW(3, c.w);
+    LH_OCCW(4, d.x); LH_OCCW(5, d.y); LH_OCCW(6, d.z); LH_OCCW(7, d.w);
+#undef LH_OCCW
+    cnt[0] += x & 0xff; cnt[1] += x >> 8 & 0xff; cnt[2] += x >> 16 & 0xff; cnt[3] += x >> 24;
+}
+
+// bwt_extend restricted to the one base `c` the caller follows: returns ok[c]
+__device__ __forceinline__ DIntv dev_extend_c(const DIndex& ix, const DIntv& ik, int c, int is_back) {
+    u64 tk[4], tl[4];
+    u64 xa = is_back ? ik.x0 : ik.x1;   // x[!is_back]
+    u64 xb = is_back ? ik.x1 : ik.x0;   // x[is_back]
+    dev_occ4(ix, xa - 1, tk);
+    dev_occ4(ix, xa - 1 + ik.x2, tl);
+    u64 s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+    u64 acc = xb + ((xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) ? 1 : 0);   // ok[3].x[is_back]
+    u64 o3 = acc, o2 = o3 + s3, o1 = o2 + s2, o0 = o1 + s1;
+    u64 na = c == 0 ? ix.L2[0] + 1 + tk[0] : c == 1 ? ix.L2[1] + 1 + tk[1] : c == 2 ? ix.L2[2] + 1 + tk[2] : ix.L2[3] + 1 + tk[3];
+    u64 nb = c == 0 ? o0 : c == 1 ? o1 : c == 2 ? o2 : o3;
+    DIntv o;
+    o.x2 = c == 0 ? s0 : c == 1 ? s1 : c == 2 ? s2 : s3;
+    if (is_back) { o.x0 = na; o.x1 = nb; } else { o.x1 = na; o.x0 = nb; }
+    o.info = 0;
+    return o;
+}
+
+__device__ __forceinline__ DIntv dev_set_intv(const DIndex& ix, int c) {
+    DIntv ik;
+    ik.x0 = ix.L2[c] + 1; ik.x2 = ix.L2[c + 1] - ix.L2[c]; ik.x1 = ix.L2[3 - c] + 1; ik.info = 0;
+    return ik;
+}
+
+// bwt_sa: walk inverse-Psi until a sampled row; *n_lf counts LF steps
+__device__ __forceinline__ u64 dev_sa(const DIndex& ix, u64 k, int* n_lf) {
+    u64 sa = 0, mask = (u64)ix.sa_intv - 1;
+    int steps = 0;
+    while (k & mask) {
+        ++sa; ++steps;
+        if (k == ix.primary) { k = 0; continue; }
+        u64 x = k - (k > ix.primary);
+        const uint32_t* blk = ix.bwt + ((x >> 7) << 4);
+        uint32_t c = blk[8 + ((x & 0x7f) >> 4)] >> ((~(uint32_t)x & 0xf) << 1) & 3;   // bwt_B0
+        u64 cnt[4];
+        dev_occ4(ix, k, cnt);
+        k = ix.L2[c] + (c == 0 ? cnt[0] : c == 1 ? cnt[1] : c == 2 ? cnt[2] : cnt[3]);
+    }
+    *n_lf = steps;
+    return sa + ix.sa[k / ix.sa_intv];
+}
+
+// ------------------------------------------------------------------ bntseq.c
+__device__ __forceinline__ int dev_pac(const uint8_t* pac, i64 l) { return pac[l >> 2] >> ((~l & 3) << 1) & 3; }
+// base at coordinate p of the fwd||rev reference
+__device__ __forceinline__ int dev_ref_base(const DIndex& ix, i64 p) {
+    return p < ix.l_pac ? dev_pac(ix.pac, p) : 3 - dev_pac(ix.pac, (ix.l_pac << 1) - 1 - p);
+}
+__device__ __forceinline__ int dev_pos2rid(const DIndex& ix, i64 pos_f) {
+    int left, mid, right;
+    if (pos_f >= ix.l_pac) return -1;
+    left = 0; mid = 0; right = ix.n_contigs;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= ix.contig_off[mid]) {
+            if (mid == ix.n_contigs - 1) break;
+            if (pos_f < ix.contig_off[mid + 1]) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+__device__ __forceinline__ i64 dev_depos(const DIndex& ix, i64 pos, int* is_rev) {
+    return (*is_rev = (pos >= ix.l_pac)) ? (ix.l_pac << 1) - 1 - pos : pos;
+}
+__device__ __forceinline__ int dev_intv2rid(const DIndex& ix, i64 rb, i64 re) {
+    int is_rev, rid_b, rid_e;
+    if (rb < ix.l_pac && re > ix.l_pac) return -2;
+    rid_b = dev_pos2rid(ix, dev_depos(ix, rb, &is_rev));
+    rid_e = rb < re ? dev_pos2rid(ix, dev_depos(ix, re - 1, &is_rev)) : rid_b;
+    return rid_b == rid_e ? rid_b : -1;
+}
+// bns_fetch_seq's clamping: [*beg,*end) restricted to the contig (on the strand of mid) that contains mid
+__device__ __forceinline__ int dev_fetch_clamp(const DIndex& ix, i64* beg, i64 mid, i64* end) {
+    int is_rev;
+    if (*end < *beg) { i64 t = *beg; *beg = *end; *end = t; }
+    int rid = dev_pos2rid(ix, dev_depos(ix, mid, &is_rev));
+    i64 far_beg = ix.contig_off[rid], far_end = far_beg + ix.contig_len[rid];
+    if (is_rev) { i64 t = far_beg; far_beg = (ix.l_pac << 1) - far_end; far_end = (ix.l_pac << 1) - t; }
+    *beg = *beg > far_beg ? *beg : far_beg;
+    *end = *end < far_end ? *end : far_end;
+    return rid;
+}
+
+__device__ __forceinline__ int dev_cal_max_gap(const DOpts& o, int qlen) {
+    int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+    int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+    int l = l_del > l_ins ? l_del : l_ins;
+    l = l > 1 ? l : 1;
+    return l < o.w << 1 ? l : o.w << 1;
+}

@@ -1,0 +1,179 @@
+// lh_sort.h — sequential (single-lane) device sorts whose tie order is part of the result contract.
+//   dev_introsort : the unstable introsort BWA applies (via klib's KSORT_INIT) to chains (by weight), alignment
+//                   regions (by end, then by score) and the per-chain seed order — reached through
+//                   mem_align1_core / mem_matesw (go/src/gobwa/gobwa.go:244,253,291,315).
+//   dev_gosort    : Go 1.9's sort.Sort as used by lariat at go/src/inference/lariat.go:1546 (ByPosition) and
+//                   go/src/inference/split.go:108 (SortSplitScoring).
+// Equal keys keep whatever order the comparison/swap sequence of these exact algorithms produces, so both are
+// implemented as the same algorithms (on small index arrays, by one lane).
+#pragma once
+#include "lh_dev.h"
+
+template <class T, class Lt> __device__ inline void dev_insertsort(T* s, T* t, Lt lt) {
+    for (T* i = s + 1; i < t; ++i)
+        for (T* j = i; j > s && lt(*j, *(j - 1)); --j) { T tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
+}
+
+template <class T, class Lt> __device__ inline void dev_combsort(int n, T* a, Lt lt) {
+    const double shrink_factor = 1.2473309501039786540366528676643;
+    int do_swap;
+    int gap = n;
+    do {
+        if (gap > 2) {
+            gap = (int)(gap / shrink_factor);
+            if (gap == 9 || gap == 10) gap = 11;
+        }
+        do_swap = 0;
+        for (T* i = a; i < a + n - gap; ++i) {
+            T* j = i + gap;
+            if (lt(*j, *i)) { T tmp = *i; *i = *j; *j = tmp; do_swap = 1; }
+        }
+    } while (do_swap || gap > 2);
+    if (gap != 1) dev_insertsort(a, a + n, lt);
+}
+
+template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, Lt lt) {
+    struct Stk { T *left, *right; int depth; };
+    Stk stack[72];
+    int d;
+    T rp, swap_tmp;
+    T *s, *t, *i, *j, *k;
+    if (n < 1) return;
+    else if (n == 2) {
+        if (lt(a[1], a[0])) { swap_tmp = a[0]; a[0] = a[1]; a[1] = swap_tmp; }
+        return;
+    }
+    for (d = 2; (1ul << d) < (unsigned long)n; ++d) {}
+    Stk* top = stack;
+    s = a; t = a + (n - 1); d <<= 1;
+    while (1) {
+        if (s < t) {
+            if (--d == 0) {
+                dev_combsort((int)(t - s + 1), s, lt);
+                t = s;
+                continue;
+            }
+            i = s; j = t; k = i + ((j - i) >> 1) + 1;
+            if (lt(*k, *i)) {
+                if (lt(*k, *j)) k = j;
+            } else k = lt(*j, *i) ? i : j;
+            rp = *k;
+            if (k != t) { swap_tmp = *k; *k = *t; *t = swap_tmp; }
+            for (;;) {
+                do ++i; while (lt(*i, rp));
+                do --j; while (i <= j && lt(rp, *j));
+                if (j <= i) break;
+                swap_tmp = *i; *i = *j; *j = swap_tmp;
+            }
+            swap_tmp = *i; *i = *t; *t = swap_tmp;
+            if (i - s > t - i) {
+                if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { top->left = i + 1; top->right = t; top->depth = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+        } else {
+            if (top == stack) {
+                dev_insertsort(a, a + n, lt);
+                return;
+            } else { --top; s = top->left; t = top->right; d = top->depth; }
+        }
+    }
+}
+
+// ---- Go 1.9 sort.Sort over an index space [0,n): less(i,j), swp(i,j) ----
+template <class L, class S> __device__ inline void gs_insertion(L& less, S& swp, int a, int b) {
+    for (int i = a + 1; i < b; i++)
+        for (int j = i; j > a && less(j, j - 1); j--) swp(j, j - 1);
+}
+template <class L, class S> __device__ inline void gs_siftdown(L& less, S& swp, int lo, int hi, int first) {
+    int root = lo;
+    for (;;) {
+        int child = 2 * root + 1;
+        if (child >= hi) return;
+        if (child + 1 < hi && less(first + child, first + child + 1)) child++;
+        if (!less(first + root, first + child)) return;
+        swp(first + root, first + child);
+        root = child;
+    }
+}
+template <class L, class S> __device__ inline void gs_heapsort(L& less, S& swp, int a, int b) {
+    int first = a, lo = 0, hi = b - a;
+    for (int i = (hi - 1) / 2; i >= 0; i--) gs_siftdown(less, swp, i, hi, first);
+    for (int i = hi - 1; i >= 0; i--) { swp(first, first + i); gs_siftdown(less, swp, lo, i, first); }
+}
+template <class L, class S> __device__ inline void gs_median3(L& less, S& swp, int m1, int m0, int m2) {
+    if (less(m1, m0)) swp(m1, m0);
+    if (less(m2, m1)) { swp(m2, m1); if (less(m1, m0)) swp(m1, m0); }
+}
+template <class L, class S> __device__ inline void gs_pivot(L& less, S& swp, int lo, int hi, int* midlo, int* midhi) {
+    int m = (int)((unsigned)(lo + hi) >> 1);
+    if (hi - lo > 40) {
+        int s = (hi - lo) / 8;
+        gs_median3(less, swp, lo, lo + s, lo + 2 * s);
+        gs_median3(less, swp, m, m - s, m + s);
+        gs_median3(less, swp, hi - 1, hi - 1 - s, hi - 1 - 2 * s);
+    }
+    gs_median3(less, swp, lo, m, hi - 1);
+    int pivot = lo;
+    int a = lo + 1, c = hi - 1;
+    for (; a < c && less(a, pivot); a++) {}
+    int b = a;
+    for (;;) {
+        for (; b < c && !less(pivot, b); b++) {}
+        for (; b < c && less(pivot, c - 1); c--) {}
+        if (b >= c) break;
+        swp(b, c - 1);
+        b++; c--;
+    }
+    bool protect = hi - c < 5;
+    if (!protect && hi - c < (hi - lo) / 4) {
+        int dups = 0;
+        if (!less(pivot, hi - 1)) { swp(c, hi - 1); c++; dups++; }
+        if (!less(b - 1, pivot)) { b--; dups++; }
+        if (!less(m, pivot)) { swp(m, b - 1); b--; dups++; }
+        protect = dups > 1;
+    }
+    if (protect) {
+        for (;;) {
+            for (; a < b && !less(b - 1, pivot); b--) {}
+            for (; a < b && less(a, pivot); a++) {}
+            if (a >= b) break;
+            swp(a, b - 1);
+            a++; b--;
+        }
+    }
+    swp(pivot, b - 1);
+    *midlo = b - 1; *midhi = c;
+}
+template <class L, class S> __device__ inline void dev_gosort(int n, L less, S swp) {
+    // quickSort(data, 0, n, maxDepth(n)) with the recursion on the smaller side turned into an explicit stack
+    struct Fr { int a, b, depth; };
+    Fr st[72];
+    int sp = 0;
+    int depth = 0;
+    for (int i = n; i > 0; i >>= 1) depth++;
+    st[sp++] = Fr{0, n, depth * 2};
+    while (sp > 0) {
+        Fr f = st[--sp];
+        int a = f.a, b = f.b, maxDepth = f.depth;
+        bool done = false;
+        while (b - a > 12) {
+            if (maxDepth == 0) { gs_heapsort(less, swp, a, b); done = true; break; }
+            maxDepth--;
+            int mlo, mhi;
+            gs_pivot(less, swp, a, b, &mlo, &mhi);
+            // Go recurses into the smaller side FIRST and then loops on the larger one.  The two sides are disjoint
+            // index ranges, so finishing the larger side later (explicit stack) issues the same Less/Swap calls per range.
+            if (mlo - a < b - mhi) { st[sp++] = Fr{mhi, b, maxDepth}; b = mlo; }
+            else { st[sp++] = Fr{a, mlo, maxDepth}; a = mhi; }
+        }
+        if (done) continue;
+        if (b - a > 1) {
+            for (int i = a + 6; i < b; i++)
+                if (less(i, i - 6)) swp(i, i - 6);
+            gs_insertion(less, swp, a, b);
+        }
+    }
+}

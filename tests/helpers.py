@@ -49,3 +49,45 @@ def small_reads(names, contigs, n_barcodes=8, pairs=40, seed=5, junk=0.02):
 
 def batch_of(rs):
     return capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed)
+
+
+DUMP_FRONT = ["intv_off", "intv", "seed_off", "seed_rbeg", "seed_qbeg", "seed_len", "seed_rid", "chain_off", "chain_nseeds", "chain_rid", "chain_w",
+              "chain_kept", "chain_pos"]
+DUMP_REGS = ["reg_off", "reg_rb", "reg_re", "reg_qb", "reg_qe", "reg_rid", "reg_score", "reg_truesc", "reg_w", "reg_seedcov", "reg_seedlen0", "reg_csub",
+             "reg_secondary"]
+
+
+def assert_same_dump(d, od, fields):
+    for f in fields:
+        a, b = getattr(d, f), getattr(od, f)
+        assert a.shape == b.shape, (f, a.shape, b.shape)
+        if not (a == b).all():
+            bad = np.nonzero((a != b).reshape(len(a), -1).any(axis=1))[0]
+            raise AssertionError("stage dump field %s differs at %s (got %s want %s)" % (f, bad[:5], a[bad[:3]], b[bad[:3]]))
+
+
+INT_FIELDS = ["cand_off", "rid", "pos", "aend", "rb", "re", "reversed", "score", "qb", "qe", "nm", "matches", "mismatches", "indels", "soft_clipped",
+              "soft_clipped_length", "in_filtered", "cigar_off", "cigar", "mm_off", "mm_ref_loc", "mm_read_loc"]
+INF_FIELDS = ["active", "is_proper", "bwa_pick", "active_molecule", "duplicate", "molecule_id", "mate_idx", "active_idx", "second_best_idx", "split_idx",
+              "split_mapq"]
+F64_FIELDS = ["log_alignment_probability", "molecule_difference", "molecule_confidence", "sum_move_probability_change", "second_best_score", "as_score",
+              "split_second_best", "split_score"]
+
+
+def assert_same_result(r, ref, inference=True, mapq_tol=1, rel=1e-9):
+    """bit-exact for integer/index fields; MAPQ within +-1; float scores within 1e-9 relative (BASELINE.json north_star)"""
+    for f in INT_FIELDS + (INF_FIELDS if inference else []):
+        a, b = getattr(r, f), getattr(ref, f)
+        assert a.shape == b.shape, (f, a.shape, b.shape)
+        if not (a == b).all():
+            bad = np.nonzero(a != b)[0]
+            raise AssertionError("result field %s differs at %s (got %s want %s)" % (f, bad[:5], a[bad[:5]], b[bad[:5]]))
+    fl = ["log_alignment_probability"] + (F64_FIELDS[1:] if inference else [])
+    for f in fl:
+        a, b = getattr(r, f), getattr(ref, f)
+        assert a.shape == b.shape, f
+        ok = np.isclose(a, b, rtol=rel, atol=1e-12, equal_nan=True)
+        assert ok.all(), (f, np.nonzero(~ok)[0][:5], a[~ok][:5], b[~ok][:5])
+    if inference:
+        d = np.abs(r.mapq.astype(np.int64) - ref.mapq.astype(np.int64))
+        assert (d <= mapq_tol).all(), ("mapq", np.nonzero(d > mapq_tol)[0][:5])

@@ -1,0 +1,34 @@
+"""Kernel SOURCES of the front end run under the CPU SPMD emulator (tests/hipemu) and diffed against the oracle.
+This is a logic check that works without a GPU; the `-m gpu` tests are the parity tests proper."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from lariat_amd import capi
+
+EMU = os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "hipemu")])
+    return capi.Library(EMU)
+
+
+def test_emu_phix_front(emu, oracle):
+    idx = emu.index_load(helpers.PHIX)
+    oidx = oracle.index_load(helpers.PHIX)
+    b = capi.Batch([capi.sequence_convert(helpers.PHIX_READ_A), capi.sequence_convert(helpers.PHIX_READ_B)], [0, 1])
+    helpers.assert_same_dump(idx.context(8).stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT)
+
+
+def test_emu_front_synthetic(emu, oracle):
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=3, pairs=30, junk=0.05)
+    b = helpers.batch_of(rs)
+    helpers.assert_same_dump(idx.context(rs.n_pairs).stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT)

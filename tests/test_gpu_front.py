@@ -1,0 +1,35 @@
+"""GPU parity of the candidate-generation front end (K1 SMEM, K2 SA lookup, K3 chaining) against the oracle,
+through the C-ABI.  Runs on the MI355X box only."""
+import numpy as np
+import pytest
+
+import helpers
+from lariat_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = capi.load_library()
+    assert L.device_count() >= 1
+    return L
+
+
+def test_phix_kat_front(lib, oracle):
+    idx = lib.index_load(helpers.PHIX)
+    oidx = oracle.index_load(helpers.PHIX)
+    b = capi.Batch([capi.sequence_convert(helpers.PHIX_READ_A), capi.sequence_convert(helpers.PHIX_READ_B)], [0, 1])
+    d = idx.context(8).stage_dump(b)
+    helpers.assert_same_dump(d, oidx.stage_dump(b), helpers.DUMP_FRONT)
+    assert list(d.seed_rbeg[:2]) == [210, 210]
+
+
+def test_front_synthetic(lib, oracle):
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=20, pairs=100, junk=0.03)
+    b = helpers.batch_of(rs)
+    d = idx.context(rs.n_pairs).stage_dump(b)
+    helpers.assert_same_dump(d, oidx.stage_dump(b), helpers.DUMP_FRONT)
