@@ -1,0 +1,240 @@
+// k_aln.h — K7: region -> alignment.  Per candidate: BWA mem_reg2aln (band inference, bwa_gen_cigar2 -> ksw_global2 with
+// traceback, NM, clip ops; go/src/gobwa/gobwa.go:400-415,449-488), bns_fetch_seq (gobwa.go:50-80) and lariat's
+// GetAlignments CIGAR walk (go/src/inference/lariat.go:1552-1704): matches / mismatches / indels / soft clips /
+// mismatch loci / log_alignment_probability / the best-17 filter.  One wavefront per read, looping over its candidates.
+#pragma once
+#include "k_rescue.h"
+
+#define LH_MAXT 704                       // reference bases staged per candidate (re - rb)
+#define LH_ZSLAB (LH_MAXT * 256)          // direction bytes per resident wave
+
+struct DCand {   // device-side result arrays (one entry per candidate unless noted)
+    i64* cand_off;   // [n_reads+1] (input)
+    int32_t* rid; i64* pos; i64* aend; i64* rb; i64* re; uint8_t* reversed; int32_t* score; int32_t* qb; int32_t* qe; int32_t* nm;
+    int32_t* matches; int32_t* mismatches; int32_t* indels; int32_t* soft_clipped; int32_t* soft_clipped_length; uint8_t* in_filtered;
+    int32_t* n_cigar; uint32_t* cigar;   // LH_MAX_CIGAR slots per candidate
+    int32_t* n_mm; int32_t* mm_ref; int32_t* mm_read;   // LH_MAX_MM slots per candidate
+    double* lap;
+    int32_t* read_len;   // per candidate (psuedoCountAlignmentScore needs len(read_seq))
+};
+
+__device__ __forceinline__ int dev_infer_bw(int l1, int l2, int score, int a, int q, int r) {
+    int w;
+    if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;   // to get equal alignment length, we need at least two gaps
+    w = (int)(((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.));
+    int d = l1 - l2; d = d < 0 ? -d : d;
+    if (w < d) w = d;
+    return w;
+}
+
+// lariat.go:599-624 scoreAlignment(aln, nil, 0) - improper  ==  log_alignment_probability (lariat.go:1691)
+__device__ __forceinline__ double dev_single_score(int mismatches, int indels, int soft_clipped, int soft_clipped_length) {
+    double score = 0.0;
+    score += (double)(mismatches * -2 + indels * -3);
+    if (soft_clipped > 0) {
+        score -= 5.0 * (double)soft_clipped;
+        score -= (double)soft_clipped_length * 0.5;
+    }
+    return score;
+}
+
+__global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+                                             const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R,
+                                             uint8_t* __restrict__ zpool, int32_t* __restrict__ status, DCounters* __restrict__ ctr) {
+    __shared__ uint8_t q[LH_MAXLEN + 6];
+    __shared__ uint8_t tref[LH_MAXT];
+    __shared__ uint32_t cg[LH_MAX_CIGAR + 4];
+    __shared__ int32_t sh[8];
+    int lane = LANE();
+    uint8_t* z = zpool + (size_t)blockIdx.x * LH_ZSLAB;
+    u64 cells = 0;
+    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        i64 off = seq_off[r];
+        int l_query = (int)(seq_off[r + 1] - off);
+        if (l_query > LH_MAXLEN) l_query = 0;
+        WAVE_SYNC();
+        for (int i = lane; i < l_query; i += 64) q[i] = seq[off + i];
+        WAVE_SYNC();
+        const DReg* av = regs + reg_off[r];
+        int n = n_regs[r];
+        i64 c0 = R.cand_off[r];
+        int st = 0;
+        if (n == 0) {   // placeholder (lariat.go:1737-1750,1773-1785): contig "", pos -1, aend 0, score 0
+            if (lane == 0) {
+                i64 c = c0;
+                R.rid[c] = -1; R.pos[c] = -1; R.aend[c] = 0; R.rb[c] = -1; R.re[c] = -1; R.reversed[c] = 0; R.score[c] = 0; R.qb[c] = 0; R.qe[c] = 0;
+                R.nm[c] = 0; R.matches[c] = 0; R.mismatches[c] = 0; R.indels[c] = 0; R.soft_clipped[c] = 0; R.soft_clipped_length[c] = 0;
+                R.in_filtered[c] = 1; R.n_cigar[c] = 0; R.n_mm[c] = 0; R.read_len[c] = l_query;
+                R.lap[c] = (dev_single_score(0, 0, 0, 0) + o.improper_pair_penalty) - o.improper_pair_penalty;
+            }
+            continue;
+        }
+        int best = 0;
+        for (int i = lane; i < n; i += 64) { int s = av[i].score; best = best > s ? best : s; }
+        best = wave_max_i32(best);
+        for (int ci = 0; ci < n; ++ci) {
+            DReg ar = av[ci];
+            i64 c = c0 + ci;
+            int qb = ar.qb, qe = ar.qe, lq = qe - qb;
+            i64 rb = ar.rb, re = ar.re;
+            int rlen = (int)(re - rb);
+            int rev = rb >= ix.l_pac;
+            // oriented views: reverse BOTH sequences on the reverse strand so that indels are left-aligned on the forward strand
+            int qoff = rev ? qe - 1 : qb, qstep = rev ? -1 : 1;
+            i64 t0 = rev ? re - 1 : rb;
+            int tstep = rev ? -1 : 1;
+            int valid = lq > 0 && rb < re && !(rb < ix.l_pac && re > ix.l_pac) && rlen <= LH_MAXT;
+            WAVE_SYNC();
+            if (valid)
+                for (int i = lane; i < rlen; i += 64) tref[i] = (uint8_t)dev_ref_base(ix, t0 + (i64)tstep * i);
+            WAVE_SYNC();
+            // mem_reg2aln: band inference and up to 3 global alignments with doubling band
+            int tmp = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_del, o.e_del);
+            int w2 = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_ins, o.e_ins);
+            w2 = w2 > tmp ? w2 : tmp;
+            if (w2 > o.w) w2 = w2 < ar.w ? w2 : ar.w;
+            int score = 0, last_sc = -(1 << 30), n_cigar = 0, NM = -1, it = 0;
+            int overflow = 0;
+            do {
+                w2 = w2 < o.w << 2 ? w2 : o.w << 2;
+                n_cigar = 0; NM = -1;
+                if (valid) {
+                    if (lq == rlen && w2 == 0) {   // no gap; no need to do DP
+                        int sc = 0;
+                        for (int i = lane; i < lq; i += 64) {
+                            int tb = tref[i], qv = q[qoff + qstep * i];
+                            sc += (tb > 3 || qv > 3) ? -1 : (tb == qv ? o.a : -o.b);
+                        }
+                        score = wave_sum_i32(sc);
+                        if (lane == 0) cg[0] = (uint32_t)lq << 4 | 0;
+                        n_cigar = 1;
+                    } else {
+                        int max_ins = (int)((double)(((lq + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
+                        int max_del = (int)((double)(((lq + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
+                        int max_gap = max_ins > max_del ? max_ins : max_del;
+                        max_gap = max_gap > 1 ? max_gap : 1;
+                        int dl = rlen - lq; dl = dl < 0 ? -dl : dl;
+                        int w = (max_gap + dl + 1) >> 1;
+                        w = w < w2 ? w : w2;
+                        int min_w = dl + 3;
+                        w = w > min_w ? w : min_w;
+                        score = wave_ksw_global2(ix, o, q, qoff, qstep, lq, t0, tstep, rlen, w, z, lane, &cells);
+                        WAVE_SYNC();
+                        if (lane == 0) {   // backtrack
+                            int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
+                            int which = 0, nc = 0, ovf = 0;
+                            int i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
+                            // ops are produced last-to-first; push_cigar merges equal neighbours
+                            while (i >= 0 && k >= 0) {
+                                which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+                                int op, len = 1;
+                                if (which == 0) { op = 0; --i; --k; }
+                                else if (which == 1) { op = 2; --i; }
+                                else { op = 1; --k; }
+                                if (nc == 0 || op != (int)(cg[nc - 1] & 0xf)) { if (nc < LH_MAX_CIGAR) cg[nc++] = (uint32_t)len << 4 | op; else ovf = 1; }
+                                else cg[nc - 1] += (uint32_t)len << 4;
+                            }
+                            if (i >= 0) { if (nc == 0 || 2 != (int)(cg[nc - 1] & 0xf)) { if (nc < LH_MAX_CIGAR) cg[nc++] = (uint32_t)(i + 1) << 4 | 2; else ovf = 1; } else cg[nc - 1] += (uint32_t)(i + 1) << 4; }
+                            if (k >= 0) { if (nc == 0 || 1 != (int)(cg[nc - 1] & 0xf)) { if (nc < LH_MAX_CIGAR) cg[nc++] = (uint32_t)(k + 1) << 4 | 1; else ovf = 1; } else cg[nc - 1] += (uint32_t)(k + 1) << 4; }
+                            for (int u = 0; u < nc >> 1; ++u) { uint32_t t = cg[u]; cg[u] = cg[nc - 1 - u]; cg[nc - 1 - u] = t; }   // reverse CIGAR
+                            sh[0] = nc; sh[1] = ovf;
+                        }
+                        WAVE_SYNC();
+                        n_cigar = sh[0]; overflow |= sh[1];
+                    }
+                    // NM: mismatches inside M runs + inserted + deleted bases (terminal D excluded)
+                    if (lane == 0) {
+                        int x = 0, y = 0, n_mm = 0, n_gap = 0;
+                        for (int k = 0; k < n_cigar; ++k) {
+                            int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
+                            if (op == 0) {
+                                for (int i = 0; i < len; ++i)
+                                    if (q[qoff + qstep * (x + i)] != tref[y + i]) ++n_mm;
+                                x += len; y += len;
+                            } else if (op == 2) {
+                                if (k > 0 && k < n_cigar - 1) n_gap += len;
+                                y += len;
+                            } else if (op == 1) { x += len; n_gap += len; }
+                        }
+                        sh[2] = n_mm + n_gap;
+                    }
+                    WAVE_SYNC();
+                    NM = sh[2];
+                }
+                if (score == last_sc || w2 == o.w << 2) break;   // it is possible that global alignment and local alignment give different scores
+                last_sc = score;
+                w2 <<= 1;
+            } while (++it < 3 && score < ar.truesc - o.a);
+            // position, clipping, then lariat's CIGAR walk: all sequential, lane 0
+            if (lane == 0) {
+                int is_rev;
+                i64 posf = dev_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+                int nc = n_cigar;
+                int s0 = 0;   // first live op in cg[]
+                if (nc > 0) {   // squeeze out leading or trailing deletions (pos is shifted upstream, but lariat ignores that pos)
+                    if ((cg[0] & 0xf) == 2) { s0 = 1; nc--; }
+                    else if ((cg[nc - 1] & 0xf) == 2) nc--;
+                }
+                uint32_t* out = R.cigar + (size_t)c * LH_MAX_CIGAR;
+                int no = 0;
+                int clip5 = 0, clip3 = 0;
+                if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
+                if (clip5) out[no++] = (uint32_t)clip5 << 4 | 3;
+                for (int u = 0; u < nc && no < LH_MAX_CIGAR; ++u) out[no++] = cg[s0 + u];
+                if (clip3) { if (no < LH_MAX_CIGAR) out[no++] = (uint32_t)clip3 << 4 | 3; else overflow = 1; }
+                if (nc + (clip5 ? 1 : 0) > LH_MAX_CIGAR) overflow = 1;
+                int rid = dev_pos2rid(ix, posf);
+                i64 coff = ix.contig_off[ar.rid];
+                // InterpretAlign (gobwa.go:339-371)
+                i64 Offset = rb < ix.l_pac ? rb - coff : ix.l_pac * 2 - 1 - rb - coff;
+                i64 End = re < ix.l_pac ? re - coff : ix.l_pac * 2 - 1 - re - coff;
+                i64 refStart = Offset, refEnd = End;
+                if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
+                // CIGAR walk in READ orientation (lariat.go:1591-1632).  refSeq[k] == base at fwd||rev coordinate rb + k.
+                int matches = 0, indels = 0, indel_length = 0, soft_clipping = 0, soft_clipping_length = 0, refSeqOffset = 0, readOffset = 0, nmm = 0, mm_ovf = 0;
+                int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
+                int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
+                int refLen = (int)(refEnd - refStart);
+                for (int u = 0; u < no; ++u) {
+                    uint32_t cv = out[is_rev ? no - 1 - u : u];
+                    int op = cv & 0xf, len = (int)(cv >> 4);
+                    if (op == 0) {
+                        matches += len;
+                        for (int t = 0; t < len; ++t) {
+                            int k = refSeqOffset + t;
+                            if (k >= refLen) continue;
+                            if (readOffset + t >= l_query) break;
+                            int rbase = (valid && k < rlen) ? tref[rev ? rlen - 1 - k : k] : 255;
+                            if (rbase != q[readOffset + t]) {
+                                if (nmm < LH_MAX_MM) {
+                                    mref[nmm] = is_rev ? (int)refEnd - k : k + (int)refStart;
+                                    mread[nmm] = readOffset + t;
+                                    nmm++;
+                                } else mm_ovf = 1;
+                            }
+                        }
+                        refSeqOffset += len; readOffset += len;
+                    } else if (op == 1) { indels += 1; indel_length += len; readOffset += len; }
+                    else if (op == 2) { indels += 1; indel_length += len; refSeqOffset += len; }
+                    else if (op == 3) { soft_clipping += 1; soft_clipping_length += len; readOffset += len; }
+                }
+                int mismatches = NM - indel_length;
+                matches -= mismatches;
+                if (mismatches < 0) mismatches = 0;
+                i64 pos = Offset, aend = End;
+                if (pos != -1 && is_rev) { pos = End + 1; aend = Offset + 1; }
+                R.rid[c] = rid; R.pos[c] = pos; R.aend[c] = aend; R.rb[c] = rb; R.re[c] = re; R.reversed[c] = (uint8_t)is_rev; R.score[c] = ar.score;
+                R.qb[c] = qb; R.qe[c] = qe; R.nm[c] = NM; R.matches[c] = matches; R.mismatches[c] = mismatches; R.indels[c] = indels;
+                R.soft_clipped[c] = soft_clipping; R.soft_clipped_length[c] = soft_clipping_length;
+                R.in_filtered[c] = ar.score >= best - o.aln_score_delta;
+                R.n_cigar[c] = no; R.n_mm[c] = nmm; R.read_len[c] = l_query;
+                R.lap[c] = (dev_single_score(mismatches, indels, soft_clipping, soft_clipping_length) + o.improper_pair_penalty) - o.improper_pair_penalty;
+                if (overflow) st |= LH_ST_CIGAR_OVERFLOW;
+                if (mm_ovf) st |= LH_ST_MM_OVERFLOW;
+                if (!valid) st |= LH_ST_TOO_LONG;
+            }
+        }
+        if (lane == 0 && st) status[r] |= st;
+    }
+    if (lane == 0 && ctr && cells) atomicAdd(&ctr->glob_cells, cells);
+}

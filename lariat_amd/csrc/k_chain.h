@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
             if (lo > 0) {
                 int ci = od[lo - 1];
                 DChainTmp c = C[ci];
+                WAVE_SYNC();   // every lane has its copy before lane 0 updates the chain
                 // test_and_merge
                 i64 qend = c.last_qbeg + c.last_len, rend = c.last_rbeg + c.last_len;
                 int res = 0;   // 0: new chain, 1: contained, 2: appended

@@ -1,0 +1,132 @@
+// k_dedup.h — K5: mem_sort_dedup_patch (+ mem_patch_reg), one wavefront per read.
+// Reached through mem_align1_core (go/src/gobwa/gobwa.go:244,253) with patching, and through mem_matesw
+// (gobwa.go:291,315) without (bns == 0).
+//
+// The two unstable introsorts and the order-dependent pairwise exclusion run on lane 0 over an index array; the one
+// heavy step — mem_patch_reg's global re-alignment score — is a wave-parallel DP (k_global.h), so the pairwise loop is
+// wave-uniform and every lane follows it.
+#pragma once
+#include "k_global.h"
+
+#define LH_PATCH_MAX_R_BW 0.05f
+#define LH_PATCH_MIN_SC_RATIO 0.90f
+
+// mem_patch_reg; a = earlier region (q), b = later region (p).  Returns the merged score (>0) or 0.
+__device__ __forceinline__ int wave_patch_reg(const DIndex& ix, const DOpts& o, const uint8_t* q, const DReg& a, const DReg& b, int* w_out, int lane, u64* cells) {
+    if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;                 // on different strands
+    if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;        // not colinear
+    int w = (int)((a.re - b.rb) - (a.qe - b.qb));                      // required bandwidth
+    w = w > 0 ? w : -w;
+    double r = (double)(a.re - b.rb) / (double)(b.re - a.rb) - (double)(a.qe - b.qb) / (double)(b.qe - a.qb);   // relative bandwidth
+    r = r > 0. ? r : -r;
+    if (a.re < b.rb || a.qe < b.qb) {   // no overlap on query or on ref
+        if (w > o.w << 1 || r >= LH_PATCH_MAX_R_BW) return 0;
+    } else if (w > o.w << 2 || r >= LH_PATCH_MAX_R_BW * 2) return 0;
+    w += a.w + b.w;
+    w = w < o.w << 2 ? w : o.w << 2;
+    int ok;
+    int score = wave_gen_score(ix, o, q, a.qb, b.qe - a.qb, w, a.rb, b.re, lane, &ok, cells);
+    if (!ok) return 0;
+    int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);   // predicted score from query
+    int r_s = (int)((double)(b.re - a.rb) / (double)((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);   // predicted score from ref
+    if ((double)score / (q_s > r_s ? q_s : r_s) < LH_PATCH_MIN_SC_RATIO) return 0;
+    *w_out = w;
+    return score;
+}
+
+// mem_sort_dedup_patch over av[0..n).  ia: int scratch [n]; tmp: DReg scratch [n].  Returns the new count (uniform).
+__device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOpts& o, const uint8_t* q, DReg* av, int n, int32_t* ia, DReg* tmp,
+                                                     int do_patch, int lane, u64* cells) {
+    if (n <= 1) return n;
+    if (lane == 0) {
+        for (int i = 0; i < n; ++i) { ia[i] = i; av[i].n_comp = 1; }
+        dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; });   // sort by the END position, not START!
+    }
+    WAVE_SYNC();
+    for (int i = 1; i < n; ++i) {
+        DReg p = av[ia[i]];
+        DReg pm = av[ia[i - 1]];
+        if (p.rid != pm.rid || p.rb >= pm.re + o.max_chain_gap) continue;   // then no need to go into the loop below
+        for (int j = i - 1; j >= 0; --j) {
+            DReg qq = av[ia[j]];
+            WAVE_SYNC();   // every lane has its copy before lane 0 may overwrite the entry
+            if (!(p.rid == qq.rid && p.rb < qq.re + o.max_chain_gap)) break;
+            if (qq.qe == qq.qb) continue;   // a[j] has been excluded
+            i64 orr = qq.re - p.rb;   // overlap length on the reference
+            i64 oq = qq.qb < p.qb ? qq.qe - p.qb : p.qe - qq.qb;   // overlap length on the query
+            i64 mr = qq.re - qq.rb < p.re - p.rb ? qq.re - qq.rb : p.re - p.rb;   // min ref len in alignment
+            i64 mq = qq.qe - qq.qb < p.qe - p.qb ? qq.qe - qq.qb : p.qe - p.qb;   // min qry len in alignment
+            int score = 0, w = 0;
+            if ((float)orr > o.mask_level_redun * (float)mr && (float)oq > o.mask_level_redun * (float)mq) {   // one of the hits is redundant
+                if (p.score < qq.score) {
+                    p.qe = p.qb;
+                    if (lane == 0) av[ia[i]].qe = p.qb;
+                    break;
+                } else {
+                    if (lane == 0) av[ia[j]].qe = qq.qb;
+                }
+            } else if (do_patch && qq.rb < p.rb && (score = wave_patch_reg(ix, o, q, qq, p, &w, lane, cells)) > 0) {   // then merge q into p
+                p.n_comp += qq.n_comp + 1;
+                p.seedcov = p.seedcov > qq.seedcov ? p.seedcov : qq.seedcov;
+                p.sub = p.sub > qq.sub ? p.sub : qq.sub;
+                p.csub = p.csub > qq.csub ? p.csub : qq.csub;
+                p.qb = qq.qb; p.rb = qq.rb;
+                p.truesc = p.score = score;
+                p.w = w;
+                if (lane == 0) { av[ia[i]] = p; av[ia[j]].qb = qq.qe; }
+            }
+            WAVE_SYNC();
+        }
+        WAVE_SYNC();
+    }
+    WAVE_SYNC();   // all lanes are done reading ia[]/av[] before lane 0 compacts and re-sorts them
+    int m = 0;
+    if (lane == 0) {
+        for (int i = 0; i < n; ++i)   // exclude identical hits
+            if (av[ia[i]].qe > av[ia[i]].qb) ia[m++] = ia[i];
+        dev_introsort(m, ia, [&](int x, int y) {
+            const DReg &A = av[x], &B = av[y];
+            return A.score > B.score || (A.score == B.score && (A.rb < B.rb || (A.rb == B.rb && A.qb < B.qb)));
+        });
+        for (int i = 1; i < m; ++i)   // mark identical hits
+            if (av[ia[i]].score == av[ia[i - 1]].score && av[ia[i]].rb == av[ia[i - 1]].rb && av[ia[i]].qb == av[ia[i - 1]].qb) av[ia[i]].qe = av[ia[i]].qb;
+        int m2 = m ? 1 : 0;
+        for (int i = 1; i < m; ++i)
+            if (av[ia[i]].qe > av[ia[i]].qb) ia[m2++] = ia[i];
+        m = m2;
+        ia[n] = m;   // broadcast slot
+    }
+    WAVE_SYNC();
+    m = ia[n];
+    for (int i = lane; i < m; i += 64) tmp[i] = av[ia[i]];
+    WAVE_SYNC();
+    for (int i = lane; i < m; i += 64) av[i] = tmp[i];
+    WAVE_SYNC();
+    return m;
+}
+
+// K5.  grid = n_reads waves.  Also records the best pre-rescue score of the read (gobwa.go:264-283).
+__global__ void __launch_bounds__(64) k_dedup(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+                                               const i64* __restrict__ reg_off, DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool,
+                                               int32_t* __restrict__ n_regs, int32_t* __restrict__ best_score, DCounters* __restrict__ ctr) {
+    __shared__ uint8_t q[LH_MAXLEN + 6];
+    int r = blockIdx.x, lane = LANE();
+    if (r >= n_reads) return;
+    i64 off = seq_off[r];
+    int l_query = (int)(seq_off[r + 1] - off);
+    if (l_query > LH_MAXLEN) l_query = 0;
+    for (int i = lane; i < l_query; i += 64) q[i] = seq[off + i];
+    WAVE_SYNC();
+    i64 ro = reg_off[r];
+    DReg* av = regs + ro;
+    int n = n_regs[r];
+    u64 cells = 0;
+    n = wave_sort_dedup_patch(ix, o, q, av, n, ia_pool + ro + r, regs_tmp + ro, 1, lane, &cells);
+    int best = 0;
+    for (int i = lane; i < n; i += 64) { int s = av[i].score; best = best > s ? best : s; }
+    best = wave_max_i32(best);
+    if (lane == 0) {
+        n_regs[r] = n; best_score[r] = best;
+        if (ctr && cells) atomicAdd(&ctr->glob_cells, cells);
+    }
+}

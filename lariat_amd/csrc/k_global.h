@@ -1,0 +1,131 @@
+// k_global.h — banded global alignment (BWA ksw_global2 / bwa_gen_cigar2) as a wave-parallel row sweep.
+// Used by K5 (mem_patch_reg: score only) and K7 (mem_reg2aln: score + traceback -> CIGAR), i.e. the arithmetic behind
+// go/src/gobwa/gobwa.go:404 (mem_reg2aln) and the patch step inside mem_align1_core (gobwa.go:244,253).
+//
+// Same idea as k_extend.h: in ksw_global2 E and F are functions of the diagonal term m, so F inside a row is a
+// max-plus prefix scan over the band; lanes own query columns (j = lane + 64*t, upstream's eh[] in registers),
+// the per-cell direction byte z[i][j-beg] is written to an HBM slab and walked back by lane 0.
+#pragma once
+#include "k_extend.h"
+
+#define LH_MINUS_INF (-0x40000000)
+
+#define LH_GLB_SLAB(T)                                                                                     \
+    if (64 * (T) <= end && 64 * (T) + 63 >= beg) {                                                         \
+        int j = 64 * (T) + lane;                                                                           \
+        int in = j >= beg && j < end;                                                                      \
+        int mm = LH_MINUS_INF, e = E##T, enew = E##T, tins = LH_MINUS_INF;                                 \
+        int d = 0;                                                                                         \
+        if (in) {                                                                                          \
+            int qv = qb##T;                                                                                \
+            int sc = (tb > 3 || qv > 3) ? -1 : (tb == qv ? a_ : -b_);                                      \
+            mm = H##T + sc;                                                                                \
+            tins = mm - oe_ins;                                                                            \
+        }                                                                                                  \
+        int bj = in ? tins + (j + 1) * e_ins : -0x7fffffff;                                                \
+        int incl = wave_scan_max_i32(bj, lane);                                                            \
+        int excl = __shfl_up(incl, 1);                                                                     \
+        if (lane == 0) excl = -0x7fffffff;                                                                 \
+        int G = gcarry > excl ? gcarry : excl;                                                             \
+        int f = G - j * e_ins;                                                                             \
+        int last = __shfl(incl, 63);                                                                       \
+        gcarry = gcarry > last ? gcarry : last;                                                            \
+        int h = 0;                                                                                         \
+        if (in) {                                                                                          \
+            d = mm >= e ? 0 : 1;                                                                           \
+            h = mm >= e ? mm : e;                                                                          \
+            d = h >= f ? d : 2;                                                                            \
+            h = h >= f ? h : f;                                                                            \
+            int t_ = mm - oe_del;                                                                          \
+            enew = e - e_del;                                                                              \
+            d |= enew > t_ ? 1 << 2 : 0;                                                                   \
+            enew = enew > t_ ? enew : t_;                                                                  \
+            int fd = f - e_ins;                                                                            \
+            d |= fd > tins ? 2 << 4 : 0;                                                                   \
+            if (zrow) zrow[j - beg] = (uint8_t)d;                                                          \
+        }                                                                                                  \
+        int hleft = __shfl_up(h, 1);                                                                       \
+        if (lane == 0) hleft = hcarry;                                                                     \
+        hcarry = __shfl(h, 63);                                                                            \
+        if (j == beg && beg < end) H##T = h1_init;                                                         \
+        else if (j > beg && j <= end) H##T = hleft;                                                        \
+        if (in) E##T = enew;                                                                               \
+        if (j == end) { E##T = LH_MINUS_INF; if (beg >= end) H##T = h1_init; }                             \
+    }
+
+// ksw_global2; returns the score.  If z != NULL the direction matrix (tlen x n_col bytes) is written for traceback.
+__device__ __forceinline__ int wave_ksw_global2(const DIndex& ix, const DOpts& o, const uint8_t* qarr, int qoff, int qstep, int qlen, i64 tcoord0, int tstep,
+                                                int tlen, int w, uint8_t* z, int lane, u64* cells) {
+    const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    int H0, H1, H2, H3, E0, E1, E2, E3, qb0, qb1, qb2, qb3;
+#define LH_GLB_INIT(T)                                                              \
+    {                                                                               \
+        int j = 64 * (T) + lane;                                                    \
+        qb##T = j < qlen ? qarr[qoff + qstep * j] : 4;                              \
+        H##T = j == 0 ? 0 : ((j <= qlen && j <= w) ? -(o_ins + e_ins * j) : LH_MINUS_INF); \
+        E##T = LH_MINUS_INF;                                                        \
+    }
+    LH_GLB_INIT(0) LH_GLB_INIT(1) LH_GLB_INIT(2) LH_GLB_INIT(3)
+#undef LH_GLB_INIT
+    int tchunk = 4;
+    u64 ncell = 0;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) {
+            int ii = i + lane;
+            tchunk = ii < tlen ? dev_ref_base(ix, tcoord0 + (i64)tstep * ii) : 4;
+        }
+        int tb = __shfl(tchunk, i & 63);
+        int beg = i > w ? i - w : 0;
+        int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : LH_MINUS_INF;
+        int gcarry = LH_MINUS_INF + beg * e_ins;
+        int hcarry = 0;
+        uint8_t* zrow = z ? z + (size_t)i * n_col : (uint8_t*)0;
+        LH_GLB_SLAB(0) LH_GLB_SLAB(1) LH_GLB_SLAB(2) LH_GLB_SLAB(3)
+        if (end > beg) ncell += (u64)(end - beg);
+    }
+    if (cells) *cells += ncell;
+    // score = eh[qlen].h
+    int src = qlen & 63, slab = qlen >> 6;
+    int v = slab == 0 ? H0 : slab == 1 ? H1 : slab == 2 ? H2 : H3;
+    return __shfl(v, src);
+}
+
+// bwa_gen_cigar2 without traceback: global score of query[qb_..qe_) against the fwd||rev reference interval [rb,re).
+// Returns 0 and sets *ok=0 when upstream would reject the interval.
+__device__ __forceinline__ int wave_gen_score(const DIndex& ix, const DOpts& o, const uint8_t* q, int qb_, int l_query, int w_, i64 rb, i64 re, int lane, int* ok,
+                                              u64* cells) {
+    i64 l_pac = ix.l_pac;
+    *ok = 0;
+    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return 0;
+    i64 b2 = rb, e2 = re;   // bns_get_seq clamps to [0, 2*l_pac)
+    if (e2 > l_pac << 1) e2 = l_pac << 1;
+    if (b2 < 0) b2 = 0;
+    if (e2 - b2 != re - rb) return 0;
+    int rlen = (int)(re - rb);
+    *ok = 1;
+    int rev = rb >= l_pac;   // reverse both sequences so that indels are left-aligned on the forward strand
+    int qoff = rev ? qb_ + l_query - 1 : qb_, qstep = rev ? -1 : 1;
+    i64 t0 = rev ? re - 1 : rb;
+    int tstep = rev ? -1 : 1;
+    if (l_query == rlen && w_ == 0) {   // no gap; no need to do DP
+        int sc = 0;
+        for (int i = lane; i < l_query; i += 64) {
+            int tb = dev_ref_base(ix, t0 + (i64)tstep * i), qv = q[qoff + qstep * i];
+            sc += (tb > 3 || qv > 3) ? -1 : (tb == qv ? o.a : -o.b);
+        }
+        return wave_sum_i32(sc);
+    }
+    int max_ins = (int)((double)(((l_query + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
+    int max_del = (int)((double)(((l_query + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
+    int max_gap = max_ins > max_del ? max_ins : max_del;
+    max_gap = max_gap > 1 ? max_gap : 1;
+    int dl = rlen - l_query; dl = dl < 0 ? -dl : dl;
+    int w = (max_gap + dl + 1) >> 1;
+    w = w < w_ ? w : w_;
+    int min_w = dl + 3;
+    w = w > min_w ? w : min_w;
+    return wave_ksw_global2(ix, o, q, qoff, qstep, l_query, t0, tstep, rlen, w, (uint8_t*)0, lane, cells);
+}

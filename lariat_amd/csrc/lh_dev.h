@@ -12,8 +12,11 @@
 
 #ifdef LH_EMU
 #include "hip_emu.h"
-#define LH_LAUNCH(kernel, grid, block, stream, ...) \
-    emu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
+#define LH_LAUNCH(kernel, grid, block, stream, ...)                                          \
+    do {                                                                                     \
+        if (getenv("LH_EMU_TRACE")) fprintf(stderr, "emu launch %s grid=%d\n", #kernel, (int)(grid)); \
+        emu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); });                \
+    } while (0)
 struct uint4 { uint32_t x, y, z, w; };
 struct uint2 { uint32_t x, y; };
 #else
@@ -29,7 +32,11 @@ struct uint2 { uint32_t x, y; };
 #define LH_MAX_MM 64             // mismatch loci per candidate
 #define LH_RESCUE_SLOTS 50       // opt->max_matesw / gobwa.go:287
 
+#ifdef LH_EMU
+#define WAVE_SYNC() (emu::note(__FILE__, __LINE__), __syncthreads())
+#else
 #define WAVE_SYNC() __syncthreads()
+#endif
 #define LANE() ((int)(threadIdx.x & 63))
 
 typedef uint64_t u64;

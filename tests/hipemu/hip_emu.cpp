@@ -24,11 +24,12 @@ __asm__(
 
 constexpr size_t STACK = 256 * 1024;
 
+static thread_local unsigned long g_progress = 0;
 static void release_wave_if_ready(Wave& w) {
-    if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; w.gen++; }
+    if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; w.gen++; g_progress++; }
 }
 static void release_block_if_ready(Block& b) {
-    if (b.blk_live > 0 && b.blk_arrived == b.blk_live) { b.blk_arrived = 0; b.blk_gen++; }
+    if (b.blk_live > 0 && b.blk_arrived == b.blk_live) { b.blk_arrived = 0; b.blk_gen++; g_progress++; }
 }
 
 static void fiber_entry() {
@@ -36,6 +37,7 @@ static void fiber_entry() {
     Fiber* f = b->cur;
     (*b->body)();
     f->done = true;
+    g_progress++;
     Wave& w = b->waves[f->tid / WAVE];
     w.live--;
     w.live_mask &= ~(1ull << (f->tid % WAVE));
@@ -47,6 +49,8 @@ static void fiber_entry() {
     abort();
 }
 
+void note(const char* file, int line) { Fiber* f = tls.blk->cur; f->file = file; f->line = line; f->hist[f->nh++ & 15] = line; }
+
 void yield() {
     Block* b = tls.blk;
     Fiber* f = b->cur;
@@ -56,14 +60,14 @@ void yield() {
 void wave_barrier() {
     Wave& w = my_wave();
     uint64_t g = w.gen;
-    if (++w.arrived == w.live) { w.arrived = 0; w.gen++; }
+    if (++w.arrived == w.live) { w.arrived = 0; w.gen++; g_progress++; }
     else while (w.gen == g) yield();
 }
 
 void block_barrier() {
     Block& b = *tls.blk;
     uint64_t g = b.blk_gen;
-    if (++b.blk_arrived == b.blk_live) { b.blk_arrived = 0; b.blk_gen++; }
+    if (++b.blk_arrived == b.blk_live) { b.blk_arrived = 0; b.blk_gen++; g_progress++; }
     else while (b.blk_gen == g) yield();
 }
 
@@ -97,7 +101,7 @@ static void run_block(Block& b, dim3 grid, dim3 block, dim3 bidx, const std::fun
     for (unsigned t = 0; t < nt; ++t) {
         Fiber& f = b.fibers[t];
         if (!f.stack) f.stack = (char*)aligned_alloc(64, STACK);
-        f.done = false; f.tid = t;
+        f.done = false; f.tid = t; f.nh = 0;
         Wave& w = b.waves[t / WAVE];
         w.live++; w.live_mask |= 1ull << (t % WAVE);
         uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
@@ -108,8 +112,10 @@ static void run_block(Block& b, dim3 grid, dim3 block, dim3 bidx, const std::fun
     }
     tls.blk = &b;
     tls.blockIdx = bidx; tls.blockDim = block; tls.gridDim = grid;
+    int stuck = 0;
     for (;;) {
         bool any = false;
+        unsigned long p0 = g_progress;
         for (unsigned t = 0; t < nt; ++t) {
             Fiber& f = b.fibers[t];
             if (f.done) continue;
@@ -119,6 +125,15 @@ static void run_block(Block& b, dim3 grid, dim3 block, dim3 bidx, const std::fun
             emu_switch(&b.main_sp, f.sp);
         }
         if (!any) break;
+        if (g_progress == p0) {
+            if (++stuck > 4) {   // every live fiber is parked at a rendezvous that can never complete: divergent cross-lane op
+                fprintf(stderr, "hip_emu: DEADLOCK in block (%u,%u): lanes reached different cross-lane ops\n", bidx.x, bidx.y);
+                for (unsigned w = 0; w < nw; ++w)
+                    fprintf(stderr, "  wave %u: live=%d arrived(wave)=%d block_arrived=%d/%d\n", w, b.waves[w].live, b.waves[w].arrived, b.blk_arrived, b.blk_live);
+                for (unsigned t = 0; t < nt; ++t) if (!b.fibers[t].done) { fprintf(stderr, "    lane %u last sync site %s:%d  hist:", t, b.fibers[t].file, b.fibers[t].line); for (int h = 0; h < 16; ++h) fprintf(stderr, " %d", b.fibers[t].hist[(b.fibers[t].nh + h) & 15]); fprintf(stderr, " (n=%d)\n", b.fibers[t].nh); }
+                abort();
+            }
+        } else stuck = 0;
     }
 }
 

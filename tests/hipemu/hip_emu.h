@@ -38,6 +38,10 @@ struct Wave {
     uint64_t exch[2][WAVE];
 };
 struct Fiber {
+    const char* file = "";
+    int line = 0;
+    int hist[16] = {0};
+    int nh = 0;
     void* sp = nullptr;
     char* stack = nullptr;
     bool done = true;
@@ -59,6 +63,7 @@ struct Tls {
 extern thread_local Tls tls;
 extern "C" void emu_switch(void** save_sp, void* load_sp);
 void yield();
+void note(const char* file, int line);
 void wave_barrier();
 void block_barrier();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);

@@ -31,4 +31,7 @@ def test_emu_front_synthetic(emu, oracle):
     idx = emu.index_from_arrays(oidx.arrays())
     rs = helpers.small_reads(names, contigs, n_barcodes=3, pairs=30, junk=0.05)
     b = helpers.batch_of(rs)
-    helpers.assert_same_dump(idx.context(rs.n_pairs).stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT)
+    ctx = idx.context(rs.n_pairs)
+    helpers.assert_same_dump(ctx.stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    res = ctx.align_barcodes(b, emu.opts(run_inference=0))
+    helpers.assert_same_result(res, oidx.align_barcodes(b, oracle.opts(run_inference=0)), inference=False)

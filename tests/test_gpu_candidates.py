@@ -1,0 +1,70 @@
+"""GPU parity of the whole candidate-generation path (K1..K7: SMEM, SA, chaining, banded SW extension, dedup/patch, mate
+rescue, region->CIGAR + lariat's GetAlignments walk) against the oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+import helpers
+from lariat_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = capi.load_library()
+    assert L.device_count() >= 1
+    return L
+
+
+def test_gobwa1_on_gpu(lib):
+    """go/src/test/gobwa_test.go:13-28 through the HIP path"""
+    idx = lib.index_load(helpers.PHIX)
+    b = capi.Batch([capi.sequence_convert(helpers.PHIX_READ_A), capi.sequence_convert(helpers.PHIX_READ_B)], [0, 1])
+    res = idx.context(8).align_barcodes(b, lib.opts(run_inference=0))
+    a0 = list(res.cands_of_read(0))
+    assert res.pos[a0[0]] == 210 and idx.contigs()[res.rid[a0[0]]][0] == "PhiX"
+    assert len(list(res.cands_of_read(1))) == 1
+
+
+def test_zero_length_read_on_gpu(lib, oracle):
+    """go/src/test/lariat_test.go:12-24"""
+    idx = lib.index_load(helpers.PHIX)
+    recs = helpers.read_fastq9(helpers.GOLDEN + "/zero_length_read_test.fastq.gz", trim=7)
+    reads = []
+    for r in recs:
+        reads += [capi.sequence_convert(r["r1"]), capi.sequence_convert(r["r2"])]
+    b = capi.Batch(reads, [0, 3])
+    res = idx.context(8).align_barcodes(b, lib.opts(improper_pair_penalty=-17.0, run_inference=0))
+    assert (np.diff(res.cand_off) >= 1).all() and (res.rid == -1).all()
+    helpers.assert_same_result(res, oracle.index_load(helpers.PHIX).align_barcodes(b, oracle.opts(improper_pair_penalty=-17.0, run_inference=0)),
+                               inference=False)
+
+
+@pytest.mark.parametrize("seed,junk", [(5, 0.03), (11, 0.15)])
+def test_candidates_synthetic(lib, oracle, seed, junk):
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=20, pairs=100, seed=seed, junk=junk)
+    b = helpers.batch_of(rs)
+    ctx = idx.context(rs.n_pairs)
+    helpers.assert_same_dump(ctx.stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    res = ctx.align_barcodes(b, lib.opts(run_inference=0))
+    ores = oidx.align_barcodes(b, oracle.opts(run_inference=0), threads=8)
+    helpers.assert_same_result(res, ores, inference=False)
+    for k in ("n_ext", "n_lf", "n_sa", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"):
+        assert res.counters[k] == ores.counters[k], k
+
+
+def test_repeat_rich_genome(lib, oracle):
+    """high candidate multiplicity (config-5 flavour): many dups and repeat families"""
+    from lariat_amd import synth
+    names = ["c1", "c2"]
+    contigs = synth.make_genome([150000, 150000], seed=9, n_dup=30, dup_len=3000, dup_identity=0.995, n_rep_family=6, rep_len=300, rep_copies=40)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = synth.make_reads(contigs, names, n_barcodes=10, pairs_per_barcode=60, seed=3, junk_frac=0.05)
+    b = helpers.batch_of(rs)
+    res = idx.context(rs.n_pairs).align_barcodes(b, lib.opts(run_inference=0))
+    helpers.assert_same_result(res, oidx.align_barcodes(b, oracle.opts(run_inference=0), threads=8), inference=False)
+    assert np.diff(res.cand_off).max() >= 4
