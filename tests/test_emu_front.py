@@ -35,3 +35,16 @@ def test_emu_front_synthetic(emu, oracle):
     helpers.assert_same_dump(ctx.stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT + helpers.DUMP_REGS)
     res = ctx.align_barcodes(b, emu.opts(run_inference=0))
     helpers.assert_same_result(res, oidx.align_barcodes(b, oracle.opts(run_inference=0)), inference=False)
+
+
+def test_emu_full_inference(emu, oracle):
+    """whole hot path (candidates + tagBest + molecules + RFA + MAPQ + duplicates + split reads) under emulation"""
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=3, pairs=40, junk=0.05)
+    rfa = np.array([1, 0, 1], dtype=np.uint8)   # the middle barcode takes the no-RFA path (lariat.go:489-496)
+    b = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed, bc_do_rfa=rfa)
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
+    assert (res.active_idx >= 0).all()

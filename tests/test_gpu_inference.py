@@ -1,0 +1,95 @@
+"""GPU parity of the complete per-barcode align loop (DoRFAForOneBarcode, lariat.go:461-547, minus DumpToBams)
+against the oracle: integer/index fields bit-exact, MAPQ within +-1, float scores within 1e-9 relative."""
+import numpy as np
+import pytest
+
+import helpers
+from lariat_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = capi.load_library()
+    assert L.device_count() >= 1
+    return L
+
+
+@pytest.fixture(scope="module")
+def small(lib, oracle):
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    return names, contigs, oidx, lib.index_from_arrays(oidx.arrays())
+
+
+@pytest.mark.parametrize("seed,junk,pairs", [(5, 0.03, 100), (7, 0.2, 60), (9, 0.0, 5)])
+def test_full_path_synthetic(lib, oracle, small, seed, junk, pairs):
+    names, contigs, oidx, idx = small
+    rs = helpers.small_reads(names, contigs, n_barcodes=16, pairs=pairs, seed=seed, junk=junk)
+    rfa = np.ones(16, dtype=np.uint8)
+    rfa[3] = 0   # a barcode that fails worthRunningRFA
+    b = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed, bc_do_rfa=rfa)
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, oidx.align_barcodes(b, threads=8), inference=True)
+
+
+def test_centromere_zeroes_mapq(lib, oracle, small):
+    names, contigs, oidx, idx = small
+    rs = helpers.small_reads(names, contigs, n_barcodes=6, pairs=50, seed=2, junk=0.0)
+    cs = np.array([0, -1, -1], dtype=np.int64)
+    ce = np.array([150000, -1, -1], dtype=np.int64)
+    b = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed, cen_start=cs, cen_end=ce)
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, oidx.align_barcodes(b, threads=8), inference=True)
+    act = res.active_idx
+    in_cen = (res.rid[act] == 0) & (res.pos[act] > 0) & (res.pos[act] <= 150000)
+    assert in_cen.any() and (res.mapq[act][in_cen] == 0).all()
+
+
+def test_repeat_rich_inference(lib, oracle):
+    names = ["c1", "c2"]
+    contigs = synth.make_genome([150000, 150000], seed=9, n_dup=30, dup_len=3000, dup_identity=0.995, n_rep_family=6, rep_len=300, rep_copies=40)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = synth.make_reads(contigs, names, n_barcodes=10, pairs_per_barcode=60, seed=3, junk_frac=0.05)
+    b = helpers.batch_of(rs)
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, oidx.align_barcodes(b, threads=8), inference=True)
+
+
+def test_improper_penalty_not_dyadic(lib, oracle, small):
+    """a penalty that is not a multiple of 0.5 exercises the floating-point summation order of fastScore"""
+    names, contigs, oidx, idx = small
+    rs = helpers.small_reads(names, contigs, n_barcodes=6, pairs=60, seed=13, junk=0.1)
+    b = helpers.batch_of(rs)
+    res = idx.context(rs.n_pairs).align_barcodes(b, lib.opts(improper_pair_penalty=-4.3))
+    helpers.assert_same_result(res, oidx.align_barcodes(b, oracle.opts(improper_pair_penalty=-4.3), threads=8), inference=True)
+
+
+def test_round_trip_properties_large(lib):
+    """size-independent properties on a batch too large for the oracle to be worth running: one active alignment per
+    read, mates linked symmetrically, candidates sorted by score, MAPQ in range, placement accuracy"""
+    names = ["chrS"]
+    contigs = synth.make_genome([4000000], seed=20261002)
+    import tempfile, os
+    d = tempfile.mkdtemp()
+    lib.index_build(os.path.join(d, "g"), names, contigs, threads=0)
+    idx = lib.index_load(os.path.join(d, "g"))
+    rs = synth.make_reads(contigs, names, n_barcodes=500, pairs_per_barcode=100, with_names=False)
+    b = helpers.batch_of(rs)
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    act = res.active_idx
+    assert (act >= 0).all()
+    assert (res.active[act] == 1).all() and res.active.sum() == res.n_reads
+    mate = res.mate_idx[act]
+    assert (res.mate_idx[mate] == act).all()
+    assert ((res.mapq[act] >= 0) & (res.mapq[act] <= 60)).all()
+    for r in range(0, res.n_reads, 997):
+        s = res.score[res.cand_off[r]:res.cand_off[r + 1]]
+        assert (np.diff(s) <= 0).all()
+    truth = np.empty(res.n_reads, dtype=np.int64)
+    truth[0::2] = rs.truth_pos1
+    truth[1::2] = rs.truth_pos2
+    ok = np.abs(res.pos[act] - truth) < 20
+    assert ok.mean() > 0.99
