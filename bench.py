@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — read-pairs/sec through the MI355X-native per-barcode align loop (BASELINE.json metric).
+
+A "step" is ONE pass of the whole hot path (lariat.go:461-547 minus DumpToBams: SMEM seeding, SA lookup, chaining,
+banded SW extension, dedup/patch, mate rescue, region->CIGAR, tagBest/molecule inference/RFA/MAPQ/duplicates/split reads)
+over one resident batch of synthetic barcode-sorted read pairs.  Workload = BASELINE.json configs[1]: a 64 Mb
+"chr20-like" synthetic genome (no real genome exists offline), 1M 2x150 pairs in 10k barcodes per GPU.  Inputs are in
+HBM when the timed region starts (lh_batch_upload before, lh_result_download after).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Multi-GPU: barcodes are independent (lariat.go:348-350), so every rank aligns its own barcode range with the index
+replicated in its HBM; there is NO collective on the data path (weak scaling: per-GPU work fixed).  torch.distributed is
+used only for the barrier and the max-over-ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=float, default=64.0, help="synthetic chr20-like genome size (configs[1]: 64 Mb)")
+    ap.add_argument("--barcodes", type=int, default=10000, help="barcodes per GPU (configs[1]: 10k, 100 pairs each)")
+    ap.add_argument("--pairs-per-barcode", type=int, default=100)
+    ap.add_argument("--cpu-sample-barcodes", type=int, default=600, help="barcodes of the same workload timed on the host cores (cpu_baseline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--index-dir", default=os.environ.get("LH_INDEX_DIR", "/tmp/lariat_amd_bench"))
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    from lariat_amd import capi, synth
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    lib = capi.load_library()
+    if lib.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: liblariat_hip has no CPU fallback")
+
+    # ---- synthetic genome + FM-index (built once per node by local rank 0, BWA-compatible files) ----
+    t0 = time.time()
+    glen = int(a.genome_mb * 1e6)
+    contigs = synth.make_genome([glen], seed=20261002)
+    names = ["chr20"]
+    os.makedirs(a.index_dir, exist_ok=True)
+    prefix = os.path.join(a.index_dir, "chr20like_%d.fa" % glen)
+    if local_rank == 0 and not os.path.exists(prefix + ".done"):
+        lib.index_build(prefix, names, contigs, threads=0)
+        open(prefix + ".done", "w").write("ok\n")
+    if dist is not None:
+        dist.barrier()
+    while not os.path.exists(prefix + ".done"):
+        time.sleep(0.2)
+    idx = lib.index_load(prefix, device=local_rank)
+    t_index = time.time() - t0
+
+    # ---- this rank's barcode range: weak scaling, barcodes [rank*B, (rank+1)*B) of the sorted input ----
+    t0 = time.time()
+    rs = synth.make_reads(contigs, names, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode, seed=20261003 + 2 + 1000 * rank, with_names=False)
+    batch = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed)
+    t_reads = time.time() - t0
+    n_pairs = rs.n_pairs
+    ctx = idx.context(n_pairs)
+    opts = lib.opts()
+    t0 = time.time()
+    ctx.upload(batch)
+    t_upload = time.time() - t0
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ctx.align_resident(opts)
+    sync_all()
+    t0 = time.perf_counter()
+    kern = {}
+    for _ in range(a.steps):
+        ctx.align_resident(opts)   # enqueues every kernel on the context's stream and synchronises it
+        for name, ms in ctx.timings():   # HIP events recorded on that stream around each launch
+            kern.setdefault(name, []).append(ms)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    t0 = time.time()
+    res = ctx.download()
+    t_download = time.time() - t0
+    cnt = res.counters
+
+    if rank == 0:
+        total_pairs = n_pairs * world * a.steps
+        value = total_pairs / elapsed
+        avg = {k: float(np.mean(v)) for k, v in kern.items()}
+        dom = max(avg, key=avg.get)
+        # roofline of the dominant kernel.  For k_smem: every bwt_extend reads two 64-B occurrence blocks;
+        # n_ext is counted by the kernel itself (and equals the oracle's count in the parity tests).
+        alg_bytes = {
+            "k_smem": 128.0 * cnt["n_ext"] + 1.0 * int(rs.seq_off[-1]),
+            "k_seed": 64.0 * cnt["n_lf"] + 8.0 * cnt["n_sa"],
+        }.get(dom, 0.0)
+        achieved = alg_bytes / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg[dom], 4),
+                    "kernel_ms": {k: round(v, 3) for k, v in avg.items()}}
+        out = {
+            "metric": "read-pairs/sec aligned (per-barcode align loop: seeding + SW + RFA/MAPQ), synthetic chr20-like reference",
+            "value": round(value, 1), "unit": "read-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64/i32 (FM-index + integer DP), f64 (RFA scores)", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: %.0f Mb chr20-like synthetic genome, %d pairs 2x150 (143+150 post-trim) / %d barcodes per GPU, "
+                                   "RFA on device" % (a.genome_mb, n_pairs, a.barcodes),
+                       "pairs_per_gpu": n_pairs, "barcodes_per_gpu": a.barcodes, "parallelism": "barcode-range shards, no collective"},
+            "roofline": roofline,
+            "setup_s": {"genome+index": round(t_index, 1), "reads": round(t_reads, 1), "upload_h2d": round(t_upload, 3), "download_d2h": round(t_download, 3)},
+            "pcie_inclusive_pairs_per_s": round(n_pairs / (elapsed / a.steps + t_upload + t_download), 1),
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, rs, prefix)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, rs, prefix):
+    """the oracle (CPU restatement of the Go+BWA path; the reference itself cannot be built here) timed on the host cores,
+    on a bounded sample of the same workload; threaded over barcodes like lariat's worker pool (lariat.go:348-350)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py
+    from lariat_amd import capi
+    o = oracle_py.load()
+    oidx = o.index_load(prefix)
+    nb = min(a.cpu_sample_barcodes, len(rs.bc_pair_off) - 1)
+    sub = rs.slice_barcodes(0, nb)
+    b = capi.Batch.from_arrays(sub.seq, sub.seq_off, sub.bc_pair_off, sub.name_seed)
+    cores = min(os.cpu_count() or 1, 64)
+    t0 = time.perf_counter()
+    oidx.time_align(b, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(sub.n_pairs / dt, 1), "unit": "read-pairs/s", "cores": cores, "kind": "port",
+            "sample": "first %d barcodes (%d pairs) of the same batch, %.1f s wall" % (nb, sub.n_pairs, dt)}
+
+
+if __name__ == "__main__":
+    main()
