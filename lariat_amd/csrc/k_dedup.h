@@ -43,12 +43,14 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
         dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; });   // sort by the END position, not START!
     }
     WAVE_SYNC();
+    int wd = 1000000;
     for (int i = 1; i < n; ++i) {
         DReg p = av[ia[i]];
         DReg pm = av[ia[i - 1]];
         if (p.rid != pm.rid || p.rb >= pm.re + o.max_chain_gap) continue;   // then no need to go into the loop below
         for (int j = i - 1; j >= 0; --j) {
             DReg qq = av[ia[j]];
+            LH_WATCH_D(wd, 4, break)
             WAVE_SYNC();   // every lane has its copy before lane 0 may overwrite the entry
             if (!(p.rid == qq.rid && p.rb < qq.re + o.max_chain_gap)) break;
             if (qq.qe == qq.qb) continue;   // a[j] has been excluded

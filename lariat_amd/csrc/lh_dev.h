@@ -42,6 +42,32 @@ struct uint2 { uint32_t x, y; };
 typedef uint64_t u64;
 typedef int64_t i64;
 
+// LH_UNI(cond): the branch condition of single-lane (lane-0) sequential code, made provably wave-uniform so that hipcc
+// emits scalar branches instead of exec-mask loops (deeply nested divergent loops proved fragile on gfx950/ROCm 7.2).
+#ifdef LH_EMU
+#define LH_UNI(c) (c)
+#else
+#define LH_UNI(c) (__builtin_amdgcn_readfirstlane((int)(c)) != 0)
+#endif
+
+// development watchdog: loops that should be short bump a budget; on exhaustion they record a site code and bail out
+#ifdef LH_EMU
+static int lh_dbg[32];
+#else
+__device__ int lh_dbg[32];
+#endif
+#define LH_WATCH(budget, code, action) if (--(budget) < 0) { lh_dbg[code] = 1; action; }
+#ifdef LH_NOWATCH_SORT
+#define LH_WATCH_S(budget, code, action)
+#else
+#define LH_WATCH_S LH_WATCH
+#endif
+#ifdef LH_NOWATCH_DEDUP
+#define LH_WATCH_D(budget, code, action)
+#else
+#define LH_WATCH_D LH_WATCH
+#endif
+
 // status bits per read
 #define LH_ST_INTV_OVERFLOW 1
 #define LH_ST_TOO_LONG 2

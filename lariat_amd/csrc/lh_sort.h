@@ -10,8 +10,8 @@
 #include "lh_dev.h"
 
 template <class T, class Lt> __device__ inline void dev_insertsort(T* s, T* t, Lt lt) {
-    for (T* i = s + 1; i < t; ++i)
-        for (T* j = i; j > s && lt(*j, *(j - 1)); --j) { T tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
+    for (T* i = s + 1; LH_UNI(i < t); ++i)
+        for (T* j = i; LH_UNI(j > s && lt(*j, *(j - 1))); --j) { T tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
 }
 
 template <class T, class Lt> __device__ inline void dev_combsort(int n, T* a, Lt lt) {
@@ -24,11 +24,11 @@ template <class T, class Lt> __device__ inline void dev_combsort(int n, T* a, Lt
             if (gap == 9 || gap == 10) gap = 11;
         }
         do_swap = 0;
-        for (T* i = a; i < a + n - gap; ++i) {
+        for (T* i = a; LH_UNI(i < a + n - gap); ++i) {
             T* j = i + gap;
-            if (lt(*j, *i)) { T tmp = *i; *i = *j; *j = tmp; do_swap = 1; }
+            if (LH_UNI(lt(*j, *i))) { T tmp = *i; *i = *j; *j = tmp; do_swap = 1; }
         }
-    } while (do_swap || gap > 2);
+    } while (LH_UNI(do_swap || gap > 2));
     if (gap != 1) dev_insertsort(a, a + n, lt);
 }
 
@@ -46,27 +46,29 @@ template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, L
     for (d = 2; (1ul << d) < (unsigned long)n; ++d) {}
     Stk* top = stack;
     s = a; t = a + (n - 1); d <<= 1;
+    int wd = 100000 + 64 * n;
     while (1) {
-        if (s < t) {
-            if (--d == 0) {
+        LH_WATCH_S(wd, 1, return)
+        if (LH_UNI(s < t)) {
+            if (LH_UNI(--d == 0)) {
                 dev_combsort((int)(t - s + 1), s, lt);
                 t = s;
                 continue;
             }
             i = s; j = t; k = i + ((j - i) >> 1) + 1;
-            if (lt(*k, *i)) {
-                if (lt(*k, *j)) k = j;
-            } else k = lt(*j, *i) ? i : j;
+            if (LH_UNI(lt(*k, *i))) {
+                if (LH_UNI(lt(*k, *j))) k = j;
+            } else k = LH_UNI(lt(*j, *i)) ? i : j;
             rp = *k;
             if (k != t) { swap_tmp = *k; *k = *t; *t = swap_tmp; }
             for (;;) {
-                do ++i; while (lt(*i, rp));
-                do --j; while (i <= j && lt(rp, *j));
-                if (j <= i) break;
+                do { ++i; LH_WATCH_S(wd, 2, return) } while (LH_UNI(lt(*i, rp)));
+                do { --j; LH_WATCH_S(wd, 3, return) } while (LH_UNI(i <= j && lt(rp, *j)));
+                if (LH_UNI(j <= i)) break;
                 swap_tmp = *i; *i = *j; *j = swap_tmp;
             }
             swap_tmp = *i; *i = *t; *t = swap_tmp;
-            if (i - s > t - i) {
+            if (LH_UNI(i - s > t - i)) {
                 if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
                 s = t - i > 16 ? i + 1 : t;
             } else {
@@ -74,7 +76,7 @@ template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, L
                 t = i - s > 16 ? i - 1 : s;
             }
         } else {
-            if (top == stack) {
+            if (LH_UNI(top == stack)) {
                 dev_insertsort(a, a + n, lt);
                 return;
             } else { --top; s = top->left; t = top->right; d = top->depth; }
@@ -83,17 +85,18 @@ template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, L
 }
 
 // ---- Go 1.9 sort.Sort over an index space [0,n): less(i,j), swp(i,j) ----
+// NOTE: called lane-parallel (one independent sort per lane) by k_rfa, so its branches must stay per-lane: no LH_UNI here.
 template <class L, class S> __device__ inline void gs_insertion(L& less, S& swp, int a, int b) {
     for (int i = a + 1; i < b; i++)
-        for (int j = i; j > a && less(j, j - 1); j--) swp(j, j - 1);
+        for (int j = i; (j > a && less(j, j - 1)); j--) swp(j, j - 1);
 }
 template <class L, class S> __device__ inline void gs_siftdown(L& less, S& swp, int lo, int hi, int first) {
     int root = lo;
     for (;;) {
         int child = 2 * root + 1;
-        if (child >= hi) return;
-        if (child + 1 < hi && less(first + child, first + child + 1)) child++;
-        if (!less(first + root, first + child)) return;
+        if ((child >= hi)) return;
+        if ((child + 1 < hi && less(first + child, first + child + 1))) child++;
+        if ((!less(first + root, first + child))) return;
         swp(first + root, first + child);
         root = child;
     }
@@ -104,8 +107,8 @@ template <class L, class S> __device__ inline void gs_heapsort(L& less, S& swp, 
     for (int i = hi - 1; i >= 0; i--) { swp(first, first + i); gs_siftdown(less, swp, lo, i, first); }
 }
 template <class L, class S> __device__ inline void gs_median3(L& less, S& swp, int m1, int m0, int m2) {
-    if (less(m1, m0)) swp(m1, m0);
-    if (less(m2, m1)) { swp(m2, m1); if (less(m1, m0)) swp(m1, m0); }
+    if ((less(m1, m0))) swp(m1, m0);
+    if ((less(m2, m1))) { swp(m2, m1); if ((less(m1, m0))) swp(m1, m0); }
 }
 template <class L, class S> __device__ inline void gs_pivot(L& less, S& swp, int lo, int hi, int* midlo, int* midhi) {
     int m = (int)((unsigned)(lo + hi) >> 1);
@@ -118,28 +121,28 @@ template <class L, class S> __device__ inline void gs_pivot(L& less, S& swp, int
     gs_median3(less, swp, lo, m, hi - 1);
     int pivot = lo;
     int a = lo + 1, c = hi - 1;
-    for (; a < c && less(a, pivot); a++) {}
+    for (; (a < c && less(a, pivot)); a++) {}
     int b = a;
     for (;;) {
-        for (; b < c && !less(pivot, b); b++) {}
-        for (; b < c && less(pivot, c - 1); c--) {}
-        if (b >= c) break;
+        for (; (b < c && !less(pivot, b)); b++) {}
+        for (; (b < c && less(pivot, c - 1)); c--) {}
+        if ((b >= c)) break;
         swp(b, c - 1);
         b++; c--;
     }
     bool protect = hi - c < 5;
     if (!protect && hi - c < (hi - lo) / 4) {
         int dups = 0;
-        if (!less(pivot, hi - 1)) { swp(c, hi - 1); c++; dups++; }
-        if (!less(b - 1, pivot)) { b--; dups++; }
-        if (!less(m, pivot)) { swp(m, b - 1); b--; dups++; }
+        if ((!less(pivot, hi - 1))) { swp(c, hi - 1); c++; dups++; }
+        if ((!less(b - 1, pivot))) { b--; dups++; }
+        if ((!less(m, pivot))) { swp(m, b - 1); b--; dups++; }
         protect = dups > 1;
     }
     if (protect) {
         for (;;) {
-            for (; a < b && !less(b - 1, pivot); b--) {}
-            for (; a < b && less(a, pivot); a++) {}
-            if (a >= b) break;
+            for (; (a < b && !less(b - 1, pivot)); b--) {}
+            for (; (a < b && less(a, pivot)); a++) {}
+            if ((a >= b)) break;
             swp(a, b - 1);
             a++; b--;
         }
@@ -155,12 +158,12 @@ template <class L, class S> __device__ inline void dev_gosort(int n, L less, S s
     int depth = 0;
     for (int i = n; i > 0; i >>= 1) depth++;
     st[sp++] = Fr{0, n, depth * 2};
-    while (sp > 0) {
+    while ((sp > 0)) {
         Fr f = st[--sp];
         int a = f.a, b = f.b, maxDepth = f.depth;
         bool done = false;
-        while (b - a > 12) {
-            if (maxDepth == 0) { gs_heapsort(less, swp, a, b); done = true; break; }
+        while ((b - a > 12)) {
+            if ((maxDepth == 0)) { gs_heapsort(less, swp, a, b); done = true; break; }
             maxDepth--;
             int mlo, mhi;
             gs_pivot(less, swp, a, b, &mlo, &mhi);
@@ -172,7 +175,7 @@ template <class L, class S> __device__ inline void dev_gosort(int n, L less, S s
         if (done) continue;
         if (b - a > 1) {
             for (int i = a + 6; i < b; i++)
-                if (less(i, i - 6)) swp(i, i - 6);
+                if ((less(i, i - 6))) swp(i, i - 6);
             gs_insertion(less, swp, a, b);
         }
     }

@@ -9,7 +9,7 @@ nb = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 junk = float(sys.argv[3]) if len(sys.argv) > 3 else 0.03
 inf = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-lib = capi.load_library()
+lib = capi.load_library(os.environ.get('LH_LIB'))
 o = oracle_py.load()
 names, contigs = helpers.small_genome()
 oidx = o.index_build_naive(names, contigs)
