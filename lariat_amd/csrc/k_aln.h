@@ -39,7 +39,7 @@ __device__ __forceinline__ double dev_single_score(int mismatches, int indels, i
 }
 
 __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
-                                             const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R,
+                                             const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, i64 cand_cap,
                                              uint8_t* __restrict__ zpool, int32_t* __restrict__ status, DCounters* __restrict__ ctr) {
     __shared__ uint8_t q[LH_MAXLEN + 6];
     __shared__ uint8_t tref[LH_MAXT];
@@ -59,6 +59,10 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
         int n = n_regs[r];
         i64 c0 = R.cand_off[r];
         int st = 0;
+        if (c0 + (n > 0 ? n : 1) > cand_cap) {   // candidate pool exhausted: flag and skip (host returns LH_E_CAPACITY)
+            if (lane == 0) status[r] |= LH_ST_POOL_OVERFLOW;
+            continue;
+        }
         if (n == 0) {   // placeholder (lariat.go:1737-1750,1773-1785): contig "", pos -1, aend 0, score 0
             if (lane == 0) {
                 i64 c = c0;

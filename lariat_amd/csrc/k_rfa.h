@@ -154,7 +154,7 @@ __device__ __forceinline__ double dev_fast_score(const DCand& R, const DInf& S, 
 #define LH_SPLIT_MAX 64
 
 __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
-                                             const u64* __restrict__ name_seed, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S,
+                                             const u64* __restrict__ name_seed, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S, i64 cand_cap,
                                              uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status) {
     __shared__ int32_t shi[8];
     __shared__ double shd[4];
@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
         i64 c_lo = R.cand_off[r0], c_hi = R.cand_off[r0 + nR];
         int NC = (int)(c_hi - c_lo);
         WAVE_SYNC();
+        if (c_hi > cand_cap) continue;   // flagged by k_aln
         // ---- init per-candidate and per-read state (Alignment defaults, lariat.go:1655-1689) ----
         for (int r = lane; r < nR; r += 64) {
             for (i64 g = R.cand_off[r0 + r]; g < R.cand_off[r0 + r + 1]; ++g) {
@@ -334,6 +335,15 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
                     if (act >= 0) { T.act_store[T.aoff[m] + na] = act; T.act_cand[lr] = act; T.act_slot[lr] = na; na++; }
                 }
                 T.alen[m] = na;
+            }
+            WAVE_SYNC();
+            // setMoleculeDifferences(candidate_molecules, false) before the optimizer (lariat.go:503): alignments that are
+            // active NOW keep this value even if a later move deactivates them
+            for (int m = lane; m < M; m += 64) {
+                int diffs = 0;
+                for (int k = 0; k < T.alen[m]; ++k) diffs += R.mismatches[c_lo + T.act_store[T.aoff[m] + k]];
+                double diff = (double)diffs / (double)T.alen[m];
+                for (int k = 0; k < T.alen[m]; ++k) S.mol_diff[c_lo + T.act_store[T.aoff[m] + k]] = diff;
             }
             WAVE_SYNC();
             // ---- optimizer.Optimize(opt, 1, 2, 4*M): 8*M greedy molecule moves ----
