@@ -8,43 +8,69 @@
 
 struct DSeed { i64 rbeg; int32_t qbeg, len; };
 
-// single-workgroup exclusive scan: out[i] = sum_{j<i} max(in[j] + add, floor_min); out[n] = total.  256 threads.
-__global__ void __launch_bounds__(256) k_scan_i32_to_i64(int n, const int32_t* __restrict__ in, int add, int at_least, i64* __restrict__ out) {
+// exclusive scan out[i] = sum_{j<i} max(in[j] + add, at_least), out[n] = total, in three launches:
+//   k_scan_partial (per 2048-element tile: tile sums) -> k_scan_tiles (one workgroup scans the tile sums) -> k_scan_final.
+#define LH_SCAN_TILE 2048
+__device__ __forceinline__ i64 scan_val(const int32_t* in, int i, int n, int add, int at_least) {
+    if (i >= n) return 0;
+    i64 v = (i64)in[i] + add;
+    return v < at_least ? at_least : v;
+}
+__global__ void __launch_bounds__(256) k_scan_partial(int n, const int32_t* __restrict__ in, int add, int at_least, i64* __restrict__ tile_sum) {
+    __shared__ i64 part[256];
+    int t = threadIdx.x, base = blockIdx.x * LH_SCAN_TILE + t * 8;
+    i64 s = 0;
+    for (int u = 0; u < 8; ++u) s += scan_val(in, base + u, n, add, at_least);
+    part[t] = s;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (t < d) part[t] += part[t + d];
+        __syncthreads();
+    }
+    if (t == 0) tile_sum[blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(256) k_scan_tiles(int n_tiles, i64* __restrict__ tile_sum) {   // in place: exclusive scan, total at [n_tiles]
     __shared__ i64 part[256];
     __shared__ i64 carry_s;
     int t = threadIdx.x;
     if (t == 0) carry_s = 0;
     __syncthreads();
-    const int PER = 8;
-    for (int base = 0; base < n; base += 256 * PER) {
-        i64 loc[PER];
-        i64 sum = 0;
-        for (int u = 0; u < PER; ++u) {
-            int i = base + t * PER + u;
-            i64 v = 0;
-            if (i < n) { v = (i64)in[i] + add; if (v < at_least) v = at_least; }
-            loc[u] = sum;
-            sum += v;
-        }
-        part[t] = sum;
+    for (int base = 0; base < n_tiles; base += 256) {
+        int i = base + t;
+        i64 v = i < n_tiles ? tile_sum[i] : 0;
+        part[t] = v;
         __syncthreads();
-        // Hillis-Steele inclusive scan over the 256 partial sums
         for (int d = 1; d < 256; d <<= 1) {
-            i64 v = t >= d ? part[t - d] : 0;
+            i64 o = t >= d ? part[t - d] : 0;
             __syncthreads();
-            part[t] += v;
+            part[t] += o;
             __syncthreads();
         }
-        i64 excl = (t ? part[t - 1] : 0) + carry_s;
-        for (int u = 0; u < PER; ++u) {
-            int i = base + t * PER + u;
-            if (i < n) out[i] = excl + loc[u];
-        }
+        i64 excl = part[t] - v + carry_s;
         __syncthreads();
+        if (i < n_tiles) tile_sum[i] = excl;
         if (t == 255) carry_s += part[255];
         __syncthreads();
     }
-    if (t == 0) out[n] = carry_s;
+    if (t == 0) tile_sum[n_tiles] = carry_s;
+}
+__global__ void __launch_bounds__(256) k_scan_final(int n, const int32_t* __restrict__ in, int add, int at_least, const i64* __restrict__ tile_sum, int n_tiles,
+                                                    i64* __restrict__ out) {
+    __shared__ i64 part[256];
+    int t = threadIdx.x, base = blockIdx.x * LH_SCAN_TILE + t * 8;
+    i64 loc[8], s = 0;
+    for (int u = 0; u < 8; ++u) { loc[u] = s; s += scan_val(in, base + u, n, add, at_least); }
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        i64 o = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += o;
+        __syncthreads();
+    }
+    i64 excl = part[t] - s + tile_sum[blockIdx.x];
+    for (int u = 0; u < 8; ++u) if (base + u < n) out[base + u] = excl + loc[u];
+    if (blockIdx.x == 0 && t == 0) out[n] = tile_sum[n_tiles];
 }
 
 // K2.  one lane per seed; grid-stride over the pool.

@@ -41,9 +41,9 @@ __device__ __forceinline__ DIntv coop_extend(const DIndex& ix, const DIntv& ik, 
     int nfull = (int)((kk & 127) >> 4);
     uint32_t pm = 0x55555555u & ~((1u << ((~(uint32_t)kk & 15) << 1)) - 1);
     uint32_t x = none ? 0u : (w < nfull ? occ_word(word, 0x55555555u) : (w == nfull ? occ_word(word, pm) : 0u));
-    x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4);
+    x += dpp_xor1(x); x += dpp_xor2(x); x += dpp_half_mirror(x);   // sum over the 8 lanes of the half-row
     u64 cnt = cntv + ((x >> ((w & 3) << 3)) & 0xff);   // lanes w < 4: occ of base w up to k
-    u64 other = shfl_u64(cnt, lane ^ 8);
+    u64 other = dpp_ror8_u64(cnt);   // lane ^ 8 within the 16-lane row
     u64 tk = half ? other : cnt, tl = half ? cnt : other;
     u64 size = tl - tk;                                  // lanes w < 4: ok[w].x[2]
     u64 s0 = shfl_u64(size, gb), s1 = shfl_u64(size, gb + 1), s2 = shfl_u64(size, gb + 2), s3 = shfl_u64(size, gb + 3);

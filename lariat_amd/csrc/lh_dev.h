@@ -136,6 +136,20 @@ __device__ __forceinline__ int wave_scan_max_i32(int v, int lane) {
 }
 __device__ __forceinline__ int lanes_below(u64 mask, int lane) { return __popcll(mask & ((1ull << lane) - 1)); }
 
+// DPP lane exchanges inside a 16-lane row (1 VALU op instead of an LDS-crossbar ds_bpermute round trip)
+#ifdef LH_EMU
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return __shfl_xor(v, 1); }
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return __shfl_xor(v, 2); }
+__device__ __forceinline__ uint32_t dpp_half_mirror(uint32_t v) { return __shfl(v, (LANE() & ~7) | (7 - (LANE() & 7))); }
+__device__ __forceinline__ uint32_t dpp_ror8(uint32_t v) { return __shfl_xor(v, 8); }
+#else
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ uint32_t dpp_half_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); }   // row_half_mirror
+__device__ __forceinline__ uint32_t dpp_ror8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); }   // row_ror:8
+#endif
+__device__ __forceinline__ u64 dpp_ror8_u64(u64 v) { return (u64)dpp_ror8((uint32_t)(v >> 32)) << 32 | dpp_ror8((uint32_t)v); }
+
 // ------------------------------------------------------------------ FM-index primitives (restated from BWA bwt.c)
 // packed per-base counts of the 16 symbols of w under the 2-bit-position mask `valid` (0x55555555 = all 16)
 __device__ __forceinline__ uint32_t occ_word(uint32_t w, uint32_t valid) {

@@ -14,7 +14,7 @@ ap.add_argument("--genome-mb", type=float, default=16)
 ap.add_argument("--barcodes", type=int, default=1000)
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
-lib = capi.load_library()
+lib = capi.load_library(os.environ.get('LH_LIB'))
 t = time.time()
 contigs = synth.make_genome([int(a.genome_mb * 1e6)], seed=20261002)
 prefix = "/tmp/lh_genome_%g" % a.genome_mb
