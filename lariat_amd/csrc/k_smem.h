@@ -34,26 +34,33 @@ __device__ __forceinline__ DIntv coop_extend(const DIndex& ix, const DIntv& ik, 
     int half = (lane >> 3) & 1, w = lane & 7, gb = lane & ~15;
     u64 k = half ? xa - 1 + ik.x2 : xa - 1;
     int none = (k == (u64)-1);
-    u64 kk = k - (k >= ix.primary);
+    u64 kk = none ? 0 : k - (k >= ix.primary);
+    // straight-line code: both loads of the row are issued back to back (no branch around either)
     const uint32_t* blk = ix.bwt + ((kk >> 7) << 4);
-    uint32_t word = none ? 0u : blk[8 + w];
-    u64 cntv = (w < 4 && !none) ? ((const u64*)blk)[w] : 0;
+    uint32_t word = blk[8 + w];
+    u64 cntv = ((const u64*)blk)[w & 3];
     int nfull = (int)((kk & 127) >> 4);
     uint32_t pm = 0x55555555u & ~((1u << ((~(uint32_t)kk & 15) << 1)) - 1);
-    uint32_t x = none ? 0u : (w < nfull ? occ_word(word, 0x55555555u) : (w == nfull ? occ_word(word, pm) : 0u));
+    uint32_t msk = w < nfull ? 0x55555555u : (w == nfull ? pm : 0u);
+    uint32_t x = occ_word(word, msk);
+    if (none) { x = 0; cntv = 0; }
+    if (w >= 4) cntv = 0;
     x += dpp_xor1(x); x += dpp_xor2(x); x += dpp_half_mirror(x);   // sum over the 8 lanes of the half-row
     u64 cnt = cntv + ((x >> ((w & 3) << 3)) & 0xff);   // lanes w < 4: occ of base w up to k
     u64 other = dpp_ror8_u64(cnt);   // lane ^ 8 within the 16-lane row
     u64 tk = half ? other : cnt, tl = half ? cnt : other;
     u64 size = tl - tk;                                  // lanes w < 4: ok[w].x[2]
-    u64 s0 = shfl_u64(size, gb), s1 = shfl_u64(size, gb + 1), s2 = shfl_u64(size, gb + 2), s3 = shfl_u64(size, gb + 3);
-    u64 tkc = shfl_u64(tk, gb + c);
+    // lanes 0-3 of the row are one quad holding tk[w], size[w]: share the four sizes by DPP, let lane c assemble ok[c],
+    // then one round of (independent) ds_bpermute broadcasts it to the row
+    u64 s1 = dpp_quad_bcast_u64<1>(size), s2 = dpp_quad_bcast_u64<2>(size), s3 = dpp_quad_bcast_u64<3>(size);
     u64 acc = xb + ((xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) ? 1 : 0);   // ok[3].x[is_back]
-    u64 o3 = acc, o2 = o3 + s3, o1 = o2 + s2, o0 = o1 + s1;
-    u64 na = (c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3]) + 1 + tkc;
-    u64 nb = c == 0 ? o0 : c == 1 ? o1 : c == 2 ? o2 : o3;
+    u64 nbw = acc + (w < 3 ? s3 : 0) + (w < 2 ? s2 : 0) + (w < 1 ? s1 : 0);        // ok[w].x[is_back]
+    u64 l2w = w == 0 ? ix.L2[0] : w == 1 ? ix.L2[1] : w == 2 ? ix.L2[2] : ix.L2[3];
+    u64 naw = l2w + 1 + tk;                                                        // ok[w].x[!is_back]
+    int src = gb + c;
+    u64 na = shfl_u64(naw, src), nb = shfl_u64(nbw, src);
     DIntv o;
-    o.x2 = c == 0 ? s0 : c == 1 ? s1 : c == 2 ? s2 : s3;
+    o.x2 = shfl_u64(size, src);
     if (is_back) { o.x0 = na; o.x1 = nb; } else { o.x1 = na; o.x0 = nb; }
     o.info = 0;
     return o;
@@ -194,7 +201,7 @@ __device__ __forceinline__ int wave_seed_strategy1(const DIndex& ix, int len, co
 }
 
 // K1.  grid = min(n_reads, resident waves); each wave strides over reads.
-__global__ void __launch_bounds__(64) k_smem(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+__global__ void __launch_bounds__(64, 8) k_smem(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                               DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ seed_cnt,
                                               int32_t* __restrict__ l_rep_out, int32_t* __restrict__ status, DIntv* __restrict__ spill,
                                               DCounters* __restrict__ ctr) {

@@ -148,6 +148,14 @@ __device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__bu
 __device__ __forceinline__ uint32_t dpp_half_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); }   // row_half_mirror
 __device__ __forceinline__ uint32_t dpp_ror8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); }   // row_ror:8
 #endif
+#ifdef LH_EMU
+template <int K> __device__ __forceinline__ uint32_t dpp_quad_bcast(uint32_t v) { return __shfl(v, (LANE() & ~3) | K); }
+#else
+template <int K> __device__ __forceinline__ uint32_t dpp_quad_bcast(uint32_t v) {   // quad_perm [K,K,K,K]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | K << 2 | K << 4 | K << 6, 0xF, 0xF, true);
+}
+#endif
+template <int K> __device__ __forceinline__ u64 dpp_quad_bcast_u64(u64 v) { return (u64)dpp_quad_bcast<K>((uint32_t)(v >> 32)) << 32 | dpp_quad_bcast<K>((uint32_t)v); }
 __device__ __forceinline__ u64 dpp_ror8_u64(u64 v) { return (u64)dpp_ror8((uint32_t)(v >> 32)) << 32 | dpp_ror8((uint32_t)v); }
 
 // ------------------------------------------------------------------ FM-index primitives (restated from BWA bwt.c)
