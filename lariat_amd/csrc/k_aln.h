@@ -240,5 +240,5 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
         }
         if (lane == 0 && st) status[r] |= st;
     }
-    if (lane == 0 && ctr && cells) atomicAdd(&ctr->glob_cells, cells);
+    if (lane == 0 && ctr && cells) atomicAdd(&LH_CTR(ctr)->glob_cells, cells);
 }

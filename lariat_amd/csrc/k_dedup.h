@@ -129,6 +129,6 @@ __global__ void __launch_bounds__(64) k_dedup(DIndex ix, DOpts o, int n_reads, c
     best = wave_max_i32(best);
     if (lane == 0) {
         n_regs[r] = n; best_score[r] = best;
-        if (ctr && cells) atomicAdd(&ctr->glob_cells, cells);
+        if (ctr && cells) atomicAdd(&LH_CTR(ctr)->glob_cells, cells);
     }
 }

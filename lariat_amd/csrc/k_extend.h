@@ -39,13 +39,12 @@ __device__ __forceinline__ i64 wave_max_i64(i64 v) {
         }                                                                                                       \
         int bj = in ? tins + (j + 1) * e_ins : LH_NEG_INF;                                                      \
         int incl = wave_scan_max_i32(bj, lane);                                                                 \
-        int excl = __shfl_up(incl, 1);                                                                          \
-        if (lane == 0) excl = LH_NEG_INF;                                                                       \
+        int excl = wave_shr1_i32(incl, LH_NEG_INF);                                                             \
         int G = gcarry > excl ? gcarry : excl;                                                                  \
         int f = G - j * e_ins;                                                                                  \
         int h = M > e ? M : e; h = h > f ? h : f;                                                               \
         if (!in) h = 0;                                                                                         \
-        int last = __shfl(incl, 63);                                                                            \
+        int last = wave_readlane(incl, 63);                                                                            \
         gcarry = gcarry > last ? gcarry : last;                                                                 \
         /* row maximum, last j among equal maxima */                                                            \
         int hm = in ? h : -1;                                                                                   \
@@ -55,9 +54,8 @@ __device__ __forceinline__ i64 wave_max_i64(i64 v) {
             m = smax; mj = 64 * (T) + 63 - __clzll(bm);                                                         \
         }                                                                                                       \
         /* write back eh[]: eh[j].h = H(i,j-1) for beg<j<=end, eh[beg].h = first-column value, eh[j].e, eh[end].e = 0 */ \
-        int hleft = __shfl_up(h, 1);                                                                            \
-        if (lane == 0) hleft = hcarry;                                                                          \
-        hcarry = __shfl(h, 63);                                                                                 \
+        int hleft = wave_shr1_i32(h, hcarry);                                                                   \
+        hcarry = wave_readlane(h, 63);                                                                                 \
         if (j == beg && beg < end) H##T = h1_init;                                                              \
         else if (j > beg && j <= end) H##T = hleft;                                                             \
         if (in) E##T = enew;                                                                                    \
@@ -107,7 +105,7 @@ __device__ __forceinline__ ExtRes wave_ksw_extend2(const DIndex& ix, const DOpts
             int ii = i + lane;
             tchunk = ii < tlen ? dev_ref_base(ix, tcoord0 + (i64)tstep * ii) : 4;
         }
-        int tb = __shfl(tchunk, i & 63);
+        int tb = wave_readlane(tchunk, i & 63);
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
@@ -121,7 +119,7 @@ __device__ __forceinline__ ExtRes wave_ksw_extend2(const DIndex& ix, const DOpts
         if (end > beg) ncell += (u64)(end - beg);
         // h1 after the row = H(i,end-1), or the first-column value if the window is empty
         int h1 = h1_init;
-        if (beg < end) { int src = (end - 1) & 63; h1 = __shfl(hlast_l, src); }
+        if (beg < end) { int src = (end - 1) & 63; h1 = wave_readlane(hlast_l, src); }
         int j_after = beg < end ? end : beg;
         if (j_after == qlen) {
             max_ie = gscore > h1 ? max_ie : i;
@@ -334,6 +332,6 @@ __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, 
     }
     if (lane == 0) {
         n_regs[r] = n_av;
-        if (ctr) { atomicAdd(&ctr->ext_cells, cells); atomicAdd(&ctr->win_bases, win); atomicAdd(&ctr->n_chain_ext, (u64)nch); }
+        if (ctr) { atomicAdd(&LH_CTR(ctr)->ext_cells, cells); atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }
     }
 }

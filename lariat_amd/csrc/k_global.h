@@ -24,11 +24,10 @@
         }                                                                                                  \
         int bj = in ? tins + (j + 1) * e_ins : -0x7fffffff;                                                \
         int incl = wave_scan_max_i32(bj, lane);                                                            \
-        int excl = __shfl_up(incl, 1);                                                                     \
-        if (lane == 0) excl = -0x7fffffff;                                                                 \
+        int excl = wave_shr1_i32(incl, -0x7fffffff);                                                       \
         int G = gcarry > excl ? gcarry : excl;                                                             \
         int f = G - j * e_ins;                                                                             \
-        int last = __shfl(incl, 63);                                                                       \
+        int last = wave_readlane(incl, 63);                                                                       \
         gcarry = gcarry > last ? gcarry : last;                                                            \
         int h = 0;                                                                                         \
         if (in) {                                                                                          \
@@ -44,9 +43,8 @@
             d |= fd > tins ? 2 << 4 : 0;                                                                   \
             if (zrow) zrow[j - beg] = (uint8_t)d;                                                          \
         }                                                                                                  \
-        int hleft = __shfl_up(h, 1);                                                                       \
-        if (lane == 0) hleft = hcarry;                                                                     \
-        hcarry = __shfl(h, 63);                                                                            \
+        int hleft = wave_shr1_i32(h, hcarry);                                                              \
+        hcarry = wave_readlane(h, 63);                                                                            \
         if (j == beg && beg < end) H##T = h1_init;                                                         \
         else if (j > beg && j <= end) H##T = hleft;                                                        \
         if (in) E##T = enew;                                                                               \
@@ -77,7 +75,7 @@ __device__ __forceinline__ int wave_ksw_global2(const DIndex& ix, const DOpts& o
             int ii = i + lane;
             tchunk = ii < tlen ? dev_ref_base(ix, tcoord0 + (i64)tstep * ii) : 4;
         }
-        int tb = __shfl(tchunk, i & 63);
+        int tb = wave_readlane(tchunk, i & 63);
         int beg = i > w ? i - w : 0;
         int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : LH_MINUS_INF;
@@ -91,7 +89,7 @@ __device__ __forceinline__ int wave_ksw_global2(const DIndex& ix, const DOpts& o
     // score = eh[qlen].h
     int src = qlen & 63, slab = qlen >> 6;
     int v = slab == 0 ? H0 : slab == 1 ? H1 : slab == 2 ? H2 : H3;
-    return __shfl(v, src);
+    return wave_readlane(v, src);
 }
 
 // bwa_gen_cigar2 without traceback: global score of query[qb_..qe_) against the fwd||rev reference interval [rb,re).

@@ -23,9 +23,8 @@ __device__ __forceinline__ int sat0(int x) { return x < 0 ? 0 : x; }
     if (64 * (T) < ncol) {                                                                                    \
         int k = 64 * (T) + lane;                                                                              \
         int in = k < ncol;                                                                                    \
-        int hd = __shfl_up(HP##T, 1);                       /* H'(i-1,k-1) */                                  \
-        if (lane == 0) hd = hdcarry;                                                                          \
-        hdcarry = __shfl(HP##T, 63);                                                                          \
+        int hd = wave_shr1_i32(HP##T, hdcarry);             /* H'(i-1,k-1) */                                  \
+        hdcarry = wave_readlane(HP##T, 63);                                                                          \
         int qv = qb##T;                                                                                       \
         int sc = k >= qlen ? 0 : ((tb > 3 || qv > 3) ? -1 : (tb == qv ? a_ : -b_));                           \
         int hnf = sat0(hd + sc);                                                                              \
@@ -36,11 +35,10 @@ __device__ __forceinline__ int sat0(int x) { return x < 0 ? 0 : x; }
         int c1 = in ? cand : -0x3fffffff;                                                                     \
         int c2 = in ? cand + LH_SEG_OFF + LH_SEG_BIG * sg##T : -0x3fffffff;   /* stripe id in the high part */ \
         int i1 = wave_scan_max_i32(c1, lane), i2 = wave_scan_max_i32(c2, lane);                               \
-        int x1 = __shfl_up(i1, 1), x2 = __shfl_up(i2, 1);                                                     \
-        if (lane == 0) { x1 = -0x3fffffff; x2 = -0x3fffffff; }                                                \
+        int x1 = wave_shr1_i32(i1, -0x3fffffff), x2 = wave_shr1_i32(i2, -0x3fffffff);                         \
         x1 = x1 > fcarry ? x1 : fcarry;                                                                       \
         x2 = x2 > scarry ? x2 : scarry;                                                                       \
-        int l1_ = __shfl(i1, 63), l2_ = __shfl(i2, 63);                                                       \
+        int l1_ = wave_readlane(i1, 63), l2_ = wave_readlane(i2, 63);                                                       \
         fcarry = fcarry > l1_ ? fcarry : l1_;                                                                 \
         scarry = scarry > l2_ ? scarry : l2_;                                                                 \
         int ffull = sat0(x1 - k * e_ins);                                                                     \
@@ -79,7 +77,7 @@ __device__ __forceinline__ void wave_ksw_u8(const DIndex& ix, const DOpts& o, co
             int ii = i + lane;
             tchunk = ii < tlen ? dev_ref_base(ix, tcoord0 + (i64)tstep * ii) : 4;
         }
-        int tb = __shfl(tchunk, i & 63);
+        int tb = wave_readlane(tchunk, i & 63);
         int imax = 0, hdcarry = 0, fcarry = -0x3fffffff, scarry = -0x3fffffff;
         LH_U8_SLAB(0) LH_U8_SLAB(1) LH_U8_SLAB(2) LH_U8_SLAB(3)
         ncell += (u64)ncol;
@@ -232,6 +230,6 @@ __global__ void __launch_bounds__(64) k_rescue(DIndex ix, DOpts o, int n_pairs, 
     }
     if (lane == 0) {
         n_regs[r1] = n1; n_regs[r2] = n2;
-        if (ctr && n_sw) { atomicAdd(&ctr->n_rescue, (u64)n_sw); atomicAdd(&ctr->rescue_cells, cells); }
+        if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); }
     }
 }

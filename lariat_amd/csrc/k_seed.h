@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_seed(DIndex ix, DOpts o, int n_reads, c
         }
         if (ctr) {
             int tl = wave_sum_i32(nlf), ts = wave_sum_i32(nsa);
-            if (LANE() == 0 && ts) { atomicAdd(&ctr->n_lf, (u64)tl); atomicAdd(&ctr->n_sa, (u64)ts); }
+            if (LANE() == 0 && ts) { atomicAdd(&LH_CTR(ctr)->n_lf, (u64)tl); atomicAdd(&LH_CTR(ctr)->n_sa, (u64)ts); }
         }
     }
 }

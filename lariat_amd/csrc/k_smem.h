@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(64, 8) k_smem(DIndex ix, DOpts o, int n_reads,
     if (so.overflow) st |= LH_ST_INTV_OVERFLOW;
     if (lane == 0) {
         n_intv[r] = n; seed_cnt[r] = total; l_rep_out[r] = l_rep; status[r] = st;
-        if (ctr) atomicAdd(&ctr->n_ext, (u64)so.n_ext);
+        if (ctr) atomicAdd(&LH_CTR(ctr)->n_ext, (u64)so.n_ext);
     }
     WAVE_SYNC();
     }

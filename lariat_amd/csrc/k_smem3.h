@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_smem3(DIndex ix, DOpts o, int n_reads, 
     }
     if (ctr) {
         unsigned tot = (unsigned)wave_sum_i32((int)n_ext_total);
-        if (LANE() == 0 && tot) atomicAdd(&ctr->n_ext, (u64)tot);
+        if (LANE() == 0 && tot) atomicAdd(&LH_CTR(ctr)->n_ext, (u64)tot);
     }
 }
 

@@ -103,7 +103,11 @@ struct DReg {   // mem_alnreg_t
     float frac_rep;
 };
 
-struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells; };
+// telemetry counters: LH_CTR_SLOTS copies on separate 128-B lines, indexed by blockIdx, summed by the host
+// (same-address atomics serialize at ~12 ns each: one shared copy cost k_extend ~70 ms per 2M waves)
+#define LH_CTR_SLOTS 64
+struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells, pad[7]; };
+#define LH_CTR(ctr) ((ctr) + (blockIdx.x & (LH_CTR_SLOTS - 1)))
 
 // ------------------------------------------------------------------ lane helpers
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
@@ -117,6 +121,7 @@ __device__ __forceinline__ u64 shfl_up_u64(u64 v, int d) {
     lo = __shfl_up(lo, d); hi = __shfl_up(hi, d);
     return (u64)hi << 32 | lo;
 }
+#ifdef LH_EMU
 __device__ __forceinline__ int wave_max_i32(int v) {
     for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v > o ? v : o; }
     return v;
@@ -134,6 +139,37 @@ __device__ __forceinline__ int wave_scan_max_i32(int v, int lane) {
     for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d); if (lane >= d) v = v > o ? v : o; }
     return v;
 }
+__device__ __forceinline__ int wave_shr1_i32(int v, int fill) { int o = __shfl_up(v, 1); return LANE() == 0 ? fill : o; }   // lane i <- lane i-1
+__device__ __forceinline__ int wave_readlane(int v, int l) { return __shfl(v, l); }                                          // l must be wave-uniform
+#else
+// gfx9 DPP: row_shr:n = 0x110+n, row_bcast:15 = 0x142 (row_mask 0xA), row_bcast:31 = 0x143 (row_mask 0xC), wave_shr:1 = 0x138.
+// Disabled / out-of-range lanes keep `old`, which carries the identity.  One VALU op per step instead of a ds_bpermute round trip.
+#define LH_DPP(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xF, false)
+__device__ __forceinline__ int wave_scan_max_i32(int v, int) {
+    const int ID = (int)0x80000000;
+    int t;
+    t = LH_DPP(ID, v, 0x111, 0xF); v = v > t ? v : t;
+    t = LH_DPP(ID, v, 0x112, 0xF); v = v > t ? v : t;
+    t = LH_DPP(ID, v, 0x114, 0xF); v = v > t ? v : t;
+    t = LH_DPP(ID, v, 0x118, 0xF); v = v > t ? v : t;
+    t = LH_DPP(ID, v, 0x142, 0xA); v = v > t ? v : t;
+    t = LH_DPP(ID, v, 0x143, 0xC); v = v > t ? v : t;
+    return v;
+}
+__device__ __forceinline__ int wave_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ int wave_shr1_i32(int v, int fill) { return LH_DPP(fill, v, 0x138, 0xF); }
+__device__ __forceinline__ int wave_max_i32(int v) { return wave_readlane(wave_scan_max_i32(v, 0), 63); }
+__device__ __forceinline__ int wave_min_i32(int v) { return -wave_max_i32(-v); }
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += LH_DPP(0, v, 0x111, 0xF);
+    v += LH_DPP(0, v, 0x112, 0xF);
+    v += LH_DPP(0, v, 0x114, 0xF);
+    v += LH_DPP(0, v, 0x118, 0xF);
+    v += LH_DPP(0, v, 0x142, 0xA);
+    v += LH_DPP(0, v, 0x143, 0xC);
+    return wave_readlane(v, 63);
+}
+#endif
 __device__ __forceinline__ int lanes_below(u64 mask, int lane) { return __popcll(mask & ((1ull << lane) - 1)); }
 
 // DPP lane exchanges inside a 16-lane row (1 VALU op instead of an LDS-crossbar ds_bpermute round trip)
