@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
     __shared__ uint8_t q[LH_MAXLEN + 6];
     __shared__ uint8_t tref[LH_MAXT];
     __shared__ uint32_t cg[LH_MAX_CIGAR + 4];
+    __shared__ uint32_t cgo[LH_MAX_CIGAR + 4];
     __shared__ int32_t sh[8];
     int lane = LANE();
     uint8_t* z = zpool + (size_t)blockIdx.x * LH_ZSLAB;
@@ -112,6 +113,7 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
                         score = wave_sum_i32(sc);
                         if (lane == 0) cg[0] = (uint32_t)lq << 4 | 0;
                         n_cigar = 1;
+                        WAVE_SYNC();
                     } else {
                         int max_ins = (int)((double)(((lq + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
                         int max_del = (int)((double)(((lq + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
@@ -146,82 +148,89 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
                         WAVE_SYNC();
                         n_cigar = sh[0]; overflow |= sh[1];
                     }
-                    // NM: mismatches inside M runs + inserted + deleted bases (terminal D excluded)
-                    if (lane == 0) {
+                    // NM: mismatches inside M runs (lane-parallel compare + ballot) + inserted + deleted bases (terminal D excluded)
+                    {
                         int x = 0, y = 0, n_mm = 0, n_gap = 0;
                         for (int k = 0; k < n_cigar; ++k) {
                             int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
                             if (op == 0) {
-                                for (int i = 0; i < len; ++i)
-                                    if (q[qoff + qstep * (x + i)] != tref[y + i]) ++n_mm;
+                                for (int t0 = 0; t0 < len; t0 += 64) {
+                                    int t = t0 + lane;
+                                    int mm = t < len && q[qoff + qstep * (x + t)] != tref[y + t];
+                                    n_mm += __popcll(__ballot(mm));
+                                }
                                 x += len; y += len;
                             } else if (op == 2) {
                                 if (k > 0 && k < n_cigar - 1) n_gap += len;
                                 y += len;
                             } else if (op == 1) { x += len; n_gap += len; }
                         }
-                        sh[2] = n_mm + n_gap;
+                        NM = n_mm + n_gap;
                     }
-                    WAVE_SYNC();
-                    NM = sh[2];
                 }
                 if (score == last_sc || w2 == o.w << 2) break;   // it is possible that global alignment and local alignment give different scores
                 last_sc = score;
                 w2 <<= 1;
             } while (++it < 3 && score < ar.truesc - o.a);
-            // position, clipping, then lariat's CIGAR walk: all sequential, lane 0
+            // position and clipping (lane 0 builds the final CIGAR in LDS), then lariat's CIGAR walk with lanes over the bases of each M run
+            int is_rev;
+            i64 posf = dev_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+            WAVE_SYNC();
             if (lane == 0) {
-                int is_rev;
-                i64 posf = dev_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
-                int nc = n_cigar;
-                int s0 = 0;   // first live op in cg[]
+                int nc = n_cigar, s0 = 0, no = 0, ovf = 0;
                 if (nc > 0) {   // squeeze out leading or trailing deletions (pos is shifted upstream, but lariat ignores that pos)
                     if ((cg[0] & 0xf) == 2) { s0 = 1; nc--; }
                     else if ((cg[nc - 1] & 0xf) == 2) nc--;
                 }
-                uint32_t* out = R.cigar + (size_t)c * LH_MAX_CIGAR;
-                int no = 0;
                 int clip5 = 0, clip3 = 0;
                 if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
-                if (clip5) out[no++] = (uint32_t)clip5 << 4 | 3;
-                for (int u = 0; u < nc && no < LH_MAX_CIGAR; ++u) out[no++] = cg[s0 + u];
-                if (clip3) { if (no < LH_MAX_CIGAR) out[no++] = (uint32_t)clip3 << 4 | 3; else overflow = 1; }
-                if (nc + (clip5 ? 1 : 0) > LH_MAX_CIGAR) overflow = 1;
-                int rid = dev_pos2rid(ix, posf);
-                i64 coff = ix.contig_off[ar.rid];
-                // InterpretAlign (gobwa.go:339-371)
-                i64 Offset = rb < ix.l_pac ? rb - coff : ix.l_pac * 2 - 1 - rb - coff;
-                i64 End = re < ix.l_pac ? re - coff : ix.l_pac * 2 - 1 - re - coff;
-                i64 refStart = Offset, refEnd = End;
-                if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
-                // CIGAR walk in READ orientation (lariat.go:1591-1632).  refSeq[k] == base at fwd||rev coordinate rb + k.
-                int matches = 0, indels = 0, indel_length = 0, soft_clipping = 0, soft_clipping_length = 0, refSeqOffset = 0, readOffset = 0, nmm = 0, mm_ovf = 0;
-                int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
-                int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
-                int refLen = (int)(refEnd - refStart);
-                for (int u = 0; u < no; ++u) {
-                    uint32_t cv = out[is_rev ? no - 1 - u : u];
-                    int op = cv & 0xf, len = (int)(cv >> 4);
-                    if (op == 0) {
-                        matches += len;
-                        for (int t = 0; t < len; ++t) {
-                            int k = refSeqOffset + t;
-                            if (k >= refLen) continue;
-                            if (readOffset + t >= l_query) break;
+                if (clip5) cgo[no++] = (uint32_t)clip5 << 4 | 3;
+                for (int u = 0; u < nc; ++u) { if (no < LH_MAX_CIGAR) cgo[no++] = cg[s0 + u]; else ovf = 1; }
+                if (clip3) { if (no < LH_MAX_CIGAR) cgo[no++] = (uint32_t)clip3 << 4 | 3; else ovf = 1; }
+                sh[3] = no; sh[4] = ovf;
+            }
+            WAVE_SYNC();
+            int no = sh[3];
+            overflow |= sh[4];
+            i64 coff = ix.contig_off[ar.rid];
+            // InterpretAlign (gobwa.go:339-371)
+            i64 Offset = rb < ix.l_pac ? rb - coff : ix.l_pac * 2 - 1 - rb - coff;
+            i64 End = re < ix.l_pac ? re - coff : ix.l_pac * 2 - 1 - re - coff;
+            i64 refStart = Offset, refEnd = End;
+            if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
+            // CIGAR walk in READ orientation (lariat.go:1591-1632).  refSeq[k] == base at fwd||rev coordinate rb + k.
+            int matches = 0, indels = 0, indel_length = 0, soft_clipping = 0, soft_clipping_length = 0, refSeqOffset = 0, readOffset = 0, nmm = 0, mm_ovf = 0;
+            int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
+            int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
+            int refLen = (int)(refEnd - refStart);
+            for (int u = 0; u < no; ++u) {
+                uint32_t cv = cgo[is_rev ? no - 1 - u : u];
+                int op = cv & 0xf, len = (int)(cv >> 4);
+                if (op == 0) {
+                    matches += len;
+                    for (int t0 = 0; t0 < len; t0 += 64) {
+                        int t = t0 + lane, k = refSeqOffset + t;
+                        int mm = 0;
+                        if (t < len && k < refLen && readOffset + t < l_query) {
                             int rbase = (valid && k < rlen) ? tref[rev ? rlen - 1 - k : k] : 255;
-                            if (rbase != q[readOffset + t]) {
-                                if (nmm < LH_MAX_MM) {
-                                    mref[nmm] = is_rev ? (int)refEnd - k : k + (int)refStart;
-                                    mread[nmm] = readOffset + t;
-                                    nmm++;
-                                } else mm_ovf = 1;
-                            }
+                            mm = rbase != q[readOffset + t];
                         }
-                        refSeqOffset += len; readOffset += len;
-                    } else if (op == 1) { indels += 1; indel_length += len; readOffset += len; }
-                    else if (op == 2) { indels += 1; indel_length += len; refSeqOffset += len; }
-                    else if (op == 3) { soft_clipping += 1; soft_clipping_length += len; readOffset += len; }
-                }
+                        u64 bm = __ballot(mm);
+                        if (mm) {
+                            int slot = nmm + lanes_below(bm, lane);
+                            if (slot < LH_MAX_MM) { mref[slot] = is_rev ? (int)refEnd - k : k + (int)refStart; mread[slot] = readOffset + t; }
+                        }
+                        nmm += __popcll(bm);
+                    }
+                    refSeqOffset += len; readOffset += len;
+                } else if (op == 1) { indels += 1; indel_length += len; readOffset += len; }
+                else if (op == 2) { indels += 1; indel_length += len; refSeqOffset += len; }
+                else if (op == 3) { soft_clipping += 1; soft_clipping_length += len; readOffset += len; }
+            }
+            if (nmm > LH_MAX_MM) { mm_ovf = 1; nmm = LH_MAX_MM; }
+            if (lane < no) R.cigar[(size_t)c * LH_MAX_CIGAR + lane] = cgo[lane];
+            if (lane == 0) {
+                int rid = dev_pos2rid(ix, posf);
                 int mismatches = NM - indel_length;
                 matches -= mismatches;
                 if (mismatches < 0) mismatches = 0;

@@ -152,12 +152,15 @@ __device__ __forceinline__ double dev_fast_score(const DCand& R, const DInf& S, 
 }
 
 #define LH_SPLIT_MAX 64
+#define LH_RFA_SORT_LDS 1536   // filtered candidates of a barcode whose position sort is staged in LDS (18 KB)
 
 __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
                                              const u64* __restrict__ name_seed, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S, i64 cand_cap,
                                              uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status) {
     __shared__ int32_t shi[8];
     __shared__ double shd[4];
+    __shared__ i64 spos[LH_RFA_SORT_LDS];
+    __shared__ int32_t sidx[LH_RFA_SORT_LDS];
     int lane = LANE();
     uint8_t* slab = slab_pool + (size_t)blockIdx.x * (size_t)slab_bytes;
     const double improper = o.improper_pair_penalty;
@@ -240,10 +243,25 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
         }
         WAVE_SYNC();
         int ncont = shi[0], NCf = shi[1];
-        for (int k = lane; k < ncont; k += 64) {   // sort.Sort(ByPosition) per contig (lariat.go:1545-1547)
-            int32_t* pl = T.plist + T.coff[k];
-            int n = T.coff[k + 1] - T.coff[k];
-            dev_gosort(n, [&](int i, int j) { return R.pos[c_lo + pl[i]] < R.pos[c_lo + pl[j]]; }, [&](int i, int j) { int t = pl[i]; pl[i] = pl[j]; pl[j] = t; });
+        // sort.Sort(ByPosition) per contig (lariat.go:1545-1547), one lane per contig; keys staged in LDS when they fit
+        if (NCf <= LH_RFA_SORT_LDS) {
+            for (int i = lane; i < NCf; i += 64) { sidx[i] = T.plist[i]; spos[i] = R.pos[c_lo + T.plist[i]]; }
+            WAVE_SYNC();
+            for (int k = lane; k < ncont; k += 64) {
+                int b0 = T.coff[k], n = T.coff[k + 1] - b0;
+                i64* kp = spos + b0;
+                int32_t* ip = sidx + b0;
+                dev_gosort(n, [&](int i, int j) { return kp[i] < kp[j]; },
+                           [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; });
+            }
+            WAVE_SYNC();
+            for (int i = lane; i < NCf; i += 64) T.plist[i] = sidx[i];
+        } else {
+            for (int k = lane; k < ncont; k += 64) {
+                int32_t* pl = T.plist + T.coff[k];
+                int n = T.coff[k + 1] - T.coff[k];
+                dev_gosort(n, [&](int i, int j) { return R.pos[c_lo + pl[i]] < R.pos[c_lo + pl[j]]; }, [&](int i, int j) { int t = pl[i]; pl[i] = pl[j]; pl[j] = t; });
+            }
         }
         WAVE_SYNC();
         int do_rfa = bc_do_rfa[bc] != 0;
