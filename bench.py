@@ -25,6 +25,11 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
+# HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB -> B), collected separately and committed
+# under profiles/ (see DESIGN.md section 4 for the calibration of FETCH_SIZE on this access pattern); None = not measured.
+TRAFFIC = {"k_smem3": (1.455e8 + 5.255e7) * 1024.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +79,7 @@ def main():
     while not os.path.exists(prefix + ".done"):
         time.sleep(0.2)
     idx = lib.index_load(prefix, device=local_rank)
+    idx_bwt_bytes = os.path.getsize(prefix + ".bwt")
     t_index = time.time() - t0
 
     # ---- this rank's barcode range: weak scaling, barcodes [rank*B, (rank+1)*B) of the sorted input ----
@@ -122,13 +128,21 @@ def main():
         dom = max(avg, key=avg.get)
         # roofline of the dominant kernel.  For k_smem: every bwt_extend reads two 64-B occurrence blocks;
         # n_ext is counted by the kernel itself (and equals the oracle's count in the parity tests).
+        smem_bytes = 128.0 * cnt["n_ext"] + 1.0 * int(rs.seq_off[-1])
         alg_bytes = {
-            "k_smem": 128.0 * cnt["n_ext"] + 1.0 * int(rs.seq_off[-1]),
+            "k_smem": smem_bytes, "k_smem3": smem_bytes,
             "k_seed": 64.0 * cnt["n_lf"] + 8.0 * cnt["n_sa"],
         }.get(dom, 0.0)
         achieved = alg_bytes / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
+        # measured ceiling for this access pattern: independent random 64-B block reads from a table the size of the BWT
+        try:
+            ceiling, _ = lib.diag_random_read(max(int(idx_bwt_bytes), 1 << 20), 64, 1 << 26, device=local_rank)
+            ceiling = round(ceiling, 1)
+        except Exception:
+            ceiling = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg[dom], 4),
+                    "traffic": TRAFFIC.get(dom), "algorithmic_bytes_per_launch": alg_bytes,
+                    "practical_ceiling_GBps": ceiling, "avg_launch_ms": round(avg[dom], 4),
                     "kernel_ms": {k: round(v, 3) for k, v in avg.items()}}
         out = {
             "metric": "read-pairs/sec aligned (per-barcode align loop: seeding + SW + RFA/MAPQ), synthetic chr20-like reference",

@@ -221,6 +221,10 @@ void lh_stage_dump_free(lh_stage_dump* d);
 /* GetSeq (gobwa.go:50-80): forward-coordinate slice [start,end) of contig rid as ASCII, reverse-complemented if reversed */
 int lh_get_seq(const lh_index* idx, int32_t rid, int64_t start, int64_t end, int32_t reversed, char* out /* end-start bytes */);
 
+/* diagnostics: rate (GB/s of requested bytes) of independent random reads of `granule_bytes` blocks (multiple of 16)
+ * from a `table_bytes` table in HBM — the practical ceiling for the FM-index walks */
+int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, int64_t n_access, double* gbps, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

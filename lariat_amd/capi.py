@@ -237,6 +237,7 @@ def _declare(L):
     L.lh_stage_dump_resident.argtypes = [C.c_void_p, C.POINTER(LhOpts), C.POINTER(C.POINTER(LhStageDump))]
     L.lh_stage_dump_free.argtypes = [C.POINTER(LhStageDump)]
     L.lh_get_seq.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_char_p]
+    L.lh_diag_random_read.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return L
 
 
@@ -271,6 +272,11 @@ class Library:
                 raise AttributeError(k)
             setattr(o, k, v)
         return o
+
+    def diag_random_read(self, table_bytes, granule_bytes, n_access, device=0):
+        g, ms = C.c_double(), C.c_double()
+        self.check(self.L.lh_diag_random_read(device, int(table_bytes), int(granule_bytes), int(n_access), C.byref(g), C.byref(ms)))
+        return g.value, ms.value
 
     def index_load(self, prefix, device=0):
         h = C.c_void_p()
@@ -409,5 +415,5 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = [
     "lh_last_error", "lh_device_count", "lh_opts_init", "lh_index_load", "lh_index_from_arrays", "lh_index_contigs", "lh_index_l_pac",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
-    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq",
+    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read",
 ]
