@@ -84,9 +84,16 @@ struct RfaTab {   // carved from the wave's slab
     int32_t* newid;      // [NCf] raw molecule -> id after scrap or -1
     int32_t* nreads;     // [NCf] raw: number of distinct reads (best_alignment_for_read.Len())
     double* sval;        // [NCf]
-    int32_t* seen_rid;   // [ncont+2]
+    int32_t* seen_rid;   // [ncont+2]   (contig tables live here when the index has more contigs than the LDS copy holds)
     int32_t* ccnt;       // [ncont+2]
     int32_t* coff;       // [ncont+2]
+    int32_t* kidx;       // [NC] local candidate -> contig slot (first-seen order) or -1 (not filtered)
+    int32_t* molc;       // [NC] local candidate -> raw molecule or -1
+    int32_t* ppos;       // [NC] local candidate -> plist index
+    int32_t* rdl;        // [NCf] local read of plist entry
+    int32_t* firstf;     // [NCf] entry is its read's first occurrence inside its molecule
+    int32_t* actc;       // [NCf+1] step 1: exclusive count of active entries; step 2: first entries' active candidate or -1
+    int32_t* psum;       // [NCf+1] step 1: exclusive count of first entries; step 2: of first entries with an active candidate
     // after scrap (M molecules)
     int32_t* seg0;       // [M] plist range of molecule
     int32_t* seg1;
@@ -100,8 +107,13 @@ struct RfaTab {   // carved from the wave's slab
     int32_t* tset;       // [R]
     int32_t* mflag;      // [M] active_molecule
     double* P;           // [M]
-    int32_t* bestT;      // [M*R]
+    u64 *dk0, *dk1, *dk2, *dk3;   // [R] markDuplicates keys
+    int32_t* htab;       // [<= 4R] open-addressing table over the keys
+    int32_t* bestT;      // [R*M] best_alignment_for_read of molecule m for local read r at [r*M + m]; bit 30: it pairs with
+                         // the molecule's best alignment of the mate read (static after markBest); -1: nil
 };
+#define RFA_T_MASK 0x3fffffff
+#define RFA_T_PAIR 0x40000000
 
 // isActiveMolecule, lariat.go:1309-1319
 __device__ __forceinline__ int dev_mol_active(int alen, int nbest, int change) {
@@ -111,65 +123,109 @@ __device__ __forceinline__ int dev_mol_active(int alen, int nbest, int change) {
     return 1;
 }
 
-// fastScore(source, sink) (lariat.go:1179-1307); returns the score change, *num = reads with an alternative in the sink.
-// If tdel != NULL also records the reads that would move (toDelete/toSet).
-__device__ __forceinline__ double dev_fast_score(const DCand& R, const DInf& S, const RfaTab& T, i64 c_lo, int r0, int nR, int src, int snk, double lup,
-                                                 int* num_out, int32_t* tdel, int32_t* tset, int* nmove) {
+#define LH_SPLIT_MAX 64
+#define LH_RFA_SORT_LDS 1536   // filtered candidates of a barcode whose position sort is staged in LDS (18 KB)
+#define LH_RFA_LDS_BYTES (LH_RFA_SORT_LDS * 12)
+#define LH_RFA_NCONT_LDS 1024  // contig slots of a barcode kept in LDS while grouping (index with more contigs: slab copy)
+#define LH_RFA_SRC_CHUNK 256   // source-molecule alignments staged per pass of fastScore
+
+// fastScore(source, sink) (lariat.go:1179-1307), evaluated by the whole wave: lane L scores sink `snk` (< 0: idle lane).
+// Everything that depends on the source alone (the read, whether its mate is active in the source and pairs with it,
+// its log alignment probability) is computed once by the lanes in parallel and staged in LDS; every lane then walks the
+// source's active alignments in OrderedAlignmentMap order, so each sink's sums keep the reference's order of additions.
+// Returns the score change, *num_out = reads with an alternative in the sink; with `record` the lane also writes the
+// reads that would move (toDelete / toSet) to T.tdel / T.tset and their number to *nmove.
+__device__ __forceinline__ double dev_fast_score_w(const DCand& R, const DInf& S, const RfaTab& T, i64 c_lo, int r0, int M, int src, int snk, double lup,
+                                                   int32_t* sLr, int32_t* sFl, double* sLap, int* num_out, int record, int* nmove) {
+    const int lane = LANE();
     double change = 0, alignment_change = 0;
     int num = 0, nm = 0;
-    int n = T.alen[src], ao = T.aoff[src];
-    for (int s = 0; s < n; ++s) {
-        int a = T.act_store[ao + s];
-        int lr = S.cand_read[c_lo + a] - r0;   // local read id
-        int t = T.bestT[(size_t)snk * nR + lr];
-        if (t >= 0) {
-            int ml = lr ^ 1;
-            int sm = T.act_cand[ml];
-            int source_has_mate = sm >= 0 && S.molecule_id[c_lo + sm] == src;
-            int source_has_mate_pair = source_has_mate && dev_is_pair(R, c_lo + a, c_lo + sm);
-            int tm = T.bestT[(size_t)snk * nR + ml];
-            int sink_has_mate_pair = tm >= 0 && dev_is_pair(R, c_lo + t, c_lo + tm) && source_has_mate;
-            if (!source_has_mate_pair || (source_has_mate && sink_has_mate_pair)) {
-                if (tdel) { tdel[nm] = lr; tset[nm] = t; }
-                nm++;
+    const int n = T.alen[src], ao = T.aoff[src];
+    for (int cb = 0; cb < n; cb += LH_RFA_SRC_CHUNK) {
+        int cn = n - cb < LH_RFA_SRC_CHUNK ? n - cb : LH_RFA_SRC_CHUNK;
+        EMU_SYNC();   // the previous chunk has been consumed
+        for (int s = lane; s < cn; s += 64) {
+            int a = T.act_store[ao + cb + s];
+            int lr = S.cand_read[c_lo + a] - r0;
+            int sm = T.act_cand[lr ^ 1];
+            int hm = sm >= 0 && S.molecule_id[c_lo + sm] == src;          // source_has_mate
+            int hp = hm && dev_is_pair(R, c_lo + a, c_lo + sm);           // source_has_mate_pair
+            sLr[s] = lr; sFl[s] = hm | hp << 1; sLap[s] = R.lap[c_lo + a];
+        }
+        WAVE_SYNC();
+        if (snk >= 0) {
+            for (int s = 0; s < cn; ++s) {
+                int lr = sLr[s];
+                int tq = T.bestT[(size_t)lr * M + snk];
+                if (tq >= 0) {
+                    int t = tq & RFA_T_MASK, fl = sFl[s];
+                    int hm = fl & 1, hp = fl >> 1;
+                    int skp = (tq & RFA_T_PAIR) && hm;                    // sink_has_mate_pair
+                    if (!hp || (hm && skp)) {
+                        if (record) { T.tdel[nm] = lr; T.tset[nm] = t; }
+                        nm++;
+                    }
+                    alignment_change += R.lap[c_lo + t] - sLap[s];
+                    if (hp && !skp) alignment_change += lup / 2.0;
+                    else if (!hp && skp) alignment_change -= lup / 2.0;
+                    num++;
+                }
             }
-            alignment_change += R.lap[c_lo + t] - R.lap[c_lo + a];
-            if (source_has_mate_pair && !sink_has_mate_pair) alignment_change += lup / 2.0;
-            else if (!source_has_mate_pair && sink_has_mate_pair) alignment_change -= lup / 2.0;
-            num++;
         }
     }
-    int sb = dev_mol_active(T.alen[src], T.nbest[src], 0), sa = dev_mol_active(T.alen[src], T.nbest[src], -num);
-    if (!sa && sb) change -= (double)T.nbest[src] * -0.5;
-    int kb = dev_mol_active(T.alen[snk], T.nbest[snk], 0), ka = dev_mol_active(T.alen[snk], T.nbest[snk], num);
-    if (ka && !kb) change += (double)T.nbest[snk] * -0.5;
-    if (T.alen[src] - num == 0 && num > 0) change -= -3.0;
-    if (T.alen[snk] == 0 && num > 0) change += -3.0;
-    change += alignment_change;
+    if (snk >= 0) {
+        int sb = dev_mol_active(T.alen[src], T.nbest[src], 0), sa = dev_mol_active(T.alen[src], T.nbest[src], -num);
+        if (!sa && sb) change -= (double)T.nbest[src] * -0.5;
+        int kb = dev_mol_active(T.alen[snk], T.nbest[snk], 0), ka = dev_mol_active(T.alen[snk], T.nbest[snk], num);
+        if (ka && !kb) change += (double)T.nbest[snk] * -0.5;
+        if (T.alen[src] - num == 0 && num > 0) change -= -3.0;
+        if (T.alen[snk] == 0 && num > 0) change += -3.0;
+        change += alignment_change;
+    }
     *num_out = num;
     if (nmove) *nmove = nm;
     return change;
 }
 
-#define LH_SPLIT_MAX 64
-#define LH_RFA_SORT_LDS 1536   // filtered candidates of a barcode whose position sort is staged in LDS (18 KB)
+__device__ __forceinline__ u64 dev_mix64(u64 x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
 
+#ifdef LH_RFA_PROF   // development aid: per-phase wall-clock (100 MHz ticks -> us) summed over waves into lh_dbg[16..]
+#define RFA_T(k) { if (lane == 0) { u64 now_ = wall_clock64(); atomicAdd(&lh_dbg[16 + (k)], (int)((now_ - t_prof) / 100)); t_prof = now_; } }
+#else
+#define RFA_T(k)
+#endif
+
+// One wavefront per barcode; barcodes are handed out through the device counter *bc_next (their costs differ widely).
 __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
                                              const u64* __restrict__ name_seed, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S, i64 cand_cap,
-                                             uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status) {
+                                             uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status, int32_t* __restrict__ bc_next) {
     __shared__ int32_t shi[8];
     __shared__ double shd[4];
-    __shared__ i64 spos[LH_RFA_SORT_LDS];
-    __shared__ int32_t sidx[LH_RFA_SORT_LDS];
-    int lane = LANE();
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LH_RFA_LDS_BYTES];   // one buffer, re-used phase by phase
+    i64* const spos = (i64*)lds_raw;                                               // position sort
+    int32_t* const sidx = (int32_t*)(lds_raw + 8 * LH_RFA_SORT_LDS);
+    int32_t* const sLr = (int32_t*)lds_raw;                                        // fastScore source staging
+    int32_t* const sFl = sLr + LH_RFA_SRC_CHUNK;
+    double* const sLap = (double*)(sFl + LH_RFA_SRC_CHUNK);
+    const int lane = LANE();
     uint8_t* slab = slab_pool + (size_t)blockIdx.x * (size_t)slab_bytes;
     const double improper = o.improper_pair_penalty;
-    for (int bc = blockIdx.x; bc < n_bc; bc += gridDim.x) {
+    for (;;) {
+        if (lane == 0) shi[5] = atomicAdd(bc_next, 1);
+        WAVE_SYNC();
+        const int bc = shi[5];
+        WAVE_SYNC();
+        if (bc >= n_bc) break;
         int p0 = bc_pair_off[bc], p1 = bc_pair_off[bc + 1];
         int nR = 2 * (p1 - p0), r0 = 2 * p0;
         i64 c_lo = R.cand_off[r0], c_hi = R.cand_off[r0 + nR];
         int NC = (int)(c_hi - c_lo);
-        WAVE_SYNC();
+#ifdef LH_RFA_PROF
+        u64 t_prof = wall_clock64();
+#endif
         if (c_hi > cand_cap) continue;   // flagged by k_aln
         // ---- init per-candidate and per-read state (Alignment defaults, lariat.go:1655-1689) ----
         for (int r = lane; r < nR; r += 64) {
@@ -181,6 +237,7 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             S.split_second_best[r0 + r] = 0; S.split_score[r0 + r] = 0; S.split_mapq[r0 + r] = 0;
         }
         WAVE_SYNC();
+        RFA_T(0)
         // ---- tagBestAlignments: one lane per pair.  Read 2 of a pair is always "touched" by read 1 (every read has >= 1
         // filtered candidate), so only read 1's scan decides; its RNG stream is seeded from the read name. ----
         for (int p = p0 + lane; p < p1; p += 64) {
@@ -202,17 +259,22 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             S.active[bm] = 1; S.bwa_pick[bm] = 1;
         }
         WAVE_SYNC();
-        // ---- positions: filtered candidates grouped by contig in first-seen order (lane 0), then Go-sorted by pos ----
-        // slab carve (sizes depend on NC, nR)
+        RFA_T(1)
+        // ---- slab carve (sizes depend on NC, nR) ----
         size_t so = 0;
         RfaTab T;
 #define CARVE(ptr, type, count) { so = (so + 7) & ~(size_t)7; T.ptr = (type*)(slab + so); so += sizeof(type) * (size_t)(count); }
         int ncmax = ix.n_contigs + 2;
+        int hbits = 6;
+        while ((1 << hbits) < 2 * nR) ++hbits;
         CARVE(plist, int32_t, NC) CARVE(molraw, int32_t, NC) CARVE(mstart, int32_t, NC + 1) CARVE(newid, int32_t, NC) CARVE(nreads, int32_t, NC)
         CARVE(sval, double, NC) CARVE(seen_rid, int32_t, ncmax) CARVE(ccnt, int32_t, ncmax) CARVE(coff, int32_t, ncmax + 1)
+        CARVE(kidx, int32_t, NC) CARVE(molc, int32_t, NC) CARVE(ppos, int32_t, NC) CARVE(rdl, int32_t, NC) CARVE(firstf, int32_t, NC)
+        CARVE(actc, int32_t, NC + 1) CARVE(psum, int32_t, NC + 1)
         CARVE(seg0, int32_t, NC) CARVE(seg1, int32_t, NC) CARVE(nbest, int32_t, NC) CARVE(aoff, int32_t, NC) CARVE(alen, int32_t, NC)
         CARVE(act_store, int32_t, NC) CARVE(act_cand, int32_t, nR) CARVE(act_slot, int32_t, nR) CARVE(tdel, int32_t, nR) CARVE(tset, int32_t, nR)
         CARVE(mflag, int32_t, NC) CARVE(P, double, NC)
+        CARVE(dk0, u64, nR) CARVE(dk1, u64, nR) CARVE(dk2, u64, nR) CARVE(dk3, u64, nR) CARVE(htab, int32_t, (size_t)1 << hbits)
         so = (so + 7) & ~(size_t)7;
         T.bestT = (int32_t*)(slab + so);
         size_t best_cap = ((size_t)slab_bytes > so) ? ((size_t)slab_bytes - so) / 4 : 0;
@@ -221,28 +283,67 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             if (lane == 0) status[r0] |= LH_ST_POOL_OVERFLOW;
             continue;
         }
-        if (lane == 0) {
-            int ncont = 0, nf = 0;
-            for (int a = 0; a < NC; ++a) {
-                if (!R.in_filtered[c_lo + a]) continue;
-                int rid = R.rid[c_lo + a], k;
-                for (k = 0; k < ncont; ++k) if (T.seen_rid[k] == rid) break;
-                if (k == ncont) { T.seen_rid[ncont] = rid; T.ccnt[ncont] = 0; ncont++; }
-                T.ccnt[k]++; nf++;
+        // ---- positions: filtered candidates grouped by contig in first-seen order, candidate order inside a contig ----
+        // pass A: contig slot of every candidate (first-seen numbering) and the slot sizes
+        int32_t* const seen = ncmax <= LH_RFA_NCONT_LDS ? (int32_t*)lds_raw : T.seen_rid;
+        int32_t* const scnt = ncmax <= LH_RFA_NCONT_LDS ? (int32_t*)lds_raw + LH_RFA_NCONT_LDS : T.ccnt;
+        int ncont = 0;
+        for (int base = 0; base < NC; base += 64) {
+            int a = base + lane;
+            int valid = a < NC && R.in_filtered[c_lo + a];
+            int rid = valid ? R.rid[c_lo + a] : 0;
+            int k = -1;
+            if (valid) for (int j = ncont - 1; j >= 0; --j) if (seen[j] == rid) { k = j; break; }
+            u64 un = __ballot(valid && k < 0);
+            while (un) {   // contigs met for the first time, in candidate order
+                int leader = __ffsll((unsigned long long)un) - 1;
+                int lrid = wave_readlane(rid, leader);
+                if (lane == 0) { seen[ncont] = lrid; scnt[ncont] = 0; }
+                if (valid && k < 0 && rid == lrid) k = ncont;
+                ncont++;
+                un = __ballot(valid && k < 0);
             }
-            int acc = 0;
-            for (int k = 0; k < ncont; ++k) { T.coff[k] = acc; acc += T.ccnt[k]; T.ccnt[k] = 0; }
-            T.coff[ncont] = acc;
-            for (int a = 0; a < NC; ++a) {
-                if (!R.in_filtered[c_lo + a]) continue;
-                int rid = R.rid[c_lo + a], k;
-                for (k = 0; k < ncont; ++k) if (T.seen_rid[k] == rid) break;
-                T.plist[T.coff[k] + T.ccnt[k]++] = a;
+            WAVE_SYNC();
+            if (a < NC) T.kidx[a] = valid ? k : -1;
+            u64 rem = __ballot(valid);
+            while (rem) {
+                int kk = wave_readlane(k, __ffsll((unsigned long long)rem) - 1);
+                u64 m = __ballot(valid && k == kk);
+                if (lane == 0) scnt[kk] += __popcll(m);
+                rem &= ~m;
             }
-            shi[0] = ncont; shi[1] = nf;
+            WAVE_SYNC();
+        }
+        int NCf = 0;
+        for (int base = 0; base < ncont; base += 64) {   // slot offsets; scnt becomes the running write position
+            int k = base + lane;
+            int c = k < ncont ? scnt[k] : 0;
+            int inc = wave_scan_add_i32(c);
+            EMU_SYNC();
+            if (k < ncont) { T.coff[k] = NCf + inc - c; scnt[k] = NCf + inc - c; }
+            NCf += wave_readlane(inc, 63);
+        }
+        if (lane == 0) T.coff[ncont] = NCf;
+        WAVE_SYNC();
+        // pass B: stable placement
+        for (int base = 0; base < NC; base += 64) {
+            int a = base + lane;
+            int k = a < NC ? T.kidx[a] : -1;
+            int valid = k >= 0;
+            u64 rem = __ballot(valid);
+            while (rem) {
+                int kk = wave_readlane(k, __ffsll((unsigned long long)rem) - 1);
+                u64 m = __ballot(valid && k == kk);
+                int at = scnt[kk];
+                EMU_SYNC();
+                if (valid && k == kk) T.plist[at + lanes_below(m, lane)] = a;
+                if (lane == 0) scnt[kk] = at + __popcll(m);
+                EMU_SYNC();
+                rem &= ~m;
+            }
         }
         WAVE_SYNC();
-        int ncont = shi[0], NCf = shi[1];
+        RFA_T(2)
         // sort.Sort(ByPosition) per contig (lariat.go:1545-1547), one lane per contig; keys staged in LDS when they fit
         if (NCf <= LH_RFA_SORT_LDS) {
             for (int i = lane; i < NCf; i += 64) { sidx[i] = T.plist[i]; spos[i] = R.pos[c_lo + T.plist[i]]; }
@@ -264,97 +365,127 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             }
         }
         WAVE_SYNC();
+        RFA_T(3)
         int do_rfa = bc_do_rfa[bc] != 0;
         int M = 0;
         if (do_rfa) {
+            for (int a = lane; a < NC; a += 64) { T.molc[a] = -1; T.ppos[a] = -1; }
+            WAVE_SYNC();
             // ---- inferMolecules: a gap > 50 kb (or a new contig list) starts a molecule ----
-            if (lane == 0) {
-                int m = -1;
-                for (int k = 0; k < ncont; ++k)
-                    for (int i = T.coff[k]; i < T.coff[k + 1]; ++i) {
-                        if (i == T.coff[k] || R.pos[c_lo + T.plist[i]] - R.pos[c_lo + T.plist[i - 1]] > 50000) { ++m; T.mstart[m] = i; }
-                        T.molraw[i] = m;
+            int Mraw = 0;
+            for (int base = 0; base < NCf; base += 64) {
+                int i = base + lane, st = 0, a = -1;
+                if (i < NCf) {
+                    a = T.plist[i];
+                    st = i == T.coff[T.kidx[a]];
+                    if (!st) st = R.pos[c_lo + a] - R.pos[c_lo + T.plist[i - 1]] > 50000;
+                }
+                u64 mk = __ballot(st);
+                int mi = Mraw + __popcll(mk & ((2ull << lane) - 1)) - 1;
+                if (i < NCf) {
+                    T.molraw[i] = mi; T.molc[a] = mi; T.ppos[a] = i; T.rdl[i] = S.cand_read[c_lo + a] - r0;
+                    if (st) T.mstart[mi] = i;
+                }
+                Mraw += __popcll(mk);
+            }
+            if (lane == 0) T.mstart[Mraw] = NCf;
+            WAVE_SYNC();
+            RFA_T(4)
+            // ---- markBestAlignmentForReadInMolecule, step 1: best pair score of every entry inside its molecule; the
+            // entry's read is counted once per molecule (its first occurrence); molecules with an active alignment ----
+            int nfirst = 0, nactive = 0;
+            for (int base = 0; base < NCf; base += 64) {
+                int i = base + lane, first = 0, isact = 0;
+                if (i < NCf) {
+                    int a = T.plist[i], m = T.molraw[i];
+                    int g = r0 + T.rdl[i], gm = g ^ 1;
+                    double best = -1.7976931348623157e308;
+                    int found = 0;
+                    for (i64 b = R.cand_off[gm]; b < R.cand_off[gm + 1]; ++b) {
+                        if (T.molc[b - c_lo] != m) continue;
+                        found = 1;
+                        double s = dev_score_aln(R, S, improper, c_lo + a, b, 0.0);
+                        if (s > best) best = s;
                     }
-                T.mstart[m + 1] = NCf;
-                shi[2] = m + 1;
-            }
-            WAVE_SYNC();
-            int Mraw = shi[2];
-            // ---- markBestAlignmentForReadInMolecule, step 1: best pair score of every entry inside its molecule ----
-            for (int i = lane; i < NCf; i += 64) {
-                int a = T.plist[i], m = T.molraw[i];
-                int mate_read = S.cand_read[c_lo + a] ^ 1;
-                double best = -1.7976931348623157e308;
-                int found = 0;
-                for (int j = T.mstart[m]; j < T.mstart[m + 1]; ++j) {
-                    int b = T.plist[j];
-                    if (S.cand_read[c_lo + b] != mate_read) continue;
-                    found = 1;
-                    double s = dev_score_aln(R, S, improper, c_lo + a, c_lo + b, 0.0);
-                    if (s > best) best = s;
+                    T.sval[i] = found ? best : R.lap[c_lo + a];
+                    first = 1;
+                    for (i64 b = R.cand_off[g]; b < R.cand_off[g + 1]; ++b)
+                        if (T.molc[b - c_lo] == m && T.ppos[b - c_lo] < i) first = 0;
+                    T.firstf[i] = first;
+                    isact = S.active[c_lo + a] != 0;
                 }
-                T.sval[i] = found ? best : R.lap[c_lo + a];
+                u64 mf = __ballot(first), ma = __ballot(isact);
+                if (i < NCf) { T.psum[i] = nfirst + lanes_below(mf, lane); T.actc[i] = nactive + lanes_below(ma, lane); }
+                nfirst += __popcll(mf); nactive += __popcll(ma);
             }
+            if (lane == 0) { T.psum[NCf] = nfirst; T.actc[NCf] = nactive; }
             WAVE_SYNC();
-            // distinct reads and "has an active alignment" per raw molecule (lane per molecule)
-            for (int m = lane; m < Mraw; m += 64) {
-                int nr = 0, has = 0;
-                for (int i = T.mstart[m]; i < T.mstart[m + 1]; ++i) {
-                    int a = T.plist[i], rd = S.cand_read[c_lo + a], first = 1;
-                    for (int j = T.mstart[m]; j < i; ++j) if (S.cand_read[c_lo + T.plist[j]] == rd) { first = 0; break; }
-                    nr += first;
-                    has |= S.active[c_lo + a];
-                }
-                T.nreads[m] = nr; T.newid[m] = has;
-            }
-            WAVE_SYNC();
+            RFA_T(5)
             // ---- scrapMolecules: keep molecules with an active alignment, renumber ----
-            if (lane == 0) {
-                int cnt = 0, ao = 0;
-                for (int m = 0; m < Mraw; ++m) {
-                    if (T.newid[m]) {
-                        T.newid[m] = cnt; T.seg0[cnt] = T.mstart[m]; T.seg1[cnt] = T.mstart[m + 1]; T.nbest[cnt] = T.nreads[m]; T.aoff[cnt] = ao; T.alen[cnt] = 0;
-                        ao += T.nreads[m]; cnt++;
-                    } else T.newid[m] = -1;
-                }
-                shi[3] = cnt;
-                shi[4] = ((size_t)cnt * (size_t)nR > best_cap) ? 1 : 0;
+            int ao = 0;
+            for (int base = 0; base < Mraw; base += 64) {
+                int m = base + lane;
+                int keep = m < Mraw && T.actc[T.mstart[m + 1]] - T.actc[T.mstart[m]] > 0;
+                int nr = keep ? T.psum[T.mstart[m + 1]] - T.psum[T.mstart[m]] : 0;
+                u64 mk = __ballot(keep);
+                int id = M + lanes_below(mk, lane);
+                int inc = wave_scan_add_i32(nr);
+                if (keep) { T.newid[m] = id; T.seg0[id] = T.mstart[m]; T.seg1[id] = T.mstart[m + 1]; T.nbest[id] = nr; T.aoff[id] = ao + inc - nr; T.alen[id] = 0; }
+                else if (m < Mraw) T.newid[m] = -1;
+                M += __popcll(mk);
+                ao += wave_readlane(inc, 63);
             }
             WAVE_SYNC();
-            M = shi[3];
-            if (shi[4]) {   // molecule table does not fit the slab
+            if ((size_t)M * (size_t)nR > best_cap) {   // molecule table does not fit the slab
                 if (lane == 0) status[r0] |= LH_ST_POOL_OVERFLOW;
                 continue;
             }
             for (size_t x = lane; x < (size_t)M * nR; x += 64) T.bestT[x] = -1;
             for (int r = lane; r < nR; r += 64) { T.act_cand[r] = -1; T.act_slot[r] = -1; }
-            for (int i = lane; i < NCf; i += 64) {
-                int nm = T.newid[T.molraw[i]];
-                S.molecule_id[c_lo + T.plist[i]] = nm;
-            }
+            for (int i = lane; i < NCf; i += 64) S.molecule_id[c_lo + T.plist[i]] = T.newid[T.molraw[i]];
             WAVE_SYNC();
             // step 2: per molecule, reads in first-occurrence order: best alignment (earliest maximum) and the active list
-            for (int m = lane; m < M; m += 64) {
-                int b0 = T.seg0[m], b1 = T.seg1[m], na = 0;
-                for (int i = b0; i < b1; ++i) {
-                    int a = T.plist[i], rd = S.cand_read[c_lo + a], first = 1;
-                    for (int j = b0; j < i; ++j) if (S.cand_read[c_lo + T.plist[j]] == rd) { first = 0; break; }
-                    if (!first) continue;
+            int nact = 0;
+            for (int base = 0; base < NCf; base += 64) {
+                int i = base + lane;
+                int m = -1, isf = 0, act = -1;
+                if (i < NCf) { m = T.newid[T.molraw[i]]; isf = T.firstf[i] && m >= 0; }
+                if (isf) {
+                    int mr = T.molraw[i], g = r0 + T.rdl[i];
                     double best = -1.7976931348623157e308;
-                    int bi = -1, act = -1;
-                    for (int j = i; j < b1; ++j) {
-                        int b = T.plist[j];
-                        if (S.cand_read[c_lo + b] != rd) continue;
-                        if (T.sval[j] > best) { best = T.sval[j]; bi = b; }
-                        if (S.active[c_lo + b]) act = b;
+                    int bi = -1, bpos = 0x7fffffff, apos = -1;
+                    for (i64 b = R.cand_off[g]; b < R.cand_off[g + 1]; ++b) {
+                        int lb = (int)(b - c_lo);
+                        if (T.molc[lb] != mr) continue;
+                        int j = T.ppos[lb];
+                        double sv = T.sval[j];
+                        if (sv > best || (sv == best && j < bpos)) { best = sv; bi = lb; bpos = j; }
+                        if (S.active[b] && j > apos) { apos = j; act = lb; }
                     }
-                    int lr = rd - r0;
-                    T.bestT[(size_t)m * nR + lr] = bi;
-                    if (act >= 0) { T.act_store[T.aoff[m] + na] = act; T.act_cand[lr] = act; T.act_slot[lr] = na; na++; }
+                    T.bestT[(size_t)T.rdl[i] * M + m] = bi;
                 }
-                T.alen[m] = na;
+                int hasact = isf && act >= 0;
+                u64 mk = __ballot(hasact);
+                if (i < NCf) { T.actc[i] = hasact ? act : -1; T.psum[i] = nact + lanes_below(mk, lane); }
+                nact += __popcll(mk);
             }
+            if (lane == 0) T.psum[NCf] = nact;
             WAVE_SYNC();
+            for (int i = lane; i < NCf; i += 64) {
+                int m = T.newid[T.molraw[i]];
+                if (m < 0 || !T.firstf[i]) continue;
+                int lr = T.rdl[i];
+                int t = T.bestT[(size_t)lr * M + m] & RFA_T_MASK, tm = T.bestT[(size_t)(lr ^ 1) * M + m];
+                if (tm >= 0 && dev_is_pair(R, c_lo + t, c_lo + (tm & RFA_T_MASK))) T.bestT[(size_t)lr * M + m] = t | RFA_T_PAIR;
+                int act = T.actc[i];
+                if (act >= 0) {
+                    int slot = T.psum[i] - T.psum[T.seg0[m]];
+                    T.act_store[T.aoff[m] + slot] = act; T.act_cand[lr] = act; T.act_slot[lr] = slot;
+                }
+            }
+            for (int m = lane; m < M; m += 64) T.alen[m] = T.psum[T.seg1[m]] - T.psum[T.seg0[m]];
+            WAVE_SYNC();
+            RFA_T(6)
             // setMoleculeDifferences(candidate_molecules, false) before the optimizer (lariat.go:503): alignments that are
             // active NOW keep this value even if a later move deactivates them
             for (int m = lane; m < M; m += 64) {
@@ -364,17 +495,18 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
                 for (int k = 0; k < T.alen[m]; ++k) S.mol_diff[c_lo + T.act_store[T.aoff[m] + k]] = diff;
             }
             WAVE_SYNC();
+            RFA_T(7)
             // ---- optimizer.Optimize(opt, 1, 2, 4*M): 8*M greedy molecule moves ----
             int source = 0;
             for (int it = 0; it < 8 * M; ++it) {
                 if (T.alen[source] == 0) { source = (source + 1) % M; continue; }
                 double bs = -1.7976931348623157e308;
                 int bl = -1, bi = 0x7fffffff;
-                for (int i = lane; i < M; i += 64) {
-                    if (i == source) continue;
-                    int num;
-                    double sc = dev_fast_score(R, S, T, c_lo, r0, nR, source, i, improper, &num, (int32_t*)0, (int32_t*)0, (int*)0);
-                    if (num > 0 && (sc > bs || (sc == bs && T.alen[i] > bl))) { bs = sc; bl = T.alen[i]; bi = i; }
+                for (int sb = 0; sb < M; sb += 64) {
+                    int i = sb + lane, num;
+                    int snk = (i < M && i != source) ? i : -1;
+                    double sc = dev_fast_score_w(R, S, T, c_lo, r0, M, source, snk, improper, sLr, sFl, sLap, &num, 0, (int*)0);
+                    if (snk >= 0 && num > 0 && (sc > bs || (sc == bs && T.alen[i] > bl))) { bs = sc; bl = T.alen[i]; bi = i; }
                 }
                 for (int msk = 32; msk >= 1; msk >>= 1) {   // lexicographic max of (score, sink size), first index on full ties
                     double os = __shfl_xor(bs, msk);
@@ -383,9 +515,10 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
                     if (take) { bs = os; bl = ol; bi = oi; }
                 }
                 if (bi != 0x7fffffff && (bs > 0 || (bs == 0 && bl > T.alen[source]))) {
-                    if (lane == 0) {   // acceptMove: recompute the move list, then apply it in order
-                        int num, nmv;
-                        dev_fast_score(R, S, T, c_lo, r0, nR, source, bi, improper, &num, T.tdel, T.tset, &nmv);
+                    int num, nmv;   // acceptMove: recompute the move list (every lane evaluates the winner, lane 0 records), apply in order
+                    dev_fast_score_w(R, S, T, c_lo, r0, M, source, bi, improper, sLr, sFl, sLap, &num, lane == 0, &nmv);
+                    WAVE_SYNC();
+                    if (lane == 0) {
                         for (int k = 0; k < nmv; ++k) {
                             int lr = T.tdel[k], t = T.tset[k];
                             int a = T.act_cand[lr], slot = T.act_slot[lr];
@@ -406,22 +539,25 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
                 WAVE_SYNC();
                 source = (source + 1) % M;
             }
+            RFA_T(8)
             // ---- moleculeMapqProbabilitySums ----
             for (int s = 0; s < M; ++s) {
-                for (int t = lane; t < M; t += 64) {
-                    int num;
-                    T.P[t] = t == s ? 0.0 : pow(10.0, dev_fast_score(R, S, T, c_lo, r0, nR, s, t, improper, &num, (int32_t*)0, (int32_t*)0, (int*)0));
+                for (int sb = 0; sb < M; sb += 64) {
+                    int t = sb + lane, num;
+                    double sc = dev_fast_score_w(R, S, T, c_lo, r0, M, s, (t < M && t != s) ? t : -1, improper, sLr, sFl, sLap, &num, 0, (int*)0);
+                    if (t < M) T.P[t] = t == s ? 0.0 : pow(10.0, sc);
                 }
                 WAVE_SYNC();
                 for (int k = lane; k < T.alen[s]; k += 64) {
                     int a = T.act_store[T.aoff[s] + k], lr = S.cand_read[c_lo + a] - r0;
                     double sum = S.sum_move[c_lo + a];
                     for (int t = 0; t < M; ++t)
-                        if (t != s && T.bestT[(size_t)t * nR + lr] >= 0) sum += T.P[t];
+                        if (t != s && T.bestT[(size_t)lr * M + t] >= 0) sum += T.P[t];
                     S.sum_move[c_lo + a] = sum;
                 }
                 WAVE_SYNC();
             }
+            RFA_T(9)
             // ---- updateAlignmentsMoleculeStatus: confidences, differences, active molecules ----
             for (int m = lane; m < M; m += 64) {
                 double conf = (double)T.alen[m] / (double)T.nbest[m];
@@ -445,6 +581,7 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             }
             WAVE_SYNC();
         }
+        RFA_T(10)
         // ---- calculateLogMoleculePenalty ----
         if (lane == 0) {
             double lmp = 0.0;
@@ -484,6 +621,7 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             S.mate[a] = m;
         }
         WAVE_SYNC();
+        RFA_T(11)
         // ---- estimateMapQualities per read (lariat.go:887-990), one lane per read ----
         for (int r = lane; r < nR; r += 64) {
             int gr = r0 + r, gm = r0 + (r ^ 1);
@@ -552,18 +690,43 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
 #undef TOP_PUSH
         }
         WAVE_SYNC();
+        RFA_T(12)
         // ---- markDuplicates: first-seen wins on (read1?, reversed, contig, pos, mate contig, mate pos) in read order ----
-        for (int r = lane; r < nR; r += 64) {
-            i64 a = S.active_idx[r0 + r], m = S.mate[a];
-            int dup = 0;
-            for (int q = 0; q < r && !dup; ++q) {
-                if ((q & 1) != (r & 1)) continue;
-                i64 b = S.active_idx[r0 + q], bm = S.mate[b];
-                if (R.reversed[a] == R.reversed[b] && R.rid[a] == R.rid[b] && R.pos[a] == R.pos[b] && R.rid[m] == R.rid[bm] && R.pos[m] == R.pos[bm]) dup = 1;
+        {   // open-addressing table over the keys; a slot ends up holding the smallest read index of its key
+            const int hmask = (1 << hbits) - 1;
+            for (int x = lane; x <= hmask; x += 64) T.htab[x] = -1;
+            for (int r = lane; r < nR; r += 64) {
+                i64 a = S.active_idx[r0 + r], m = S.mate[a];
+                T.dk0[r] = (u64)R.pos[a]; T.dk1[r] = (u64)R.pos[m];
+                T.dk2[r] = (u64)(uint32_t)R.rid[a] << 32 | (u64)(R.reversed[a] != 0) << 1 | (u64)(r & 1);
+                T.dk3[r] = (u64)(uint32_t)R.rid[m];
             }
-            S.duplicate[a] = (uint8_t)dup;
+            WAVE_SYNC();
+            for (int r = lane; r < nR; r += 64) {
+                u64 k0 = T.dk0[r], k1 = T.dk1[r], k2 = T.dk2[r], k3 = T.dk3[r];
+                int slot = (int)(dev_mix64(k0 ^ dev_mix64(k1 ^ dev_mix64(k2 ^ dev_mix64(k3)))) & (u64)hmask);
+                for (;;) {
+                    int cur = atomicCAS(&T.htab[slot], -1, r);
+                    if (cur == -1) break;
+                    if (T.dk0[cur] == k0 && T.dk1[cur] == k1 && T.dk2[cur] == k2 && T.dk3[cur] == k3) { atomicMin(&T.htab[slot], r); break; }
+                    slot = (slot + 1) & hmask;
+                }
+            }
+            WAVE_SYNC();
+            for (int r = lane; r < nR; r += 64) {
+                u64 k0 = T.dk0[r], k1 = T.dk1[r], k2 = T.dk2[r], k3 = T.dk3[r];
+                int slot = (int)(dev_mix64(k0 ^ dev_mix64(k1 ^ dev_mix64(k2 ^ dev_mix64(k3)))) & (u64)hmask);
+                int dup = 0;
+                for (;;) {
+                    int cur = atomicAdd(&T.htab[slot], 0);   // read at L2, where the atomics above landed
+                    if (T.dk0[cur] == k0 && T.dk1[cur] == k1 && T.dk2[cur] == k2 && T.dk3[cur] == k3) { dup = cur != r; break; }
+                    slot = (slot + 1) & hmask;
+                }
+                S.duplicate[S.active_idx[r0 + r]] = (uint8_t)dup;
+            }
         }
         WAVE_SYNC();
+        RFA_T(13)
         // ---- CheckSplitReads / GetSplitAlignment over the unfiltered candidates (split.go) ----
         for (int r = lane; r < nR; r += 64) {
             int gr = r0 + r;
@@ -603,6 +766,7 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             S.split_idx[gr] = c; S.split_mapq[gr] = (int)mapq; S.split_second_best[gr] = second_best;
             S.split_score[gr] = dev_score_aln(R, S, improper, c, S.mate[P], 0.0);
         }
+        RFA_T(14)
         WAVE_SYNC();
     }
 }

@@ -38,6 +38,13 @@ struct uint2 { uint32_t x, y; };
 #define WAVE_SYNC() __syncthreads()
 #endif
 #define LANE() ((int)(threadIdx.x & 63))
+// EMU_SYNC(): orders one lane's LDS store after the other lanes' earlier LDS loads.  A hardware wave issues its LDS
+// operations in program order for all lanes at once, so nothing is needed there; the emulator's fibers need a rendezvous.
+#ifdef LH_EMU
+#define EMU_SYNC() WAVE_SYNC()
+#else
+#define EMU_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 
 typedef uint64_t u64;
 typedef int64_t i64;
@@ -139,6 +146,12 @@ __device__ __forceinline__ int wave_scan_max_i32(int v, int lane) {
     for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d); if (lane >= d) v = v > o ? v : o; }
     return v;
 }
+// inclusive prefix sum over lanes
+__device__ __forceinline__ int wave_scan_add_i32(int v) {
+    int lane = LANE();
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d); if (lane >= d) v += o; }
+    return v;
+}
 __device__ __forceinline__ int wave_shr1_i32(int v, int fill) { int o = __shfl_up(v, 1); return LANE() == 0 ? fill : o; }   // lane i <- lane i-1
 __device__ __forceinline__ int wave_readlane(int v, int l) { return __shfl(v, l); }                                          // l must be wave-uniform
 #else
@@ -160,6 +173,15 @@ __device__ __forceinline__ int wave_readlane(int v, int l) { return __builtin_am
 __device__ __forceinline__ int wave_shr1_i32(int v, int fill) { return LH_DPP(fill, v, 0x138, 0xF); }
 __device__ __forceinline__ int wave_max_i32(int v) { return wave_readlane(wave_scan_max_i32(v, 0), 63); }
 __device__ __forceinline__ int wave_min_i32(int v) { return -wave_max_i32(-v); }
+__device__ __forceinline__ int wave_scan_add_i32(int v) {   // inclusive prefix sum over lanes
+    v += LH_DPP(0, v, 0x111, 0xF);
+    v += LH_DPP(0, v, 0x112, 0xF);
+    v += LH_DPP(0, v, 0x114, 0xF);
+    v += LH_DPP(0, v, 0x118, 0xF);
+    v += LH_DPP(0, v, 0x142, 0xA);
+    v += LH_DPP(0, v, 0x143, 0xC);
+    return v;
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
     v += LH_DPP(0, v, 0x111, 0xF);
     v += LH_DPP(0, v, 0x112, 0xF);

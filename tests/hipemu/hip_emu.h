@@ -135,6 +135,14 @@ template <class T> static inline T atomicMax(T* p, T v) {
     while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return o;
 }
+template <class T> static inline T atomicMin(T* p, T v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (o > v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+template <class T> static inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <class T> static inline T atomicCAS(T* p, T cmp, T v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return cmp; }
+static inline unsigned long long wall_clock64() { return 0; }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // ---- mini runtime --------------------------------------------------------------------------------
