@@ -193,6 +193,13 @@ int lh_index_from_arrays(int device, uint64_t primary, const uint64_t L2[5], con
 /* GetReferenceContigsInfo (gobwa.go:26) */
 int lh_index_contigs(const lh_index* idx, int32_t* n, const char* const** names, const int64_t** lens, const int64_t** offsets);
 int64_t lh_index_l_pac(const lh_index* idx);
+/* The .sa file holds every 32nd suffix-array row (bwa index default); bwt_sa (reached from mem_chain via gobwa.go:244,253)
+ * walks the BWT to the next sampled row.  On load the samples are re-derived ON THE DEVICE at the densest power-of-two
+ * interval whose table fits a quarter of the free HBM (<= 64 GiB; override with the environment variable LH_SA_INTV), so a
+ * lookup costs (interval-1)/2 occurrence-block reads instead of 15.5.  The values are exact at any interval; results do not
+ * change.  lh_index_resample_sa switches the resident table to another interval (denser: walk; sparser: sub-sample). */
+int lh_index_resample_sa(lh_index* idx, int32_t sa_intv);
+int32_t lh_index_sa_interval(const lh_index* idx);
 void lh_index_free(lh_index* idx);
 
 /* FM-index construction: text = fwd || revcomp of the 2-bit contigs, BWA-byte-compatible output.

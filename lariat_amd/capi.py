@@ -224,6 +224,10 @@ def _declare(L):
     L.lh_index_contigs.argtypes = [C.c_void_p, c_i32p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(c_i64p), C.POINTER(c_i64p)]
     L.lh_index_l_pac.argtypes = [C.c_void_p]
     L.lh_index_l_pac.restype = C.c_int64
+    L.lh_index_resample_sa.argtypes = [C.c_void_p, C.c_int32]
+    L.lh_index_resample_sa.restype = C.c_int
+    L.lh_index_sa_interval.argtypes = [C.c_void_p]
+    L.lh_index_sa_interval.restype = C.c_int32
     L.lh_index_free.argtypes = [C.c_void_p]
     L.lh_index_build.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(c_u8p), c_i64p, C.c_int32]
     L.lh_context_create.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
@@ -329,6 +333,14 @@ class Index:
     def l_pac(self):
         return self.lib.L.lh_index_l_pac(self.h)
 
+    @property
+    def sa_interval(self):
+        """sampling interval of the suffix array resident in HBM (the .sa file's is 32; see lh_index_resample_sa)"""
+        return int(self.lib.L.lh_index_sa_interval(self.h))
+
+    def resample_sa(self, intv):
+        self.lib.check(self.lib.L.lh_index_resample_sa(self.h, int(intv)))
+
     def contigs(self):
         n = C.c_int32()
         names = C.POINTER(C.c_char_p)()
@@ -414,6 +426,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = [
     "lh_last_error", "lh_device_count", "lh_opts_init", "lh_index_load", "lh_index_from_arrays", "lh_index_contigs", "lh_index_l_pac",
+    "lh_index_resample_sa", "lh_index_sa_interval",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read",
 ]

@@ -166,6 +166,7 @@ static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)8 << 30; *t = (size_t)8 << 30; return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new EmuEvent(); return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }

@@ -52,8 +52,19 @@ def test_candidates_synthetic(lib, oracle, seed, junk):
     res = ctx.align_barcodes(b, lib.opts(run_inference=0))
     ores = oidx.align_barcodes(b, oracle.opts(run_inference=0), threads=8)
     helpers.assert_same_result(res, ores, inference=False)
-    for k in ("n_ext", "n_lf", "n_sa", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"):
+    for k in ("n_ext", "n_sa", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"):
         assert res.counters[k] == ores.counters[k], k
+    # the suffix array is re-sampled densely on load (every row for a genome this small): no BWT walk is left in bwt_sa
+    assert idx.sa_interval == 1 and res.counters["n_lf"] == 0
+    # back at the .sa file's interval (sub-sampling path) the walk lengths are the oracle's, and nothing else changes
+    idx.resample_sa(oidx.arrays()["sa_intv"])
+    res2 = ctx.align_barcodes(b, lib.opts(run_inference=0))
+    helpers.assert_same_result(res2, ores, inference=False)
+    assert res2.counters["n_lf"] == ores.counters["n_lf"]
+    idx.resample_sa(4)   # densifying path from a sparser table
+    res3 = ctx.align_barcodes(b, lib.opts(run_inference=0))
+    helpers.assert_same_result(res3, ores, inference=False)
+    assert 0 < res3.counters["n_lf"] < ores.counters["n_lf"]
 
 
 def test_repeat_rich_genome(lib, oracle):
