@@ -1,0 +1,274 @@
+// k_smem4.h — K1 v4: SMEM seeding with PERSISTENT lanes (one read per lane, every lane always busy).
+//
+// Measured on MI355X (profiles/r01_*): with one lane per read but BWA's loop nest kept as written (k_smem3.h), the lanes of
+// a wave drift into different loops and the hardware serialises them: 13 of 64 lanes are active on average, so the wave
+// has ~13 x 2 occurrence-block reads in flight instead of 128 and issues 5x more instructions than needed.
+//
+// Here mem_collect_intv (bwt_smem1a passes 1+2 and bwt_seed_strategy1; reached from go/src/gobwa/gobwa.go:244,253) is a
+// per-lane STATE MACHINE around one shared program point: in every turn of the main loop each lane that has a
+// bwt_extend pending performs it (all lanes together: 2 x 64-B block reads per lane in flight), then each lane does the
+// bookkeeping of the loop it is in (forward extension / backward sweep / pass 3) and prepares its next request.  A lane
+// that finishes its read takes the next one from the wave's chunk (chunks of 64 reads come from one device counter), so
+// no lane waits for the slowest read of a batch.  The arithmetic and the order of list operations per read are exactly
+// those of bwt_smem1a / bwt_seed_strategy1: only the interleaving across reads differs.
+//
+//  - query: 4-bit packed in LDS (8 bases per word, word w of lane L at qn[w*64+L]), staged by the whole wave
+//  - prev/curr interval lists: 16-B packed entries in an HBM slab interleaved by thread; the entry the next row starts
+//    with stays in registers and the following one is prefetched while the current extension is in flight
+#pragma once
+#include "k_smem3.h"
+
+struct __attribute__((aligned(16))) PEnt { u64 lo, hi; };   // x0:40 | x2[0..23]  /  x1:40 | x2[24..32] | info:15
+#define LH_M40 0xffffffffffull
+__device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
+    PEnt e;
+    e.lo = x0 | (x2 << 40);
+    e.hi = x1 | ((x2 >> 24) << 40) | ((u64)(uint32_t)info << 49);
+    return e;
+}
+#define PE_X0(e) ((e).lo & LH_M40)
+#define PE_X1(e) ((e).hi & LH_M40)
+#define PE_X2(e) (((e).lo >> 40) | ((((e).hi >> 40) & 0x1ffull) << 24))
+#define PE_INFO(e) ((int)((e).hi >> 49))
+
+#define S4_FETCH 0
+#define S4_DONE 1
+#define S4_REQ_FWD 2
+#define S4_REQ_BWD 3
+#define S4_REQ_P3 4
+#define S4_BWD_NEXT 8    // states >= 8 are transitions handled without an extension
+#define S4_BWD_INIT 9
+#define S4_BWD_ROW 10
+#define S4_SMEM_DONE 11
+#define S4_P1_SCAN 12
+#define S4_P2_NEXT 13
+#define S4_P3_SCAN 14
+#define S4_FWD_PREP 15
+#define S4_P3_PREP 16
+#define S4_READ_DONE 17
+
+__global__ void __launch_bounds__(64) k_smem4(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+                                               DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
+                                               int32_t* __restrict__ next_read, DCounters* __restrict__ ctr) {
+    __shared__ uint32_t qn[32 * 64];
+    const int lane = LANE();
+    const size_t T = (size_t)gridDim.x * 64, t = (size_t)blockIdx.x * 64 + lane;
+    PEnt* const LA = slab + t;                                    // entry e of list A at LA[e * T]
+    PEnt* const LB = slab + (size_t)(LH_MAXLEN + 2) * T + t;
+    const int split_len = (int)(o.min_seed_len * o.split_factor + .499);
+    int chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of reads
+    int st = S4_FETCH;
+    int r = -1, len = 0, rst = 0, on = 0, ovf = 0;
+    DIntv* out = intv_out;
+    u64 c0 = 0, c1 = 0, c2 = 0, last_size = 0, p2mask = 0;   // c*: ik (forward, pass 3) or the prev entry p (backward)
+    int cinfo = 0, ec = 0, i = 0, x = 0, j = 0, ncurr = 0, nprev = 0, rev = 0, min_intv = 1, have_mem = 0, last_mem_start = 0, ret = 0, phase = 0, curA = 1;
+    PEnt ce, pn;
+    ce.lo = ce.hi = pn.lo = pn.hi = 0;
+    unsigned n_ext_total = 0;
+#define QB(i_) ((int)((qn[((i_) >> 3) * 64 + lane] >> (((i_) & 7) * 4)) & 0xF))
+#define CURR (curA ? LA : LB)
+#define PREV (curA ? LB : LA)
+#define START_SMEM1()                                                                                       \
+    {                                                                                                        \
+        int b_ = QB(x);                                                                                      \
+        c0 = ix.L2[b_] + 1; c2 = ix.L2[b_ + 1] - ix.L2[b_]; c1 = ix.L2[3 - b_] + 1; cinfo = x + 1;          \
+        ncurr = 0; i = x + 1; curA = 1; st = S4_FWD_PREP;                                                    \
+    }
+    for (;;) {
+        // ---- A. lanes without a read take the next ones of the wave's chunk; the wave stages their bases in LDS ----
+        u64 need = __ballot(st == S4_FETCH);
+        if (need) {
+            int cnt = __popcll(need), newbase = 0;
+            if (chunk_next + cnt > chunk_end) {
+                int nb = 0;
+                if (lane == 0) nb = atomicAdd(next_read, 64);
+                newbase = wave_readlane(nb, 0);
+            }
+            i64 off = 0;
+            int ln = 0, rr = -1;
+            if (st == S4_FETCH) {
+                int idx = chunk_next + lanes_below(need, lane);
+                rr = idx < chunk_end ? idx : newbase + (idx - chunk_end);
+                if (rr >= n_reads) st = S4_DONE;
+                else { off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
+            }
+            if (chunk_next + cnt > chunk_end) { chunk_next = newbase + (chunk_next + cnt - chunk_end); chunk_end = newbase + 64; }
+            else chunk_next += cnt;
+            u64 got = __ballot(st == S4_FETCH);
+            while (got) {
+                int L = __ffsll((unsigned long long)got) - 1;
+                got &= got - 1;
+                i64 offL = shfl_i64(off, L);
+                int lnL = wave_readlane(ln, L);
+                if (lnL > LH_MAXLEN) lnL = 0;
+                uint32_t w = 0;
+                if (4 * lane < lnL) __builtin_memcpy(&w, seq + offL + 4 * lane, 4);   // the batch buffer is padded: a read's tail word is readable
+                uint32_t nb16 = 0;
+                for (int b = 0; b < 4; ++b) {
+                    uint32_t v = (w >> (8 * b)) & 0xff;
+                    v = (4 * lane + b < lnL && v < 4) ? v : 4;
+                    nb16 |= v << (4 * b);
+                }
+                uint32_t other = __shfl_xor(nb16, 1);
+                if (!(lane & 1)) qn[(lane >> 1) * 64 + L] = nb16 | other << 16;
+            }
+            if (st == S4_FETCH) {
+                r = rr; len = ln; rst = 0; on = 0; ovf = 0; p2mask = 0;
+                if (len > LH_MAXLEN) { rst |= LH_ST_TOO_LONG; len = 0; }
+                out = intv_out + (size_t)r * LH_MAX_INTV;
+                if (len >= o.min_seed_len) { x = 0; phase = 1; st = S4_P1_SCAN; }
+                else st = S4_READ_DONE;
+            }
+        }
+        // ---- B. transitions (no extension involved); blocks are ordered so that the usual chains finish in one pass ----
+        while (__any(st >= 8)) {
+            if (st == S4_BWD_NEXT) {
+                if (j < nprev) {
+                    c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn); cinfo = PE_INFO(pn);
+                    st = S4_REQ_BWD;
+                    if (j + 1 < nprev) pn = PREV[(size_t)(rev ? nprev - 2 - j : j + 1) * T];
+                } else if (ncurr == 0) st = S4_SMEM_DONE;
+                else { curA ^= 1; nprev = ncurr; rev = 0; --i; st = i < -1 ? S4_SMEM_DONE : S4_BWD_ROW; }
+            }
+            if (st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
+                ret = cinfo; curA ^= 1; nprev = ncurr; rev = 1; have_mem = 0; last_mem_start = 0; i = x - 1;
+                st = S4_BWD_ROW;
+            }
+            if (st == S4_BWD_ROW) {
+                int c = i < 0 ? 4 : QB(i);
+                ncurr = 0; last_size = 0; j = 0;
+                c0 = PE_X0(ce); c1 = PE_X1(ce); c2 = PE_X2(ce); cinfo = PE_INFO(ce);   // first entry of the row: kept in registers
+                if (c > 3) {   // nothing extends: only the first (longest) entry can be a new MEM
+                    if (!have_mem || i + 1 < last_mem_start) {
+                        if (cinfo - (i + 1) >= o.min_seed_len) {
+                            if (on >= LH_MAX_INTV) ovf = 1;
+                            else {
+                                DIntv m; m.x0 = c0; m.x1 = c1; m.x2 = c2; m.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32;
+                                if (phase == 1 && cinfo - (i + 1) >= split_len && c2 <= (u64)o.split_width) p2mask |= 1ull << on;
+                                out[on++] = m;
+                            }
+                        }
+                        have_mem = 1; last_mem_start = i + 1;
+                    }
+                    st = S4_SMEM_DONE;
+                } else {
+                    ec = c; st = S4_REQ_BWD;
+                    if (nprev > 1) pn = PREV[(size_t)(rev ? nprev - 2 : 1) * T];
+                }
+            }
+            if (st == S4_SMEM_DONE) {
+                if (phase == 1) { x = ret; st = S4_P1_SCAN; }
+                else st = S4_P2_NEXT;
+            }
+            if (st == S4_P1_SCAN) {   // first pass: all SMEMs
+                while (x < len && QB(x) > 3) ++x;
+                if (x >= len) { phase = 2; st = S4_P2_NEXT; }
+                else { min_intv = 1; START_SMEM1() }
+            }
+            if (st == S4_P2_NEXT) {   // second pass: re-seed inside long, rare SMEMs of the first pass
+                st = S4_P3_SCAN; x = 0;
+                if (o.max_mem_intv <= 0) st = S4_READ_DONE;
+                while (p2mask) {
+                    int k = __ffsll((unsigned long long)p2mask) - 1;
+                    p2mask &= p2mask - 1;
+                    DIntv p = out[k];
+                    int xm = ((int)(p.info >> 32) + (int)(uint32_t)p.info) >> 1;
+                    if (QB(xm) > 3) continue;   // bwt_smem1a returns at once on an ambiguous base
+                    x = xm; min_intv = (int)p.x2 + 1;
+                    START_SMEM1()
+                    break;
+                }
+            }
+            if (st == S4_P3_SCAN) {   // third pass: LAST-like forward-only seeds (bwt_seed_strategy1)
+                while (x < len && QB(x) > 3) ++x;
+                if (x >= len) st = S4_READ_DONE;
+                else {
+                    int b = QB(x);
+                    c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1;
+                    i = x + 1; st = S4_P3_PREP;
+                }
+            }
+            if (st == S4_FWD_PREP) {
+                int b = i < len ? QB(i) : 4;
+                if (b > 3) {   // end of read or ambiguous base: the current interval closes the forward list
+                    ce = pe_pack(c0, c1, c2, cinfo);
+                    CURR[(size_t)ncurr * T] = ce; ncurr++;
+                    st = S4_BWD_INIT;
+                } else { ec = 3 - b; st = S4_REQ_FWD; }
+            }
+            if (st == S4_P3_PREP) {
+                if (i >= len) st = S4_READ_DONE;
+                else {
+                    int b = QB(i);
+                    if (b > 3) { x = i + 1; st = S4_P3_SCAN; }
+                    else { ec = 3 - b; st = S4_REQ_P3; }
+                }
+            }
+            if (st == S4_READ_DONE) {
+                if (ovf) rst |= LH_ST_INTV_OVERFLOW;
+                n_intv[r] = on; status[r] = rst;
+                st = S4_FETCH;
+            }
+        }
+        // ---- C. anything left to extend? ----
+        if (!__any(st >= S4_REQ_FWD)) {
+            if (!__any(st != S4_DONE)) break;
+            continue;
+        }
+        // ---- D. the shared program point: one bwt_extend per requesting lane ----
+        DIntv ok;
+        ok.x0 = ok.x1 = ok.x2 = ok.info = 0;
+        if (st >= S4_REQ_FWD) {
+            DIntv a;
+            a.x0 = c0; a.x1 = c1; a.x2 = c2; a.info = 0;
+            ok = dev_extend_c(ix, a, ec, st == S4_REQ_BWD);
+            n_ext_total++;
+        }
+        // ---- E. bookkeeping of the loop the lane is in ----
+        if (st == S4_REQ_FWD) {
+            st = S4_FWD_PREP;
+            if (ok.x2 != c2) {
+                ce = pe_pack(c0, c1, c2, cinfo);
+                CURR[(size_t)ncurr * T] = ce; ncurr++;
+                if (ok.x2 < (u64)min_intv) st = S4_BWD_INIT;   // the interval is too small to be extended further
+            }
+            if (st == S4_FWD_PREP) { c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i; }
+        } else if (st == S4_REQ_BWD) {
+            if (ok.x2 < (u64)min_intv) {
+                if (ncurr == 0 && (!have_mem || i + 1 < last_mem_start)) {   // no longer match survived, not contained in the previous MEM
+                    if (cinfo - (i + 1) >= o.min_seed_len) {
+                        if (on >= LH_MAX_INTV) ovf = 1;
+                        else {
+                            DIntv m; m.x0 = c0; m.x1 = c1; m.x2 = c2; m.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32;
+                            if (phase == 1 && cinfo - (i + 1) >= split_len && c2 <= (u64)o.split_width) p2mask |= 1ull << on;
+                            out[on++] = m;
+                        }
+                    }
+                    have_mem = 1; last_mem_start = i + 1;
+                }
+            } else if (ncurr == 0 || ok.x2 != last_size) {
+                PEnt e = pe_pack(ok.x0, ok.x1, ok.x2, cinfo);
+                if (ncurr == 0) ce = e;
+                CURR[(size_t)ncurr * T] = e; ncurr++;
+                last_size = ok.x2;
+            }
+            ++j; st = S4_BWD_NEXT;
+        } else if (st == S4_REQ_P3) {
+            if (ok.x2 < (u64)o.max_mem_intv && i - x >= o.min_seed_len) {
+                if (ok.x2 > 0) {
+                    if (on >= LH_MAX_INTV) ovf = 1;
+                    else { DIntv m = ok; m.info = (u64)x << 32 | (u64)(i + 1); out[on++] = m; }
+                }
+                x = i + 1; st = S4_P3_SCAN;
+            } else { c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; ++i; st = S4_P3_PREP; }
+        }
+    }
+#undef QB
+#undef CURR
+#undef PREV
+#undef START_SMEM1
+    if (ctr) {
+        unsigned tot = (unsigned)wave_sum_i32((int)n_ext_total);
+        if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->n_ext, (u64)tot);
+    }
+}
