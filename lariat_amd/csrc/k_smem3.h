@@ -1,6 +1,6 @@
 // k_smem3.h — K1 v3: SMEM seeding with one LANE per read (64 independent FM-index walks per wavefront).
 //
-// Measured on MI355X (profiles/r01_*): giving a read a whole wave (k_smem.h) makes the kernel VALU-issue bound — the
+// Measured on MI355X (profiles/r01_*): giving a read a whole wave (the first K1, since removed) makes the kernel VALU-issue bound — the
 // forward extension is one dependent chain, so 64 lanes spend ~120 instructions per bwt_extend.  Here every lane runs
 // BWA's mem_collect_intv (bwt_smem1a passes 1+2, bwt_seed_strategy1 pass 3; reached from go/src/gobwa/gobwa.go:244,253)
 // for its own read: one wave instruction advances up to 64 walks, each lane decodes its own 64-B occurrence blocks
@@ -10,7 +10,7 @@
 //
 // Output: unsorted intervals + count per read; k_smem_fin sorts by `info` and derives seed counts / l_rep.
 #pragma once
-#include "k_smem.h"
+#include "lh_dev.h"
 
 struct TList {   // one thread's interval list inside the interleaved slab: field f of entry e at base[(e*4+f)*stride]
     u64* base;

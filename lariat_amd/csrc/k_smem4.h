@@ -47,7 +47,10 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_P3_PREP 16
 #define S4_READ_DONE 17
 
-__global__ void __launch_bounds__(64) k_smem4(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+#ifndef LH_SMEM4_WAVES
+#define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
+#endif
+__global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
                                                int32_t* __restrict__ next_read, DCounters* __restrict__ ctr) {
     __shared__ uint32_t qn[32 * 64];

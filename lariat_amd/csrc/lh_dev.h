@@ -83,7 +83,12 @@ __device__ int lh_dbg[32];
 #define LH_ST_POOL_OVERFLOW 16
 
 struct DIndex {
-    const uint32_t* bwt;     // occ-interleaved BWT exactly as in <prefix>.bwt: per 128 symbols [4 x u64 occ | 8 x u32 symbols]
+    // FM-index occurrence table, re-laid out on load from <prefix>.bwt (which interleaves 4 x u64 counts with 128 2-bit
+    // symbols per 64 B): per 64 symbols one 32-B record [4 x u32 counts before the block | u64 high bit-plane | u64 low
+    // bit-plane] (symbol s of the block = bit s of the planes).  One 32-B read and three 64-bit popcounts per bwt_occ4.
+    const uint4* occ;
+    const u64* sb;           // absolute counts at every 2^sb_shift-th symbol (the u32 counts are relative to them); null if there is one super-block
+    int32_t sb_shift;        // 31 (LH_SB_SHIFT overrides it for tests)
     const u64* sa;           // sampled SA, sa[0] = -1
     const uint8_t* pac;      // 2-bit forward reference, MSB first
     const i64* contig_off;   // [n_contigs]
@@ -218,29 +223,19 @@ __device__ __forceinline__ u64 dpp_ror8_u64(u64 v) { return (u64)dpp_ror8((uint3
 
 // ------------------------------------------------------------------ FM-index primitives (restated from BWA bwt.c)
 // packed per-base counts of the 16 symbols of w under the 2-bit-position mask `valid` (0x55555555 = all 16)
-__device__ __forceinline__ uint32_t occ_word(uint32_t w, uint32_t valid) {
-    uint32_t lo = w & valid, hi = (w >> 1) & valid;
-    uint32_t t = __popc(hi & lo), g = __popc(hi & ~lo), c = __popc(~hi & lo & valid);
-    uint32_t a = __popc(valid) - t - g - c;
-    return a | c << 8 | g << 16 | t << 24;
-}
-
-// bwt_occ4: occurrences of A,C,G,T in BWT[0..k] ($ removed at primary); k == -1 -> 0.  One lane reads one 64-B block.
+// bwt_occ4: occurrences of each base in BWT[0..k]
 __device__ __forceinline__ void dev_occ4(const DIndex& ix, u64 k, u64 cnt[4]) {
     if (k == (u64)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
     k -= (k >= ix.primary);
-    const uint4* p = (const uint4*)(ix.bwt + ((k >> 7) << 4));
-    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-    cnt[0] = (u64)a.y << 32 | a.x; cnt[1] = (u64)a.w << 32 | a.z;
-    cnt[2] = (u64)b.y << 32 | b.x; cnt[3] = (u64)b.w << 32 | b.z;
-    int nfull = (int)((k & 127) >> 4);
-    uint32_t pm = 0x55555555u & ~((1u << ((~(uint32_t)k & 15) << 1)) - 1);   // symbols 0..(k&15) of the partial word (MSB first)
-    uint32_t x = 0;
-#define LH_OCCW(t, wv) x += (t) < nfull ? occ_word(wv, 0x55555555u) : ((t) == nfull ? occ_word(wv, pm) : 0u)
-    LH_OCCW(0, c.x); LH_OCCW(1, c.y); LH_OCCW(2, c.z); LH_OCCW(3, c.w);
-    LH_OCCW(4, d.x); LH_OCCW(5, d.y); LH_OCCW(6, d.z); LH_OCCW(7, d.w);
-#undef LH_OCCW
-    cnt[0] += x & 0xff; cnt[1] += x >> 8 & 0xff; cnt[2] += x >> 16 & 0xff; cnt[3] += x >> 24;
+    const uint4* p = ix.occ + ((k >> 6) << 1);
+    uint4 h = p[0], d = p[1];
+    int m = (int)(k & 63) + 1;                     // symbols of the block that count
+    u64 mask = ~0ull >> (64 - m);
+    u64 hi = ((u64)d.y << 32 | d.x) & mask, lo = ((u64)d.w << 32 | d.z) & mask;
+    u64 i3 = hi & lo, i2 = hi ^ i3, i1 = lo ^ i3;
+    int n3 = __popcll(i3), n2 = __popcll(i2), n1 = __popcll(i1);
+    cnt[0] = (u64)h.x + (u64)(m - n1 - n2 - n3); cnt[1] = (u64)h.y + (u64)n1; cnt[2] = (u64)h.z + (u64)n2; cnt[3] = (u64)h.w + (u64)n3;
+    if (ix.sb) { const u64* sb = ix.sb + ((k >> ix.sb_shift) << 2); cnt[0] += sb[0]; cnt[1] += sb[1]; cnt[2] += sb[2]; cnt[3] += sb[3]; }
 }
 
 // bwt_extend restricted to the one base `c` the caller follows: returns ok[c]
@@ -276,8 +271,9 @@ __device__ __forceinline__ u64 dev_sa(const DIndex& ix, u64 k, int* n_lf) {
         ++sa; ++steps;
         if (k == ix.primary) { k = 0; continue; }
         u64 x = k - (k > ix.primary);
-        const uint32_t* blk = ix.bwt + ((x >> 7) << 4);
-        uint32_t c = blk[8 + ((x & 0x7f) >> 4)] >> ((~(uint32_t)x & 0xf) << 1) & 3;   // bwt_B0
+        uint4 pl = ix.occ[((x >> 6) << 1) + 1];
+        int sh = (int)(x & 63);
+        uint32_t c = (uint32_t)((((u64)pl.y << 32 | pl.x) >> sh & 1) << 1 | (((u64)pl.w << 32 | pl.z) >> sh & 1));   // bwt_B0
         u64 cnt[4];
         dev_occ4(ix, k, cnt);
         k = ix.L2[c] + (c == 0 ? cnt[0] : c == 1 ? cnt[1] : c == 2 ? cnt[2] : cnt[3]);

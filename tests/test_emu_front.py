@@ -37,6 +37,20 @@ def test_emu_front_synthetic(emu, oracle):
     helpers.assert_same_result(res, oidx.align_barcodes(b, oracle.opts(run_inference=0)), inference=False)
 
 
+def test_emu_occ_superblocks_and_sparse_sa(emu, oracle, monkeypatch):
+    """the occurrence table's u32 counts are relative to super-block bases (needed past 2^31 symbols, e.g. hg38): force
+    tiny super-blocks; and keep the .sa file's sampling so that bwt_sa really walks the re-laid-out BWT"""
+    monkeypatch.setenv("LH_SB_SHIFT", "14")
+    monkeypatch.setenv("LH_SA_INTV", "32")
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    assert idx.sa_interval == 32
+    rs = helpers.small_reads(names, contigs, n_barcodes=2, pairs=30, junk=0.05, seed=11)
+    b = helpers.batch_of(rs)
+    helpers.assert_same_dump(idx.context(rs.n_pairs).stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT)
+
+
 def test_emu_full_inference(emu, oracle):
     """whole hot path (candidates + tagBest + molecules + RFA + MAPQ + duplicates + split reads) under emulation"""
     names, contigs = helpers.small_genome()
