@@ -25,7 +25,7 @@ __device__ __forceinline__ i64 wave_max_i64(i64 v) {
 
 // One DP row over slab T (columns 64*T .. 64*T+63).  Uses/updates H##T, E##T, and the running row state.
 #define LH_EXT_SLAB(T)                                                                                          \
-    if (64 * (T) <= end && 64 * (T) + 63 >= beg) {                                                              \
+    if ((T) < NS && 64 * (T) <= end && 64 * (T) + 63 >= beg) {                                                            \
         int j = 64 * (T) + lane;                                                                                \
         int in = j >= beg && j < end;                                                                           \
         int M = 0, e = E##T, tins = 0, enew = E##T;                                                             \
@@ -66,6 +66,8 @@ __device__ __forceinline__ i64 wave_max_i64(i64 v) {
 #define LH_EXT_NZ(T) (H##T != 0 || E##T != 0)
 
 // ksw_extend2.  Query column j holds qarr[qoff + qstep*j]; target row i is the reference base at tcoord0 + tstep*i.
+// NS = number of 64-column slabs instantiated (qlen <= 64*NS): the common short extension pays for one slab only.
+template <int NS>
 __device__ __forceinline__ ExtRes wave_ksw_extend2(const DIndex& ix, const DOpts& o, const uint8_t* qarr, int qoff, int qstep, int qlen, i64 tcoord0, int tstep,
                                                    int tlen, int w, int end_bonus, int zdrop, int h0, int lane, u64* cells) {
     const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
@@ -141,9 +143,9 @@ __device__ __forceinline__ ExtRes wave_ksw_extend2(const DIndex& ix, const DOpts
         int nbeg = end;
         {
             u64 b0 = __ballot(LH_EXT_NZ(0) && lane >= beg && lane < end);
-            u64 b1 = __ballot(LH_EXT_NZ(1) && 64 + lane >= beg && 64 + lane < end);
-            u64 b2 = __ballot(LH_EXT_NZ(2) && 128 + lane >= beg && 128 + lane < end);
-            u64 b3 = __ballot(LH_EXT_NZ(3) && 192 + lane >= beg && 192 + lane < end);
+            u64 b1 = NS > 1 ? __ballot(LH_EXT_NZ(1) && 64 + lane >= beg && 64 + lane < end) : 0;
+            u64 b2 = NS > 2 ? __ballot(LH_EXT_NZ(2) && 128 + lane >= beg && 128 + lane < end) : 0;
+            u64 b3 = NS > 3 ? __ballot(LH_EXT_NZ(3) && 192 + lane >= beg && 192 + lane < end) : 0;
             if (b0) nbeg = __ffsll((unsigned long long)b0) - 1;
             else if (b1) nbeg = 64 + __ffsll((unsigned long long)b1) - 1;
             else if (b2) nbeg = 128 + __ffsll((unsigned long long)b2) - 1;
@@ -152,9 +154,9 @@ __device__ __forceinline__ ExtRes wave_ksw_extend2(const DIndex& ix, const DOpts
         int nend_j = nbeg - 1;
         {
             u64 b0 = __ballot(LH_EXT_NZ(0) && lane >= nbeg && lane <= end);
-            u64 b1 = __ballot(LH_EXT_NZ(1) && 64 + lane >= nbeg && 64 + lane <= end);
-            u64 b2 = __ballot(LH_EXT_NZ(2) && 128 + lane >= nbeg && 128 + lane <= end);
-            u64 b3 = __ballot(LH_EXT_NZ(3) && 192 + lane >= nbeg && 192 + lane <= end);
+            u64 b1 = NS > 1 ? __ballot(LH_EXT_NZ(1) && 64 + lane >= nbeg && 64 + lane <= end) : 0;
+            u64 b2 = NS > 2 ? __ballot(LH_EXT_NZ(2) && 128 + lane >= nbeg && 128 + lane <= end) : 0;
+            u64 b3 = NS > 3 ? __ballot(LH_EXT_NZ(3) && 192 + lane >= nbeg && 192 + lane <= end) : 0;
             if (b3) nend_j = 192 + 63 - __clzll((unsigned long long)b3);
             else if (b2) nend_j = 128 + 63 - __clzll((unsigned long long)b2);
             else if (b1) nend_j = 64 + 63 - __clzll((unsigned long long)b1);
@@ -169,15 +171,20 @@ __device__ __forceinline__ ExtRes wave_ksw_extend2(const DIndex& ix, const DOpts
     return r;
 }
 
-// K4.  grid = n_reads waves.
-__global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+// K4, one wavefront per read.  Without a list: grid = n_reads waves.  With a list (k_extend2.h hands over the reads that
+// do not suit its lane-per-read kernel): the waves stride over list[range[0] .. range[1]).
+__global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, const int32_t* __restrict__ list, const int32_t* __restrict__ range,
+                                                const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                 const i64* __restrict__ seed_off, const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds,
                                                 const int32_t* __restrict__ n_chains, int32_t* __restrict__ sorder, int32_t* __restrict__ sdone,
                                                 const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs,
-                                                DCounters* __restrict__ ctr) {
+                                                DCounters* __restrict__ ctr, int count_chains) {
     __shared__ uint8_t q[LH_MAXLEN + 6];
-    int r = blockIdx.x, lane = LANE();
-    if (r >= n_reads) return;
+    const int lane = LANE();
+    int it_first = list ? range[0] + (int)blockIdx.x : (int)blockIdx.x, it_last = list ? range[1] : n_reads, it_step = list ? (int)gridDim.x : n_reads;
+    for (int it = it_first; it < it_last; it += it_step) {
+    int r = list ? list[it] : it;
+    WAVE_SYNC();   // the previous read's query is no longer in use
     i64 off = seq_off[r];
     int l_query = (int)(seq_off[r + 1] - off);
     if (l_query > LH_MAXLEN) l_query = 0;
@@ -274,47 +281,48 @@ __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, 
             a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = 0; a.seedcov = 0; a.secondary = 0; a.n_comp = 0; a.is_alt = 0;
             int aw0 = o.w, aw1 = o.w;
             a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid;
-            if (s.qbeg) {   // left extension: reversed query prefix vs reversed reference prefix
-                int tlen = (int)(s.rbeg - rmax0);
+            for (int side = 0; side < 2; ++side) {   // one extension site: 0 = left (reversed query prefix vs reversed reference prefix), 1 = right
+                int qoff, qstep, qlen, tstep, tlen, bonus, h0, sc0 = a.score, qe = s.qbeg + s.len;
+                i64 tc0, re = s.rbeg + s.len;
+                if (side == 0) {
+                    if (!s.qbeg) { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; continue; }
+                    qoff = s.qbeg - 1; qstep = -1; qlen = s.qbeg; tc0 = s.rbeg - 1; tstep = -1; tlen = (int)(s.rbeg - rmax0); bonus = o.pen_clip5; h0 = s.len * o.a;
+                } else {
+                    if (qe == l_query) { a.qe = l_query; a.re = s.rbeg + s.len; continue; }
+                    qoff = qe; qstep = 1; qlen = l_query - qe; tc0 = re; tstep = 1; tlen = (int)(rmax1 - re); bonus = o.pen_clip3; h0 = sc0;
+                }
                 ExtRes e;
                 e.score = -1; e.qle = e.tle = e.gtle = 0; e.gscore = -1; e.max_off = 0;
+                int aw = o.w;
                 for (int i = 0; i < 2; ++i) {   // MAX_BAND_TRY
                     int prev = a.score;
-                    aw0 = o.w << i;
-                    e = wave_ksw_extend2(ix, o, q, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tlen, aw0, o.pen_clip5, o.zdrop, s.len * o.a, lane, &cells);
+                    aw = o.w << i;
+                    if (qlen <= 64) e = wave_ksw_extend2<1>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, aw, bonus, o.zdrop, h0, lane, &cells);
+                    else if (qlen <= 128) e = wave_ksw_extend2<2>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, aw, bonus, o.zdrop, h0, lane, &cells);
+                    else e = wave_ksw_extend2<4>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, aw, bonus, o.zdrop, h0, lane, &cells);
                     a.score = e.score;
-                    if (a.score == prev || e.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+                    if (a.score == prev || e.max_off < (aw >> 1) + (aw >> 2)) break;
                 }
-                if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip5) {   // local extension
-                    a.qb = s.qbeg - e.qle; a.rb = s.rbeg - e.tle;
-                    a.truesc = a.score;
-                } else {   // to-end extension
-                    a.qb = 0; a.rb = s.rbeg - e.gtle;
-                    a.truesc = e.gscore;
+                if (side == 0) {
+                    aw0 = aw;
+                    if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip5) {   // local extension
+                        a.qb = s.qbeg - e.qle; a.rb = s.rbeg - e.tle;
+                        a.truesc = a.score;
+                    } else {   // to-end extension
+                        a.qb = 0; a.rb = s.rbeg - e.gtle;
+                        a.truesc = e.gscore;
+                    }
+                } else {
+                    aw1 = aw;
+                    if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip3) {   // local extension
+                        a.qe = qe + e.qle; a.re = re + e.tle;
+                        a.truesc += a.score - sc0;
+                    } else {   // to-end extension
+                        a.qe = l_query; a.re = re + e.gtle;
+                        a.truesc += e.gscore - sc0;
+                    }
                 }
-            } else { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; }
-            if (s.qbeg + s.len != l_query) {   // right extension
-                int sc0 = a.score;
-                int qe = s.qbeg + s.len;
-                i64 re = s.rbeg + s.len;
-                int tlen = (int)(rmax1 - re);
-                ExtRes e;
-                e.score = -1; e.qle = e.tle = e.gtle = 0; e.gscore = -1; e.max_off = 0;
-                for (int i = 0; i < 2; ++i) {
-                    int prev = a.score;
-                    aw1 = o.w << i;
-                    e = wave_ksw_extend2(ix, o, q, qe, 1, l_query - qe, re, 1, tlen, aw1, o.pen_clip3, o.zdrop, sc0, lane, &cells);
-                    a.score = e.score;
-                    if (a.score == prev || e.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-                }
-                if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip3) {   // local extension
-                    a.qe = qe + e.qle; a.re = re + e.tle;
-                    a.truesc += a.score - sc0;
-                } else {   // to-end extension
-                    a.qe = l_query; a.re = re + e.gtle;
-                    a.truesc += e.gscore - sc0;
-                }
-            } else { a.qe = l_query; a.re = s.rbeg + s.len; }
+            }
             // seedcov
             int cov = 0;
             for (int i = lane; i < n; i += 64) {
@@ -332,6 +340,10 @@ __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, 
     }
     if (lane == 0) {
         n_regs[r] = n_av;
-        if (ctr) { atomicAdd(&LH_CTR(ctr)->ext_cells, cells); atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }
+        if (ctr) {
+            atomicAdd(&LH_CTR(ctr)->ext_cells, cells);
+            if (count_chains) { atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }   // else counted by k_ext_prep
+        }
+    }
     }
 }

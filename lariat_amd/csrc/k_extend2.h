@@ -1,0 +1,378 @@
+// k_extend2.h — K4 v2: seed extension (BWA mem_chain2aln + ksw_extend2) with ONE LANE PER READ.
+// Reached in the reference through mem_align1_core (go/src/gobwa/gobwa.go:244,253).
+//
+// Measured on MI355X (profiles/r01_*): the wave-per-read kernel (k_extend.h: lanes = query columns, one DP row per step)
+// is VALU-issue bound at ~120 instructions per row for extensions that are ~35 columns wide: ~4.5 instructions per DP
+// cell.  ksw_extend2 is a short sequential program, so here every lane runs it for its own read exactly as written
+// (row-major cells, f/h1 carried in registers), 64 reads per wave:
+//   - eh[] lives in LDS, one 32-bit word per query column: h (16 bits) | e (13 bits) | the column's query base (3 bits),
+//     word j of lane L at ehl[j*64+L] (conflict-free for any per-lane j); one LDS read + one write per cell;
+//   - the reads are bucketed by their longest possible extension (k_ext_prep computes it from the chains), so the lanes
+//     of a wave sweep similar windows, and the bucket classes select the LDS footprint (64 / 128 / 256 columns);
+//   - the per-chain work that is parallel over seeds (reference window, extension order) stays wave-per-read in k_ext_prep.
+#pragma once
+#include "k_extend.h"
+
+// buckets: 0 = reads with many chains / seeds (handed to the wave-per-read kernel, which is parallel over seeds and columns);
+// 1..32 = by the length of the first extension, longest first: 1..16 need 256 LDS columns, 17..24 128, 25..32 64
+#define LH_EXT_BINS 33
+#define LH_EXT_COMPLEX_SEEDS 6
+struct DExtBins {
+    int32_t count[LH_EXT_BINS], cursor[LH_EXT_BINS];
+    int32_t range[12];   // [first,last) pairs into the bucket-sorted order: complex, 256, 128, 64 columns; range[8..9] = the deferred list
+};
+
+// ---- pre-pass, one wave per read: per chain the reference window [rmax0,rmax1) and the seed order; per read the bucket ----
+__global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
+                                                  const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
+                                                  int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, i64* __restrict__ chain_rmax, int32_t* __restrict__ key,
+                                                  DCounters* __restrict__ ctr) {
+    int r = blockIdx.x, lane = LANE();
+    if (r >= n_reads) return;
+    int l_query = (int)(seq_off[r + 1] - seq_off[r]);
+    if (l_query > LH_MAXLEN) l_query = 0;
+    i64 base = seed_off[r];
+    int nch = n_chains[r];
+    i64 l_pac = ix.l_pac;
+    u64 win = 0;
+    int longest = 0, nseeds = 0;
+    for (int ci = 0; ci < nch; ++ci) {
+        DChain c = chains[base + ci];
+        nseeds += c.n;
+        const DSeed* sd = cseeds + base + c.seed_start;
+        int32_t* srt = sorder + base + c.seed_start;   // seed indices by (score, index) ascending
+        int32_t* done = sdone + base + c.seed_start;   // 1 = extension performed (upstream: srt[k] != 0)
+        int n = c.n;
+        if (n == 0) continue;
+        i64 r0 = l_pac << 1, r1 = 0;   // max possible span
+        for (int i = lane; i < n; i += 64) {
+            DSeed t = sd[i];
+            i64 b = t.rbeg - (t.qbeg + dev_cal_max_gap(o, t.qbeg));
+            i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_cal_max_gap(o, l_query - t.qbeg - t.len));
+            r0 = r0 < b ? r0 : b;
+            r1 = r1 > e ? r1 : e;
+        }
+        i64 rmax0 = wave_min_i64(r0), rmax1 = wave_max_i64(r1);
+        rmax0 = rmax0 > 0 ? rmax0 : 0;
+        rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+        DSeed s0 = sd[0];
+        if (rmax0 < l_pac && l_pac < rmax1) {   // crossing the forward-reverse boundary; then choose one side
+            if (s0.rbeg < l_pac) rmax1 = l_pac;
+            else rmax0 = l_pac;
+        }
+        dev_fetch_clamp(ix, &rmax0, s0.rbeg, &rmax1);   // bns_fetch_seq clamps the window to the contig
+        win += (u64)(rmax1 - rmax0);
+        if (lane == 0) { chain_rmax[2 * (base + ci)] = rmax0; chain_rmax[2 * (base + ci) + 1] = rmax1; }
+        // order of extension: by seed score (= len) then index, descending (upstream sorts score<<32|i ascending and walks down)
+        for (int i = lane; i < n; i += 64) {
+            DSeed t = sd[i];
+            int rank = 0;
+            for (int u = 0; u < n; ++u) { DSeed x = sd[u]; rank += (x.len < t.len) || (x.len == t.len && u < i); }
+            srt[rank] = i;
+            done[i] = 1;
+            if (ci == 0 && rank == n - 1) longest = t.qbeg > l_query - t.qbeg - t.len ? t.qbeg : l_query - t.qbeg - t.len;   // the seed extended first
+        }
+    }
+    longest = wave_max_i32(longest);
+    if (lane == 0) {
+        key[r] = nseeds > LH_EXT_COMPLEX_SEEDS ? 0 : 32 - (longest >> 3 < 31 ? longest >> 3 : 31);   // longest extensions first
+        if (ctr) { atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }
+    }
+}
+
+// ---- counting sort of the reads by bucket (order inside a bucket is irrelevant: every read writes its own output slots) ----
+#define LH_EXT_SORT_PER_THREAD 4   // 1024 reads per block: device-scope atomics on 32 shared addresses are slow (~0.25 us each across the XCDs)
+__global__ void __launch_bounds__(256) k_ext_count(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins) {
+    __shared__ int32_t hist[LH_EXT_BINS];
+    if (threadIdx.x < LH_EXT_BINS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
+        int r = (blockIdx.x * LH_EXT_SORT_PER_THREAD + u) * 256 + threadIdx.x;
+        if (r < n_reads) atomicAdd(&hist[key[r]], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < LH_EXT_BINS && hist[threadIdx.x]) atomicAdd(&bins->count[threadIdx.x], hist[threadIdx.x]);
+}
+__global__ void __launch_bounds__(64) k_ext_offsets(DExtBins* __restrict__ bins) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < LH_EXT_BINS; ++b) {
+            if (b == 0) bins->range[0] = acc;
+            if (b == 1) { bins->range[1] = acc; bins->range[2] = acc; }
+            if (b == 17) { bins->range[3] = acc; bins->range[4] = acc; }
+            if (b == 25) { bins->range[5] = acc; bins->range[6] = acc; }
+            bins->cursor[b] = acc; acc += bins->count[b];
+        }
+        bins->range[7] = acc; bins->range[8] = 0; bins->range[9] = 0;
+    }
+}
+__global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins, int32_t* __restrict__ order) {
+    __shared__ int32_t hist[LH_EXT_BINS], basep[LH_EXT_BINS];
+    if (threadIdx.x < LH_EXT_BINS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    int k[LH_EXT_SORT_PER_THREAD], rank[LH_EXT_SORT_PER_THREAD];
+    for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
+        int r = (blockIdx.x * LH_EXT_SORT_PER_THREAD + u) * 256 + threadIdx.x;
+        k[u] = r < n_reads ? key[r] : -1;
+        rank[u] = k[u] >= 0 ? atomicAdd(&hist[k[u]], 1) : 0;   // position inside the block's share of the bucket
+    }
+    __syncthreads();
+    if (threadIdx.x < LH_EXT_BINS && hist[threadIdx.x]) basep[threadIdx.x] = atomicAdd(&bins->cursor[threadIdx.x], hist[threadIdx.x]);
+    __syncthreads();
+    for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
+        int r = (blockIdx.x * LH_EXT_SORT_PER_THREAD + u) * 256 + threadIdx.x;
+        if (k[u] >= 0) order[basep[k[u]] + rank[u]] = r;
+    }
+}
+
+struct LaneTgt {   // the reference bases of an extension, read 16 at a time from the 2-bit forward array
+    const uint32_t* pac32;
+    i64 idx0, widx;
+    int dir, comp;
+    uint32_t w;
+    __device__ __forceinline__ void init(const DIndex& ix, i64 p0, int tstep) {
+        pac32 = (const uint32_t*)ix.pac;
+        int fwd = p0 < ix.l_pac;
+        idx0 = fwd ? p0 : (ix.l_pac << 1) - 1 - p0;
+        dir = fwd ? tstep : -tstep;
+        comp = fwd ? 0 : 3;
+        widx = -1; w = 0;
+    }
+    __device__ __forceinline__ int base(int i) {
+        i64 ii = idx0 + (i64)dir * i;
+        i64 wi = ii >> 4;
+        if (wi != widx) { w = pac32[wi]; widx = wi; }
+        return (int)((w >> (8 * (int)((ii >> 2) & 3) + (int)((~ii & 3) << 1))) & 3) ^ comp;
+    }
+};
+
+#define EH_H(v) ((int)((v) & 0xffffu))
+#define EH_E(v) ((int)(((v) >> 16) & 0x1fffu))
+#define EH_Q(v) ((int)((v) >> 29))
+#define EH_PACK(q, e, h) ((uint32_t)(q) << 29 | (uint32_t)(e) << 16 | (uint32_t)(h))
+
+// ksw_extend2 for one lane.  Column j's query base is qn-nibble (qoff + qstep*j); row i's target base is tg.base(i).
+__device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint32_t* qn, uint32_t* ehl, int lane, int qoff, int qstep, int qlen, LaneTgt& tg, int tlen, int w,
+                                                   int end_bonus, int zdrop, int h0, u64* cells) {
+    const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+#define EHW(j_) ehl[(j_) * 64 + lane]
+    {   // fill the first row
+        int hprev = h0;
+        for (int j = 0; j <= qlen; ++j) {
+            int v = 0;
+            if (j == 0) v = h0;
+            else if (j == 1) v = h0 > oe_ins ? h0 - oe_ins : 0;
+            else v = hprev > e_ins ? hprev - e_ins : 0;
+            if (j >= 2 && hprev == 0) v = 0;
+            hprev = v;
+            int qi = qoff + qstep * j;
+            int qv = j < qlen ? (int)((qn[(qi >> 3) * 64 + lane] >> ((qi & 7) * 4)) & 0xF) : 4;
+            EHW(j) = EH_PACK(qv > 4 ? 4 : qv, 0, v);
+        }
+    }
+    int maxsc = a_ > 0 ? a_ : 0;   // max entry of mat (a, -b, -1)
+    int max_ins = (int)((double)(qlen * maxsc + end_bonus - o_ins) / e_ins + 1.);
+    max_ins = max_ins > 1 ? max_ins : 1;
+    w = w < max_ins ? w : max_ins;
+    int max_del = (int)((double)(qlen * maxsc + end_bonus - o_del) / e_del + 1.);
+    max_del = max_del > 1 ? max_del : 1;
+    w = w < max_del ? w : max_del;
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    int beg = 0, end = qlen;
+    u64 ncell = 0;
+    for (int i = 0; i < tlen; ++i) {
+        int f = 0, h1, m = 0, mj = -1;
+        int tb = tg.base(i);
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+        else h1 = 0;
+        int j;
+        uint32_t p = EHW(beg);
+        for (j = beg; j < end; ++j) {
+            uint32_t pnext = EHW(j + 1);   // j + 1 <= qlen: fetched while this cell is computed
+            int M = EH_H(p), e = EH_E(p), qv = EH_Q(p);
+            int sc = qv > 3 ? -1 : (tb == qv ? a_ : -b_);
+            M = M ? M + sc : 0;
+            int h = M > e ? M : e;
+            h = h > f ? h : f;
+            mj = m > h ? mj : j;
+            m = m > h ? m : h;
+            int t = M - oe_del; t = t > 0 ? t : 0;
+            e -= e_del; e = e > t ? e : t;
+            EHW(j) = EH_PACK(qv, e, h1);
+            h1 = h;
+            t = M - oe_ins; t = t > 0 ? t : 0;
+            f -= e_ins; f = f > t ? f : t;
+            p = pnext;
+        }
+        { uint32_t pe = EHW(end); EHW(end) = EH_PACK(EH_Q(pe), 0, h1); }
+        if (end > beg) ncell += (u64)(end - beg);
+        if (j == qlen) {
+            max_ie = gscore > h1 ? max_ie : i;
+            gscore = gscore > h1 ? gscore : h1;
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            int d = mj - i; d = d < 0 ? -d : d;
+            max_off = max_off > d ? max_off : d;
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) {
+                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+            } else {
+                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+            }
+        }
+        for (j = beg; j < end && (EHW(j) & 0x1fffffffu) == 0; ++j) {}
+        beg = j;
+        for (j = end; j >= beg && (EHW(j) & 0x1fffffffu) == 0; --j) {}
+        end = j + 2 < qlen ? j + 2 : qlen;
+    }
+#undef EHW
+    if (cells) *cells += ncell;
+    ExtRes r;
+    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    return r;
+}
+
+// Reads order[range[0] .. range[1]).  EHW_ = LDS words per lane: a read that turns out to need an extension of EHW_ or more
+// columns (its bucket only bounds the FIRST extension) is left without output and appended to the deferred list, which the
+// wave-per-read kernel processes afterwards from scratch.
+template <int EHW_>
+__global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_reads, const int32_t* __restrict__ range, const int32_t* __restrict__ order,
+                                                     int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list,
+                                                     const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
+                                                     const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
+                                                     const int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, const i64* __restrict__ chain_rmax,
+                                                     const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs, DCounters* __restrict__ ctr) {
+    __shared__ uint32_t qn[32 * 64];
+    __shared__ uint32_t ehl[EHW_ * 64];
+    const int lane = LANE();
+    int first = range[0], last = range[1];
+    int g = first + blockIdx.x * 64 + lane;
+    if (first + blockIdx.x * 64 >= last) return;
+    int r = g < last ? order[g] : -1;
+    i64 off = 0;
+    int l_query = 0;
+    if (r >= 0) { off = seq_off[r]; l_query = (int)(seq_off[r + 1] - off); if (l_query > LH_MAXLEN) l_query = 0; }
+    for (int L = 0; L < 64; ++L) {   // the wave stages the 64 queries, 4 bits per base
+        i64 offL = shfl_i64(off, L);
+        int lnL = wave_readlane(l_query, L);
+        uint32_t wv = 0;
+        if (4 * lane < lnL) __builtin_memcpy(&wv, seq + offL + 4 * lane, 4);
+        uint32_t nb16 = 0;
+        for (int b = 0; b < 4; ++b) {
+            uint32_t v = (wv >> (8 * b)) & 0xff;
+            v = (4 * lane + b < lnL && v < 4) ? v : 4;
+            nb16 |= v << (4 * b);
+        }
+        uint32_t other = __shfl_xor(nb16, 1);
+        if (!(lane & 1)) qn[(lane >> 1) * 64 + L] = nb16 | other << 16;
+    }
+    EMU_SYNC();
+    u64 cells = 0;
+    if (r >= 0) {
+        i64 base = seed_off[r];
+        DReg* av = regs + reg_off[r];
+        int n_av = 0, nch = n_chains[r], deferred = 0;
+        for (int ci = 0; ci < nch && !deferred; ++ci) {
+            DChain c = chains[base + ci];
+            const DSeed* sd = cseeds + base + c.seed_start;
+            const int32_t* srt = sorder + base + c.seed_start;
+            int32_t* done = sdone + base + c.seed_start;
+            int n = c.n;
+            if (n == 0) continue;
+            i64 rmax0 = chain_rmax[2 * (base + ci)], rmax1 = chain_rmax[2 * (base + ci) + 1];
+            for (int k = n - 1; k >= 0 && !deferred; --k) {
+                int si = srt[k];
+                DSeed s = sd[si];
+                // test whether extension has been made before (any earlier region of this read "around" the seed)
+                int hit = 0;
+                for (int i = 0; i < n_av && !hit; ++i) {
+                    DReg p = av[i];
+                    if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;   // not fully contained
+                    if (s.len - p.seedlen0 > .1 * l_query) continue;   // this seed may give a better alignment
+                    int qd = s.qbeg - p.qb; i64 rd = s.rbeg - p.rb;
+                    int max_gap = dev_cal_max_gap(o, qd < rd ? qd : (int)rd);
+                    int w = max_gap < p.w ? max_gap : p.w;
+                    if (qd - rd < w && rd - qd < w) { hit = 1; break; }
+                    qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+                    max_gap = dev_cal_max_gap(o, qd < rd ? qd : (int)rd);
+                    w = max_gap < p.w ? max_gap : p.w;
+                    if (qd - rd < w && rd - qd < w) { hit = 1; break; }
+                }
+                if (hit) {   // (almost) contained: extend only if an overlapping, already-extended seed of the chain lies on another diagonal
+                    int other = 0;
+                    for (int i = k + 1; i < n && !other; ++i) {
+                        int ti = srt[i];
+                        if (!done[ti]) continue;
+                        DSeed t = sd[ti];
+                        if (t.len < s.len * .95) continue;
+                        if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) other = 1;
+                        if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) other = 1;
+                    }
+                    if (!other) { done[si] = 0; continue; }
+                }
+                DReg a;
+                a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = 0; a.seedcov = 0; a.secondary = 0; a.n_comp = 0; a.is_alt = 0;
+                int aw0 = o.w, aw1 = o.w;
+                a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid;
+                for (int side = 0; side < 2; ++side) {   // 0 = left (reversed query prefix vs reversed reference prefix), 1 = right
+                    int qoff, qstep, qlen, tstep, tlen, bonus, h0, sc0 = a.score, qe = s.qbeg + s.len;
+                    i64 tc0, re = s.rbeg + s.len;
+                    if (side == 0) {
+                        if (!s.qbeg) { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; continue; }
+                        qoff = s.qbeg - 1; qstep = -1; qlen = s.qbeg; tc0 = s.rbeg - 1; tstep = -1; tlen = (int)(s.rbeg - rmax0); bonus = o.pen_clip5; h0 = s.len * o.a;
+                    } else {
+                        if (qe == l_query) { a.qe = l_query; a.re = s.rbeg + s.len; continue; }
+                        qoff = qe; qstep = 1; qlen = l_query - qe; tc0 = re; tstep = 1; tlen = (int)(rmax1 - re); bonus = o.pen_clip3; h0 = sc0;
+                    }
+                    ExtRes e;
+                    e.score = -1; e.qle = e.tle = e.gtle = 0; e.gscore = -1; e.max_off = 0;
+                    int aw = o.w;
+                    if (qlen >= EHW_) { deferred = 1; break; }
+                    for (int i = 0; i < 2; ++i) {   // MAX_BAND_TRY
+                        int prev = a.score;
+                        aw = o.w << i;
+                        LaneTgt tg;
+                        tg.init(ix, tc0, tstep);
+                        e = lane_ksw_extend2(o, qn, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells);
+                        a.score = e.score;
+                        if (a.score == prev || e.max_off < (aw >> 1) + (aw >> 2)) break;
+                    }
+                    if (side == 0) {
+                        aw0 = aw;
+                        if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip5) { a.qb = s.qbeg - e.qle; a.rb = s.rbeg - e.tle; a.truesc = a.score; }   // local extension
+                        else { a.qb = 0; a.rb = s.rbeg - e.gtle; a.truesc = e.gscore; }                                                                  // to-end extension
+                    } else {
+                        aw1 = aw;
+                        if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip3) { a.qe = qe + e.qle; a.re = re + e.tle; a.truesc += a.score - sc0; }
+                        else { a.qe = l_query; a.re = re + e.gtle; a.truesc += e.gscore - sc0; }
+                    }
+                }
+                if (deferred) break;
+                int cov = 0;   // seedcov
+                for (int i = 0; i < n; ++i) {
+                    DSeed t = sd[i];
+                    if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
+                }
+                a.seedcov = cov;
+                a.w = aw0 > aw1 ? aw0 : aw1;
+                a.seedlen0 = s.len;
+                a.frac_rep = c.frac_rep;
+                av[n_av++] = a;
+            }
+        }
+        if (!deferred) n_regs[r] = n_av;
+        else { defer_list[atomicAdd(defer_count, 1)] = r; cells = 0; }   // the read is redone from scratch: its cells are counted there
+    }
+    if (ctr) {
+        uint32_t lo = (uint32_t)cells;   // < 2^32 cells per read
+        u64 tot = (u64)(uint32_t)wave_sum_i32((int)(lo >> 16)) << 16;
+        tot += (u64)(uint32_t)wave_sum_i32((int)(lo & 0xffff));
+        if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->ext_cells, tot);
+    }
+}
