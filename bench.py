@@ -27,7 +27,7 @@ import numpy as np
 
 # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB -> B), collected separately and committed
 # under profiles/ (see DESIGN.md section 4 for the calibration of FETCH_SIZE on this access pattern); None = not measured.
-TRAFFIC = {"k_smem3": (1.455e8 + 5.255e7) * 1024.0}
+TRAFFIC = {"k_smem3": (1.455e8 + 5.255e7) * 1024.0, "k_smem4": None}
 
 
 def main():
@@ -126,17 +126,18 @@ def main():
         value = total_pairs / elapsed
         avg = {k: float(np.mean(v)) for k, v in kern.items()}
         dom = max(avg, key=avg.get)
-        # roofline of the dominant kernel.  For k_smem: every bwt_extend reads two 64-B occurrence blocks;
+        # roofline of the dominant kernel.  For K1 (k_smem4): every bwt_extend reads two 32-B occurrence records of the
+        # re-laid-out FM-index (the .bwt file's own layout would be two 64-B blocks) and every read's bases once;
         # n_ext is counted by the kernel itself (and equals the oracle's count in the parity tests).
-        smem_bytes = 128.0 * cnt["n_ext"] + 1.0 * int(rs.seq_off[-1])
+        smem_bytes = 64.0 * cnt["n_ext"] + 1.0 * int(rs.seq_off[-1])
         alg_bytes = {
-            "k_smem": smem_bytes, "k_smem3": smem_bytes,
+            "k_smem3": smem_bytes, "k_smem4": smem_bytes,
             "k_seed": 64.0 * cnt["n_lf"] + 8.0 * cnt["n_sa"],
         }.get(dom, 0.0)
         achieved = alg_bytes / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
-        # measured ceiling for this access pattern: independent random 64-B block reads from a table the size of the BWT
+        # measured ceiling for this access pattern: independent random 32-B record reads from a table the size of the occurrence table
         try:
-            ceiling, _ = lib.diag_random_read(max(int(idx_bwt_bytes), 1 << 20), 64, 1 << 26, device=local_rank)
+            ceiling, _ = lib.diag_random_read(max(int(idx_bwt_bytes), 1 << 20), 32, 1 << 27, device=local_rank)
             ceiling = round(ceiling, 1)
         except Exception:
             ceiling = None
