@@ -14,7 +14,8 @@
 //
 //  - query: 4-bit packed in LDS (8 bases per word, word w of lane L at qn[w*64+L]), staged by the whole wave
 //  - prev/curr interval lists: 16-B packed entries in an HBM slab interleaved by thread; the entry the next row starts
-//    with stays in registers and the following one is prefetched while the current extension is in flight
+//    with stays in registers (and is never written to the slab: most backward rows have a single survivor) and the
+//    following one is prefetched while the current extension is in flight
 #pragma once
 #include "k_smem3.h"
 
@@ -36,16 +37,14 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_REQ_FWD 2
 #define S4_REQ_BWD 3
 #define S4_REQ_P3 4
-#define S4_BWD_NEXT 8    // states >= 8 are transitions handled without an extension
+#define S4_BWD_EMIT 8    // states >= 8 are transitions handled without an extension (section B of the main loop)
 #define S4_BWD_INIT 9
-#define S4_BWD_ROW 10
+#define S4_BWD_EMIT0 10
 #define S4_SMEM_DONE 11
 #define S4_P1_SCAN 12
 #define S4_P2_NEXT 13
 #define S4_P3_SCAN 14
-#define S4_FWD_PREP 15
-#define S4_P3_PREP 16
-#define S4_READ_DONE 17
+#define S4_READ_DONE 15
 
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
@@ -55,7 +54,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                                                int32_t* __restrict__ next_read, DCounters* __restrict__ ctr) {
     __shared__ uint32_t qn[32 * 64];
     const int lane = LANE();
-    const size_t T = (size_t)gridDim.x * 64, t = (size_t)blockIdx.x * 64 + lane;
+    const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)lane;
     PEnt* const LA = slab + t;                                    // entry e of list A at LA[e * T]
     PEnt* const LB = slab + (size_t)(LH_MAXLEN + 2) * T + t;
     const int split_len = (int)(o.min_seed_len * o.split_factor + .499);
@@ -71,11 +70,72 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
 #define QB(i_) ((int)((qn[((i_) >> 3) * 64 + lane] >> (((i_) & 7) * 4)) & 0xF))
 #define CURR (curA ? LA : LB)
 #define PREV (curA ? LB : LA)
-#define START_SMEM1()                                                                                       \
+    // forward extension: the next base decides between another bwt_extend and the end of the forward list
+#define FWD_ADVANCE()                                                                                        \
     {                                                                                                        \
-        int b_ = QB(x);                                                                                      \
-        c0 = ix.L2[b_] + 1; c2 = ix.L2[b_ + 1] - ix.L2[b_]; c1 = ix.L2[3 - b_] + 1; cinfo = x + 1;          \
-        ncurr = 0; i = x + 1; curA = 1; st = S4_FWD_PREP;                                                    \
+        int b_ = i < len ? QB(i) : 4;                                                                        \
+        if (b_ > 3) {   /* end of read or ambiguous base: the current interval closes the forward list */    \
+            ce = pe_pack(c0, c1, c2, cinfo);   /* the list's last entry is only ever read through ce */      \
+            ncurr++;                                                                                         \
+            st = S4_BWD_INIT;                                                                                \
+        } else { ec = 3 - b_; st = S4_REQ_FWD; }                                                             \
+    }
+#define START_SMEM1()                                                                                        \
+    {                                                                                                        \
+        int s_ = QB(x);                                                                                      \
+        c0 = ix.L2[s_] + 1; c2 = ix.L2[s_ + 1] - ix.L2[s_]; c1 = ix.L2[3 - s_] + 1; cinfo = x + 1;          \
+        ncurr = 0; i = x + 1; curA = 1;                                                                      \
+        FWD_ADVANCE()                                                                                        \
+    }
+    // pass 3: next base of the forward-only walk
+#define P3_ADVANCE()                                                                                         \
+    {                                                                                                        \
+        if (i >= len) st = S4_READ_DONE;                                                                     \
+        else {                                                                                               \
+            int b_ = QB(i);                                                                                  \
+            if (b_ > 3) { x = i + 1; st = S4_P3_SCAN; }                                                      \
+            else { ec = 3 - b_; st = S4_REQ_P3; }                                                            \
+        }                                                                                                    \
+    }
+    // start of a backward row at read position i: the first prev entry is in registers (ce)
+#define BWD_ROW_BODY()                                                                                       \
+    {                                                                                                        \
+        int c_ = i < 0 ? 4 : QB(i);                                                                          \
+        ncurr = 0; last_size = 0; j = 0;                                                                     \
+        c0 = PE_X0(ce); c1 = PE_X1(ce); c2 = PE_X2(ce); cinfo = PE_INFO(ce);                                 \
+        if (c_ > 3) st = S4_BWD_EMIT0;   /* nothing extends: only the first (longest) entry can be a new MEM */ \
+        else {                                                                                               \
+            ec = c_; st = S4_REQ_BWD;                                                                        \
+            if (nprev > 1) pn = PREV[(uint32_t)(rev ? nprev - 2 : 1) * T];                                   \
+        }                                                                                                    \
+    }
+    // after prev entry j: the next entry of the row (prefetched), or the next row, or the end of this bwt_smem1a
+#define BWD_ADVANCE()                                                                                        \
+    {                                                                                                        \
+        ++j;                                                                                                 \
+        if (j < nprev) {                                                                                     \
+            c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn); cinfo = PE_INFO(pn);                             \
+            st = S4_REQ_BWD;                                                                                 \
+            if (j + 1 < nprev) pn = PREV[(uint32_t)(rev ? nprev - 2 - j : j + 1) * T];                       \
+        } else if (ncurr == 0) st = S4_SMEM_DONE;                                                            \
+        else {                                                                                               \
+            curA ^= 1; nprev = ncurr; rev = 0; --i;                                                          \
+            if (i < -1) st = S4_SMEM_DONE;                                                                   \
+            else BWD_ROW_BODY()                                                                              \
+        }                                                                                                    \
+    }
+    // a backward-sweep interval that cannot be extended and is not contained in the previous MEM becomes a MEM
+#define EMIT_MEM()                                                                                           \
+    {                                                                                                        \
+        if (cinfo - (i + 1) >= o.min_seed_len) {                                                             \
+            if (on >= LH_MAX_INTV) ovf = 1;                                                                  \
+            else {                                                                                           \
+                DIntv m_; m_.x0 = c0; m_.x1 = c1; m_.x2 = c2; m_.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32; \
+                if (phase == 1 && cinfo - (i + 1) >= split_len && c2 <= (u64)o.split_width) p2mask |= 1ull << on; \
+                out[on++] = m_;                                                                              \
+            }                                                                                                \
+        }                                                                                                    \
+        have_mem = 1; last_mem_start = i + 1;                                                                \
     }
     for (;;) {
         // ---- A. lanes without a read take the next ones of the wave's chunk; the wave stages their bases in LDS ----
@@ -123,41 +183,20 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 else st = S4_READ_DONE;
             }
         }
-        // ---- B. transitions (no extension involved); blocks are ordered so that the usual chains finish in one pass ----
+        // ---- B. transitions between the loops of mem_collect_intv (rare per lane; the blocks are ordered so that the
+        //         usual chains finish in one pass) ----
         while (__any(st >= 8)) {
-            if (st == S4_BWD_NEXT) {
-                if (j < nprev) {
-                    c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn); cinfo = PE_INFO(pn);
-                    st = S4_REQ_BWD;
-                    if (j + 1 < nprev) pn = PREV[(size_t)(rev ? nprev - 2 - j : j + 1) * T];
-                } else if (ncurr == 0) st = S4_SMEM_DONE;
-                else { curA ^= 1; nprev = ncurr; rev = 0; --i; st = i < -1 ? S4_SMEM_DONE : S4_BWD_ROW; }
+            if (st == S4_BWD_EMIT) {
+                EMIT_MEM()
+                BWD_ADVANCE()
             }
             if (st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
                 ret = cinfo; curA ^= 1; nprev = ncurr; rev = 1; have_mem = 0; last_mem_start = 0; i = x - 1;
-                st = S4_BWD_ROW;
+                BWD_ROW_BODY()
             }
-            if (st == S4_BWD_ROW) {
-                int c = i < 0 ? 4 : QB(i);
-                ncurr = 0; last_size = 0; j = 0;
-                c0 = PE_X0(ce); c1 = PE_X1(ce); c2 = PE_X2(ce); cinfo = PE_INFO(ce);   // first entry of the row: kept in registers
-                if (c > 3) {   // nothing extends: only the first (longest) entry can be a new MEM
-                    if (!have_mem || i + 1 < last_mem_start) {
-                        if (cinfo - (i + 1) >= o.min_seed_len) {
-                            if (on >= LH_MAX_INTV) ovf = 1;
-                            else {
-                                DIntv m; m.x0 = c0; m.x1 = c1; m.x2 = c2; m.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32;
-                                if (phase == 1 && cinfo - (i + 1) >= split_len && c2 <= (u64)o.split_width) p2mask |= 1ull << on;
-                                out[on++] = m;
-                            }
-                        }
-                        have_mem = 1; last_mem_start = i + 1;
-                    }
-                    st = S4_SMEM_DONE;
-                } else {
-                    ec = c; st = S4_REQ_BWD;
-                    if (nprev > 1) pn = PREV[(size_t)(rev ? nprev - 2 : 1) * T];
-                }
+            if (st == S4_BWD_EMIT0) {
+                if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
+                st = S4_SMEM_DONE;
             }
             if (st == S4_SMEM_DONE) {
                 if (phase == 1) { x = ret; st = S4_P1_SCAN; }
@@ -182,29 +221,14 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                     break;
                 }
             }
-            if (st == S4_P3_SCAN) {   // third pass: LAST-like forward-only seeds (bwt_seed_strategy1)
+            while (st == S4_P3_SCAN) {   // third pass: LAST-like forward-only seeds (bwt_seed_strategy1)
                 while (x < len && QB(x) > 3) ++x;
                 if (x >= len) st = S4_READ_DONE;
                 else {
                     int b = QB(x);
                     c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1;
-                    i = x + 1; st = S4_P3_PREP;
-                }
-            }
-            if (st == S4_FWD_PREP) {
-                int b = i < len ? QB(i) : 4;
-                if (b > 3) {   // end of read or ambiguous base: the current interval closes the forward list
-                    ce = pe_pack(c0, c1, c2, cinfo);
-                    CURR[(size_t)ncurr * T] = ce; ncurr++;
-                    st = S4_BWD_INIT;
-                } else { ec = 3 - b; st = S4_REQ_FWD; }
-            }
-            if (st == S4_P3_PREP) {
-                if (i >= len) st = S4_READ_DONE;
-                else {
-                    int b = QB(i);
-                    if (b > 3) { x = i + 1; st = S4_P3_SCAN; }
-                    else { ec = 3 - b; st = S4_REQ_P3; }
+                    i = x + 1;
+                    P3_ADVANCE()
                 }
             }
             if (st == S4_READ_DONE) {
@@ -227,35 +251,29 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
             ok = dev_extend_c(ix, a, ec, st == S4_REQ_BWD);
             n_ext_total++;
         }
-        // ---- E. bookkeeping of the loop the lane is in ----
+        // ---- E. bookkeeping of the loop the lane is in, and its next request ----
         if (st == S4_REQ_FWD) {
-            st = S4_FWD_PREP;
             if (ok.x2 != c2) {
                 ce = pe_pack(c0, c1, c2, cinfo);
-                CURR[(size_t)ncurr * T] = ce; ncurr++;
-                if (ok.x2 < (u64)min_intv) st = S4_BWD_INIT;   // the interval is too small to be extended further
+                if (ok.x2 < (u64)min_intv) st = S4_BWD_INIT;   // the interval is too small to be extended further: ce is the list's last entry
+                else CURR[(uint32_t)ncurr * T] = ce;
+                ncurr++;
             }
-            if (st == S4_FWD_PREP) { c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i; }
+            if (st == S4_REQ_FWD) {
+                c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i;
+                FWD_ADVANCE()
+            }
         } else if (st == S4_REQ_BWD) {
             if (ok.x2 < (u64)min_intv) {
-                if (ncurr == 0 && (!have_mem || i + 1 < last_mem_start)) {   // no longer match survived, not contained in the previous MEM
-                    if (cinfo - (i + 1) >= o.min_seed_len) {
-                        if (on >= LH_MAX_INTV) ovf = 1;
-                        else {
-                            DIntv m; m.x0 = c0; m.x1 = c1; m.x2 = c2; m.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32;
-                            if (phase == 1 && cinfo - (i + 1) >= split_len && c2 <= (u64)o.split_width) p2mask |= 1ull << on;
-                            out[on++] = m;
-                        }
-                    }
-                    have_mem = 1; last_mem_start = i + 1;
-                }
+                if (ncurr == 0 && (!have_mem || i + 1 < last_mem_start)) st = S4_BWD_EMIT;   // no longer match survived, not contained in the previous MEM
             } else if (ncurr == 0 || ok.x2 != last_size) {
                 PEnt e = pe_pack(ok.x0, ok.x1, ok.x2, cinfo);
-                if (ncurr == 0) ce = e;
-                CURR[(size_t)ncurr * T] = e; ncurr++;
+                if (ncurr == 0) ce = e;   // a row's first entry is only ever read through ce
+                else CURR[(uint32_t)ncurr * T] = e;
+                ncurr++;
                 last_size = ok.x2;
             }
-            ++j; st = S4_BWD_NEXT;
+            if (st == S4_REQ_BWD) BWD_ADVANCE()
         } else if (st == S4_REQ_P3) {
             if (ok.x2 < (u64)o.max_mem_intv && i - x >= o.min_seed_len) {
                 if (ok.x2 > 0) {
@@ -263,13 +281,21 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                     else { DIntv m = ok; m.info = (u64)x << 32 | (u64)(i + 1); out[on++] = m; }
                 }
                 x = i + 1; st = S4_P3_SCAN;
-            } else { c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; ++i; st = S4_P3_PREP; }
+            } else {
+                c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; ++i;
+                P3_ADVANCE()
+            }
         }
     }
 #undef QB
 #undef CURR
 #undef PREV
 #undef START_SMEM1
+#undef FWD_ADVANCE
+#undef P3_ADVANCE
+#undef BWD_ROW_BODY
+#undef BWD_ADVANCE
+#undef EMIT_MEM
     if (ctr) {
         unsigned tot = (unsigned)wave_sum_i32((int)n_ext_total);
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->n_ext, (u64)tot);
