@@ -13,9 +13,13 @@
 #pragma once
 #include "k_extend.h"
 
-// buckets: 0 = reads with many chains / seeds (handed to the wave-per-read kernel, which is parallel over seeds and columns);
-// 1..32 = by the length of the first extension, longest first: 1..16 need 256 LDS columns, 17..24 128, 25..32 64
-#define LH_EXT_BINS 33
+// primary buckets: 0 = reads with many chains / seeds (handed to the wave-per-read kernel, which is parallel over seeds and
+// columns); 1..32 = by the length of the LONGER side of the first extension, longest first: 1..16 need 256 LDS columns,
+// 17..24 128, 25..32 64.  Each primary bucket has LH_EXT_SUB sub-buckets by the length of the SHORTER side, so that the
+// lanes of a wave sweep similar windows on both sides of the seed.
+#define LH_EXT_PRIMARY 33
+#define LH_EXT_SUB 8
+#define LH_EXT_BINS (LH_EXT_PRIMARY * LH_EXT_SUB)
 #define LH_EXT_COMPLEX_SEEDS 6
 struct DExtBins {
     int32_t count[LH_EXT_BINS], cursor[LH_EXT_BINS];
@@ -35,7 +39,7 @@ __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, int n_reads
     int nch = n_chains[r];
     i64 l_pac = ix.l_pac;
     u64 win = 0;
-    int longest = 0, nseeds = 0;
+    int longest = 0, shorter = 0, nseeds = 0;
     for (int ci = 0; ci < nch; ++ci) {
         DChain c = chains[base + ci];
         nseeds += c.n;
@@ -70,12 +74,17 @@ __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, int n_reads
             for (int u = 0; u < n; ++u) { DSeed x = sd[u]; rank += (x.len < t.len) || (x.len == t.len && u < i); }
             srt[rank] = i;
             done[i] = 1;
-            if (ci == 0 && rank == n - 1) longest = t.qbeg > l_query - t.qbeg - t.len ? t.qbeg : l_query - t.qbeg - t.len;   // the seed extended first
+            if (ci == 0 && rank == n - 1) {   // the seed extended first
+                int lt = t.qbeg, rt = l_query - t.qbeg - t.len;
+                longest = lt > rt ? lt : rt; shorter = lt > rt ? rt : lt;
+            }
         }
     }
-    longest = wave_max_i32(longest);
+    longest = wave_max_i32(longest); shorter = wave_max_i32(shorter);
     if (lane == 0) {
-        key[r] = nseeds > LH_EXT_COMPLEX_SEEDS ? 0 : 32 - (longest >> 3 < 31 ? longest >> 3 : 31);   // longest extensions first
+        int prim = nseeds > LH_EXT_COMPLEX_SEEDS ? 0 : 32 - (longest >> 3 < 31 ? longest >> 3 : 31);   // longest extensions first
+        int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
+        key[r] = prim * LH_EXT_SUB + sub;
         if (ctr) { atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }
     }
 }
@@ -84,23 +93,23 @@ __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, int n_reads
 #define LH_EXT_SORT_PER_THREAD 4   // 1024 reads per block: device-scope atomics on 32 shared addresses are slow (~0.25 us each across the XCDs)
 __global__ void __launch_bounds__(256) k_ext_count(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins) {
     __shared__ int32_t hist[LH_EXT_BINS];
-    if (threadIdx.x < LH_EXT_BINS) hist[threadIdx.x] = 0;
+    for (int b = threadIdx.x; b < LH_EXT_BINS; b += 256) hist[b] = 0;
     __syncthreads();
     for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
         int r = (blockIdx.x * LH_EXT_SORT_PER_THREAD + u) * 256 + threadIdx.x;
         if (r < n_reads) atomicAdd(&hist[key[r]], 1);
     }
     __syncthreads();
-    if (threadIdx.x < LH_EXT_BINS && hist[threadIdx.x]) atomicAdd(&bins->count[threadIdx.x], hist[threadIdx.x]);
+    for (int b = threadIdx.x; b < LH_EXT_BINS; b += 256) if (hist[b]) atomicAdd(&bins->count[b], hist[b]);
 }
 __global__ void __launch_bounds__(64) k_ext_offsets(DExtBins* __restrict__ bins) {
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int b = 0; b < LH_EXT_BINS; ++b) {
             if (b == 0) bins->range[0] = acc;
-            if (b == 1) { bins->range[1] = acc; bins->range[2] = acc; }
-            if (b == 17) { bins->range[3] = acc; bins->range[4] = acc; }
-            if (b == 25) { bins->range[5] = acc; bins->range[6] = acc; }
+            if (b == 1 * LH_EXT_SUB) { bins->range[1] = acc; bins->range[2] = acc; }
+            if (b == 17 * LH_EXT_SUB) { bins->range[3] = acc; bins->range[4] = acc; }
+            if (b == 25 * LH_EXT_SUB) { bins->range[5] = acc; bins->range[6] = acc; }
             bins->cursor[b] = acc; acc += bins->count[b];
         }
         bins->range[7] = acc; bins->range[8] = 0; bins->range[9] = 0;
@@ -108,7 +117,7 @@ __global__ void __launch_bounds__(64) k_ext_offsets(DExtBins* __restrict__ bins)
 }
 __global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins, int32_t* __restrict__ order) {
     __shared__ int32_t hist[LH_EXT_BINS], basep[LH_EXT_BINS];
-    if (threadIdx.x < LH_EXT_BINS) hist[threadIdx.x] = 0;
+    for (int b = threadIdx.x; b < LH_EXT_BINS; b += 256) hist[b] = 0;
     __syncthreads();
     int k[LH_EXT_SORT_PER_THREAD], rank[LH_EXT_SORT_PER_THREAD];
     for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
@@ -117,7 +126,7 @@ __global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t*
         rank[u] = k[u] >= 0 ? atomicAdd(&hist[k[u]], 1) : 0;   // position inside the block's share of the bucket
     }
     __syncthreads();
-    if (threadIdx.x < LH_EXT_BINS && hist[threadIdx.x]) basep[threadIdx.x] = atomicAdd(&bins->cursor[threadIdx.x], hist[threadIdx.x]);
+    for (int b = threadIdx.x; b < LH_EXT_BINS; b += 256) if (hist[b]) basep[b] = atomicAdd(&bins->cursor[b], hist[b]);
     __syncthreads();
     for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
         int r = (blockIdx.x * LH_EXT_SORT_PER_THREAD + u) * 256 + threadIdx.x;
