@@ -199,9 +199,14 @@ __device__ __forceinline__ u64 dev_mix64(u64 x) {
 #endif
 
 // One wavefront per barcode; barcodes are handed out through the device counter *bc_next (their costs differ widely).
+// A barcode whose tables do not fit the wave's slab (the reader caps a work unit at 30,000 pairs, fastqreader/reader.go:205,
+// far above the common few hundred) is appended to ovf_list and processed by a second launch whose few waves own much
+// larger slabs (work_list = that list); only there an overflow is final (LH_ST_POOL_OVERFLOW).
 __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
                                              const u64* __restrict__ name_seed, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S, i64 cand_cap,
-                                             uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status, int32_t* __restrict__ bc_next) {
+                                             uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status, int32_t* __restrict__ bc_next,
+                                             const int32_t* __restrict__ work_list, const int32_t* __restrict__ work_count, int32_t* __restrict__ ovf_list,
+                                             int32_t* __restrict__ ovf_count) {
     __shared__ int32_t shi[8];
     __shared__ double shd[4];
     __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LH_RFA_LDS_BYTES];   // one buffer, re-used phase by phase
@@ -213,12 +218,24 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
     const int lane = LANE();
     uint8_t* slab = slab_pool + (size_t)blockIdx.x * (size_t)slab_bytes;
     const double improper = o.improper_pair_penalty;
+    const int n_work = work_list ? *work_count : n_bc;
+#define RFA_OVERFLOW()                                                                                 \
+    {                                                                                                  \
+        if (lane == 0) {                                                                               \
+            if (ovf_list) ovf_list[atomicAdd(ovf_count, 1)] = bc;                                      \
+            else status[r0] |= LH_ST_POOL_OVERFLOW;                                                    \
+        }                                                                                              \
+        continue;                                                                                      \
+    }
+    int wd_main = 1 << 24;
     for (;;) {
+        LH_WATCH(wd_main, 12, break)
         if (lane == 0) shi[5] = atomicAdd(bc_next, 1);
         WAVE_SYNC();
-        const int bc = shi[5];
+        const int widx = shi[5];
         WAVE_SYNC();
-        if (bc >= n_bc) break;
+        if (widx >= n_work) break;
+        const int bc = work_list ? work_list[widx] : widx;
         int p0 = bc_pair_off[bc], p1 = bc_pair_off[bc + 1];
         int nR = 2 * (p1 - p0), r0 = 2 * p0;
         i64 c_lo = R.cand_off[r0], c_hi = R.cand_off[r0 + nR];
@@ -279,10 +296,7 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
         T.bestT = (int32_t*)(slab + so);
         size_t best_cap = ((size_t)slab_bytes > so) ? ((size_t)slab_bytes - so) / 4 : 0;
 #undef CARVE
-        if (so > (size_t)slab_bytes) {   // barcode too large for the slab
-            if (lane == 0) status[r0] |= LH_ST_POOL_OVERFLOW;
-            continue;
-        }
+        if (so > (size_t)slab_bytes) RFA_OVERFLOW()   // barcode too large for the slab
         // ---- positions: filtered candidates grouped by contig in first-seen order, candidate order inside a contig ----
         // pass A: contig slot of every candidate (first-seen numbering) and the slot sizes
         int32_t* const seen = ncmax <= LH_RFA_NCONT_LDS ? (int32_t*)lds_raw : T.seen_rid;
@@ -436,10 +450,7 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
                 ao += wave_readlane(inc, 63);
             }
             WAVE_SYNC();
-            if ((size_t)M * (size_t)nR > best_cap) {   // molecule table does not fit the slab
-                if (lane == 0) status[r0] |= LH_ST_POOL_OVERFLOW;
-                continue;
-            }
+            if ((size_t)M * (size_t)nR > best_cap) RFA_OVERFLOW()   // molecule table does not fit the slab
             for (size_t x = lane; x < (size_t)M * nR; x += 64) T.bestT[x] = -1;
             for (int r = lane; r < nR; r += 64) { T.act_cand[r] = -1; T.act_slot[r] = -1; }
             for (int i = lane; i < NCf; i += 64) S.molecule_id[c_lo + T.plist[i]] = T.newid[T.molraw[i]];
@@ -705,7 +716,9 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             for (int r = lane; r < nR; r += 64) {
                 u64 k0 = T.dk0[r], k1 = T.dk1[r], k2 = T.dk2[r], k3 = T.dk3[r];
                 int slot = (int)(dev_mix64(k0 ^ dev_mix64(k1 ^ dev_mix64(k2 ^ dev_mix64(k3)))) & (u64)hmask);
+                int wd_ins = hmask + 2;
                 for (;;) {
+                    LH_WATCH(wd_ins, 13, break)
                     int cur = atomicCAS(&T.htab[slot], -1, r);
                     if (cur == -1) break;
                     if (T.dk0[cur] == k0 && T.dk1[cur] == k1 && T.dk2[cur] == k2 && T.dk3[cur] == k3) { atomicMin(&T.htab[slot], r); break; }
@@ -717,7 +730,9 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
                 u64 k0 = T.dk0[r], k1 = T.dk1[r], k2 = T.dk2[r], k3 = T.dk3[r];
                 int slot = (int)(dev_mix64(k0 ^ dev_mix64(k1 ^ dev_mix64(k2 ^ dev_mix64(k3)))) & (u64)hmask);
                 int dup = 0;
+                int wd_look = hmask + 2;
                 for (;;) {
+                    LH_WATCH(wd_look, 14, break)
                     int cur = atomicAdd(&T.htab[slot], 0);   // read at L2, where the atomics above landed
                     if (T.dk0[cur] == k0 && T.dk1[cur] == k1 && T.dk2[cur] == k2 && T.dk3[cur] == k3) { dup = cur != r; break; }
                     slot = (slot + 1) & hmask;

@@ -62,3 +62,15 @@ def test_emu_full_inference(emu, oracle):
     res = idx.context(rs.n_pairs).align_barcodes(b)
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
     assert (res.active_idx >= 0).all()
+
+
+def test_emu_inference_slab_overflow_pass(emu, oracle, monkeypatch):
+    """barcodes whose tables outgrow a wave's slab are redone by the second launch with large slabs: force that path"""
+    monkeypatch.setenv("LH_RFA_SLAB_KB", "4")
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=3, pairs=30, junk=0.05, seed=21)
+    b = helpers.batch_of(rs)
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
