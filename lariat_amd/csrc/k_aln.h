@@ -1,9 +1,15 @@
 // k_aln.h — K7: region -> alignment.  Per candidate: BWA mem_reg2aln (band inference, bwa_gen_cigar2 -> ksw_global2 with
 // traceback, NM, clip ops; go/src/gobwa/gobwa.go:400-415,449-488), bns_fetch_seq (gobwa.go:50-80) and lariat's
 // GetAlignments CIGAR walk (go/src/inference/lariat.go:1552-1704): matches / mismatches / indels / soft clips /
-// mismatch loci / log_alignment_probability / the best-17 filter.  One wavefront per read, looping over its candidates.
+// mismatch loci / log_alignment_probability / the best-17 filter.
+//
+// Two kernels.  k_aln_fast (one LANE per read) settles every candidate that needs no DP — query and reference spans of
+// equal length and an inferred band of 0, i.e. bwa_gen_cigar2's "no gap; no need to do DP" branch, the great majority — and
+// writes the others to a list; k_aln (one WAVE per listed candidate) runs the banded global alignment with traceback.
+// Measured: one wave per read for everything was a chain of ~10 dependent phases per candidate (11.7 ms per 2 M reads).
 #pragma once
 #include "k_rescue.h"
+#include "k_extend2.h"   // LaneTgt
 
 #define LH_MAXT 704                       // reference bases staged per candidate (re - rb)
 #define LH_ZSLAB (LH_MAXT * 256)          // direction bytes per resident wave
@@ -40,7 +46,8 @@ __device__ __forceinline__ double dev_single_score(int mismatches, int indels, i
 
 __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                              const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, i64 cand_cap,
-                                             uint8_t* __restrict__ zpool, int32_t* __restrict__ status, DCounters* __restrict__ ctr) {
+                                             uint8_t* __restrict__ zpool, int32_t* __restrict__ status, DCounters* __restrict__ ctr,
+                                             const int32_t* __restrict__ slow_r, const int32_t* __restrict__ slow_ci, const int32_t* __restrict__ slow_count) {
     __shared__ uint8_t q[LH_MAXLEN + 6];
     __shared__ uint8_t tref[LH_MAXT];
     __shared__ uint32_t cg[LH_MAX_CIGAR + 4];
@@ -49,7 +56,9 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
     int lane = LANE();
     uint8_t* z = zpool + (size_t)blockIdx.x * LH_ZSLAB;
     u64 cells = 0;
-    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const int n_items = *slow_count;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int r = slow_r[item], ci = slow_ci[item];
         i64 off = seq_off[r];
         int l_query = (int)(seq_off[r + 1] - off);
         if (l_query > LH_MAXLEN) l_query = 0;
@@ -60,24 +69,10 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
         int n = n_regs[r];
         i64 c0 = R.cand_off[r];
         int st = 0;
-        if (c0 + (n > 0 ? n : 1) > cand_cap) {   // candidate pool exhausted: flag and skip (host returns LH_E_CAPACITY)
-            if (lane == 0) status[r] |= LH_ST_POOL_OVERFLOW;
-            continue;
-        }
-        if (n == 0) {   // placeholder (lariat.go:1737-1750,1773-1785): contig "", pos -1, aend 0, score 0
-            if (lane == 0) {
-                i64 c = c0;
-                R.rid[c] = -1; R.pos[c] = -1; R.aend[c] = 0; R.rb[c] = -1; R.re[c] = -1; R.reversed[c] = 0; R.score[c] = 0; R.qb[c] = 0; R.qe[c] = 0;
-                R.nm[c] = 0; R.matches[c] = 0; R.mismatches[c] = 0; R.indels[c] = 0; R.soft_clipped[c] = 0; R.soft_clipped_length[c] = 0;
-                R.in_filtered[c] = 1; R.n_cigar[c] = 0; R.n_mm[c] = 0; R.read_len[c] = l_query;
-                R.lap[c] = (dev_single_score(0, 0, 0, 0) + o.improper_pair_penalty) - o.improper_pair_penalty;
-            }
-            continue;
-        }
-        int best = 0;
+        int best = 0;   // (pool overflow and reads without regions were settled by k_aln_fast)
         for (int i = lane; i < n; i += 64) { int s = av[i].score; best = best > s ? best : s; }
         best = wave_max_i32(best);
-        for (int ci = 0; ci < n; ++ci) {
+        {
             DReg ar = av[ci];
             i64 c = c0 + ci;
             int qb = ar.qb, qe = ar.qe, lq = qe - qb;
@@ -247,7 +242,108 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
                 if (!valid) st |= LH_ST_TOO_LONG;
             }
         }
-        if (lane == 0 && st) status[r] |= st;
+        if (lane == 0 && st) atomicOr(&status[r], st);   // other waves may hold other candidates of the same read
     }
     if (lane == 0 && ctr && cells) atomicAdd(&LH_CTR(ctr)->glob_cells, cells);
+}
+
+// ---- one lane per read: candidates without DP are finished here, the others are listed for k_aln ----
+__global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+                                                   const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, i64 cand_cap,
+                                                   int32_t* __restrict__ status, int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    const int live = r < n_reads;
+    int n = 0, n_slow = 0, all_slow = 0;
+    uint32_t slow_mask = 0;   // candidates ci < 32 that need DP; reads with more regions are listed entirely
+    i64 c0 = 0;
+    if (live) {
+        const i64 off = seq_off[r];
+        int l_query = (int)(seq_off[r + 1] - off);
+        if (l_query > LH_MAXLEN) l_query = 0;
+        const uint8_t* q = seq + off;
+        const DReg* av = regs + reg_off[r];
+        n = n_regs[r];
+        c0 = R.cand_off[r];
+        if (c0 + (n > 0 ? n : 1) > cand_cap) {   // candidate pool exhausted: flag and skip (host returns LH_E_CAPACITY)
+            atomicOr(&status[r], LH_ST_POOL_OVERFLOW);
+            n = 0;
+        } else if (n == 0) {   // placeholder (lariat.go:1737-1750,1773-1785): contig "", pos -1, aend 0, score 0
+            i64 c = c0;
+            R.rid[c] = -1; R.pos[c] = -1; R.aend[c] = 0; R.rb[c] = -1; R.re[c] = -1; R.reversed[c] = 0; R.score[c] = 0; R.qb[c] = 0; R.qe[c] = 0;
+            R.nm[c] = 0; R.matches[c] = 0; R.mismatches[c] = 0; R.indels[c] = 0; R.soft_clipped[c] = 0; R.soft_clipped_length[c] = 0;
+            R.in_filtered[c] = 1; R.n_cigar[c] = 0; R.n_mm[c] = 0; R.read_len[c] = l_query;
+            R.lap[c] = (dev_single_score(0, 0, 0, 0) + o.improper_pair_penalty) - o.improper_pair_penalty;
+        }
+        if (n > 32) { all_slow = 1; n_slow = n; }
+        else {
+            int best = 0;
+            for (int i = 0; i < n; ++i) { int s = av[i].score; best = best > s ? best : s; }
+            for (int ci = 0; ci < n; ++ci) {
+                DReg ar = av[ci];
+                const i64 c = c0 + ci;
+                const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
+                const i64 rb = ar.rb, re = ar.re;
+                const int rlen = (int)(re - rb);
+                const int valid = lq > 0 && rb < re && !(rb < ix.l_pac && re > ix.l_pac) && rlen <= LH_MAXT;
+                int tmp = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_del, o.e_del);
+                int w2 = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_ins, o.e_ins);
+                w2 = w2 > tmp ? w2 : tmp;
+                if (w2 > o.w) w2 = w2 < ar.w ? w2 : ar.w;
+                w2 = w2 < o.w << 2 ? w2 : o.w << 2;
+                if (!(valid && lq == rlen && w2 == 0)) { slow_mask |= 1u << ci; n_slow++; continue; }
+                // no gap: CIGAR = [clip] lq M [clip]; one pass over the bases gives NM and lariat's mismatch loci.
+                // The aligned pairs are q[qb + t] vs the base at fwd||rev coordinate rb + t (the wave kernel's oriented views
+                // pair the same bases in the opposite order on the reverse strand).
+                int is_rev;
+                const i64 posf = dev_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+                const i64 coff = ix.contig_off[ar.rid];
+                const i64 Offset = rb < ix.l_pac ? rb - coff : ix.l_pac * 2 - 1 - rb - coff;   // InterpretAlign (gobwa.go:339-371)
+                const i64 End = re < ix.l_pac ? re - coff : ix.l_pac * 2 - 1 - re - coff;
+                i64 refStart = Offset, refEnd = End;
+                if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
+                int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
+                int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
+                LaneTgt tg;
+                tg.init(ix, rb, 1);
+                int nmm = 0;
+                for (int t = 0; t < lq; ++t) {
+                    int rbase = tg.base(t), qv = q[qb + t];
+                    if (rbase != qv) {
+                        if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
+                        nmm++;
+                    }
+                }
+                const int NM = nmm;
+                int mm_ovf = 0;
+                if (nmm > LH_MAX_MM) { mm_ovf = 1; nmm = LH_MAX_MM; }
+                int clip5 = 0, clip3 = 0, no = 0;
+                if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
+                uint32_t* cgo = R.cigar + (size_t)c * LH_MAX_CIGAR;
+                if (clip5) cgo[no++] = (uint32_t)clip5 << 4 | 3;
+                cgo[no++] = (uint32_t)lq << 4 | 0;
+                if (clip3) cgo[no++] = (uint32_t)clip3 << 4 | 3;
+                const int soft_clipping = (clip5 > 0) + (clip3 > 0), soft_clipping_length = clip5 + clip3;
+                int mismatches = NM, matches = lq - NM;
+                const int rid = dev_pos2rid(ix, posf);
+                i64 pos = Offset, aend = End;
+                if (pos != -1 && is_rev) { pos = End + 1; aend = Offset + 1; }
+                R.rid[c] = rid; R.pos[c] = pos; R.aend[c] = aend; R.rb[c] = rb; R.re[c] = re; R.reversed[c] = (uint8_t)is_rev; R.score[c] = ar.score;
+                R.qb[c] = qb; R.qe[c] = qe; R.nm[c] = NM; R.matches[c] = matches; R.mismatches[c] = mismatches; R.indels[c] = 0;
+                R.soft_clipped[c] = soft_clipping; R.soft_clipped_length[c] = soft_clipping_length;
+                R.in_filtered[c] = ar.score >= best - o.aln_score_delta;
+                R.n_cigar[c] = no; R.n_mm[c] = nmm; R.read_len[c] = l_query;
+                R.lap[c] = (dev_single_score(mismatches, 0, soft_clipping, soft_clipping_length) + o.improper_pair_penalty) - o.improper_pair_penalty;
+                if (mm_ovf) atomicOr(&status[r], LH_ST_MM_OVERFLOW);
+            }
+        }
+    }
+    // the wave reserves list space once (same-address atomics are slow), then every lane writes its own items
+    int incl = wave_scan_add_i32(n_slow);
+    int total = wave_readlane(incl, 63), basep = 0;
+    if (total) {
+        if (lane == 0) basep = atomicAdd(slow_count, total);
+        basep = wave_readlane(basep, 0) + incl - n_slow;
+        for (int ci = 0; ci < n; ++ci)
+            if (all_slow || (slow_mask >> ci & 1)) { slow_r[basep] = r; slow_ci[basep] = ci; basep++; }
+    }
 }
