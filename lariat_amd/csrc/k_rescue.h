@@ -190,11 +190,15 @@ __device__ __forceinline__ int wave_matesw(const DIndex& ix, const DOpts& o, con
 // K6.  grid = n_pairs waves.
 __global__ void __launch_bounds__(64) k_rescue(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                 const i64* __restrict__ reg_off, DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool,
-                                                int32_t* __restrict__ n_regs, const int32_t* __restrict__ best_score, DCounters* __restrict__ ctr) {
+                                                int32_t* __restrict__ n_regs, const int32_t* __restrict__ best_score, DCounters* __restrict__ ctr,
+                                                const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
     __shared__ uint8_t q1[LH_MAXLEN + 6];
     __shared__ uint8_t q2[LH_MAXLEN + 6];
-    int p = blockIdx.x, lane = LANE();
-    if (p >= n_pairs) return;
+    const int lane = LANE();
+    const int n_items = *list_count;   // the pairs k_rescue_filter found a rescue attempt for
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int p = list[item];
+    WAVE_SYNC();   // the previous pair's queries are no longer in use
     int r1 = 2 * p, r2 = 2 * p + 1;
     i64 off1 = seq_off[r1], off2 = seq_off[r2];
     int l1 = (int)(off2 - off1), l2 = (int)(seq_off[r2 + 1] - off2);
@@ -231,5 +235,52 @@ __global__ void __launch_bounds__(64) k_rescue(DIndex ix, DOpts o, int n_pairs, 
     if (lane == 0) {
         n_regs[r1] = n1; n_regs[r2] = n2;
         if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); }
+    }
+    }
+}
+
+// One lane per pair: does any of the pair's rescue attempts (gobwa.go:286-325) get past mem_matesw's first test, "a
+// consistent pair exists; no need to perform SW"?  Almost no pair does (12 per 10 k reads on the bench data), so the wave
+// kernel above only sees the listed ones.  A pair that is not listed is left exactly as it is: without a rescue nothing
+// is inserted, so the second loop of k_rescue sees the same regions this filter tests.
+__global__ void __launch_bounds__(256) k_rescue_filter(DIndex ix, DOpts o, int n_pairs, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
+                                                        const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, const int32_t* __restrict__ best_score,
+                                                        int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    int need = 0;
+    if (p < n_pairs) {
+        const int r1 = 2 * p, r2 = 2 * p + 1;
+        const i64 off1 = seq_off[r1], off2 = seq_off[r2];
+        int l1 = (int)(off2 - off1), l2 = (int)(seq_off[r2 + 1] - off2);
+        if (l1 > LH_MAXLEN) l1 = 0;
+        if (l2 > LH_MAXLEN) l2 = 0;
+        const DReg *av1 = regs + reg_off[r1], *av2 = regs + reg_off[r2];
+        const int n1 = n_regs[r1], n2 = n_regs[r2];
+        const int best1 = best_score[r1], best2 = best_score[r2];
+        for (int dir = 0; dir < 2 && !need; ++dir) {
+            const DReg* from = dir ? av1 : av2;   // the anchors ...
+            const DReg* ma = dir ? av2 : av1;     // ... and the mate's own regions
+            const int nf = dir ? n1 : n2, nm = dir ? n2 : n1, bestf = dir ? best1 : best2, l_ms = dir ? l2 : l1;
+            int num = 0;
+            for (int i = 0; i < nf && num < o.rescue_max_hits && l_ms > 0 && !need; ++i) {
+                const i64 arb = from[i].rb;
+                if (from[i].score < bestf - o.rescue_score_delta) continue;
+                num++;
+                int skip1 = 0;
+                for (int j = 0; j < nm && !skip1; ++j) {
+                    i64 dist;
+                    int r = dev_infer_dir(ix.l_pac, arb, ma[j].rb, &dist);
+                    skip1 = (r == 1 && dist >= o.pes_low && dist <= o.pes_high);
+                }
+                if (!skip1) need = 1;
+            }
+        }
+    }
+    u64 m = __ballot(need);
+    if (m) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(list_count, (int32_t)__popcll(m));
+        basep = wave_readlane(basep, 0);
+        if (need) list[basep + lanes_below(m, lane)] = p;
     }
 }
