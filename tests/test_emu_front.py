@@ -74,3 +74,16 @@ def test_emu_inference_slab_overflow_pass(emu, oracle, monkeypatch):
     b = helpers.batch_of(rs)
     res = idx.context(rs.n_pairs).align_barcodes(b)
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
+
+
+def test_emu_long_noisy_reads(emu, oracle):
+    """240-bp reads with substitutions and indels: the 128/256-column classes of the lane-per-read extension, deferred reads,
+    gapped global alignments"""
+    from lariat_amd import synth
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = synth.make_reads(contigs, names, n_barcodes=2, pairs_per_barcode=40, seed=31, len1=240, len2=236, sub_lo=0.005, sub_hi=0.03, indel_rate=0.003, junk_frac=0.02)
+    b = helpers.batch_of(rs)
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)

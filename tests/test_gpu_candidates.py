@@ -79,3 +79,21 @@ def test_repeat_rich_genome(lib, oracle):
     res = idx.context(rs.n_pairs).align_barcodes(b, lib.opts(run_inference=0))
     helpers.assert_same_result(res, oidx.align_barcodes(b, oracle.opts(run_inference=0), threads=8), inference=False)
     assert np.diff(res.cand_off).max() >= 4
+
+
+def test_long_noisy_reads(lib, oracle):
+    """240-bp reads with 3 % substitutions and indels: first extensions of 128+ columns (the 256-column LDS class of
+    k_extend_lane), deferred reads, gapped global alignments with wide bands, long CIGARs and many mismatch loci"""
+    from lariat_amd import synth
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = synth.make_reads(contigs, names, n_barcodes=12, pairs_per_barcode=80, seed=31, len1=240, len2=236, sub_lo=0.005, sub_hi=0.03, indel_rate=0.003, junk_frac=0.02)
+    b = helpers.batch_of(rs)
+    ctx = idx.context(rs.n_pairs)
+    helpers.assert_same_dump(ctx.stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    res = ctx.align_barcodes(b)
+    ores = oidx.align_barcodes(b, threads=8)
+    helpers.assert_same_result(res, ores, inference=True)
+    for k in ("n_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"):
+        assert res.counters[k] == ores.counters[k], k
