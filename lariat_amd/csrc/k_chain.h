@@ -26,14 +26,18 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
                                                i64 pool_cap, const DSeed* __restrict__ seeds, const int32_t* __restrict__ s_rid,
                                                const int32_t* __restrict__ l_rep, int32_t* __restrict__ s_next, DChainTmp* __restrict__ ct,
                                                int32_t* __restrict__ ord, int32_t* __restrict__ srt, DChain* __restrict__ chains,
-                                               DSeed* __restrict__ cseeds, int32_t* __restrict__ n_chains, int32_t* __restrict__ status) {
-    int r = blockIdx.x, lane = LANE();
-    if (r >= n_reads) return;
+                                               DSeed* __restrict__ cseeds, int32_t* __restrict__ n_chains, int32_t* __restrict__ status,
+                                               const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
+    const int lane = LANE();
+    const int n_items = list ? *list_count : n_reads;   // with a list: the reads k_chain_lane left to this kernel
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int r = list ? list[item] : item;
+    WAVE_SYNC();
     i64 base = seed_off[r];
     int S = (int)(seed_off[r + 1] - base);
     if (seed_off[r + 1] > pool_cap) {   // pool overflow: flag, produce nothing (host retries with a smaller batch)
-        if (lane == 0) { n_chains[r] = 0; status[r] |= LH_ST_POOL_OVERFLOW; }
-        return;
+        if (lane == 0) { n_chains[r] = 0; atomicOr(&status[r], LH_ST_POOL_OVERFLOW); }
+        continue;
     }
     int len = (int)(seq_off[r + 1] - seq_off[r]);
     const DSeed* sd_ = seeds + base;
@@ -185,5 +189,194 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
         DChain oc = chains[base + k];
         int s = C[oc.pad].head;
         for (int t = 0; s >= 0; s = nx[s], ++t) cseeds[base + oc.seed_start + t] = sd_[s];
+    }
+    }
+}
+
+// klib's ks_introsort for n <= 16: one median-of-3 partition step, then insertion sort (ranges of <= 16 elements are
+// never pushed on its stack).  Per-lane control flow: callable from lane-per-read kernels.
+#define LH_CHAIN_LANE_MAX 16
+template <class T, class Lt> __device__ inline void dev_introsort_small(int n, T* a, Lt lt) {
+    T rp, swap_tmp;
+    if (n < 1) return;
+    if (n == 2) {
+        if (lt(a[1], a[0])) { swap_tmp = a[0]; a[0] = a[1]; a[1] = swap_tmp; }
+        return;
+    }
+    if (n > 1) {
+        T *s = a, *t = a + (n - 1), *i = s, *j = t, *k = i + ((j - i) >> 1) + 1;
+        if (lt(*k, *i)) {
+            if (lt(*k, *j)) k = j;
+        } else k = lt(*j, *i) ? i : j;
+        rp = *k;
+        if (k != t) { swap_tmp = *k; *k = *t; *t = swap_tmp; }
+        int wd = 4 * LH_CHAIN_LANE_MAX + 8;
+        for (;;) {
+            do { ++i; LH_WATCH(wd, 4, return) } while (lt(*i, rp));
+            do { --j; LH_WATCH(wd, 5, return) } while (i <= j && lt(rp, *j));
+            if (j <= i) break;
+            swap_tmp = *i; *i = *j; *j = swap_tmp;
+        }
+        swap_tmp = *i; *i = *t; *t = swap_tmp;
+    }
+    for (T* i = a + 1; i < a + n; ++i)
+        for (T* j = i; j > a && lt(*j, *(j - 1)); --j) { T tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
+}
+
+// K3 for the common read: one LANE per read when it has at most LH_CHAIN_LANE_MAX seeds (mem_chain is a short sequential
+// program over a handful of seeds; a wave per read spent its time on launch and single-lane latency: 5.4 ms per 2 M
+// reads).  Same arithmetic and the same order of B-tree / sort / filter operations as the wave kernel above, whose
+// single-lane sections appear here inline.  Reads with more seeds are listed for the wave kernel.
+__global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
+                                                    i64 pool_cap, const DSeed* __restrict__ seeds, const int32_t* __restrict__ s_rid,
+                                                    const int32_t* __restrict__ l_rep, int32_t* __restrict__ s_next, DChainTmp* __restrict__ ct,
+                                                    int32_t* __restrict__ ord, int32_t* __restrict__ srt, DChain* __restrict__ chains,
+                                                    DSeed* __restrict__ cseeds, int32_t* __restrict__ n_chains, int32_t* __restrict__ status,
+                                                    int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    int heavy = 0;
+    if (r < n_reads) {
+        const i64 base = seed_off[r];
+        const int S = (int)(seed_off[r + 1] - base);
+        if (seed_off[r + 1] > pool_cap) { n_chains[r] = 0; atomicOr(&status[r], LH_ST_POOL_OVERFLOW); }
+        else if (S > LH_CHAIN_LANE_MAX) heavy = 1;
+        else {
+            const int len = (int)(seq_off[r + 1] - seq_off[r]);
+            const DSeed* sd_ = seeds + base;
+            const int32_t* rid_ = s_rid + base;
+            int32_t* nx = s_next + base;
+            DChainTmp* C = ct + base;
+            int32_t* od = ord + base;
+            int32_t* st = srt + base;
+            int nch = 0;
+            for (int s = 0; s < S; ++s) {
+                int rid = rid_[s];
+                if (rid < 0) continue;   // bridging contigs / the forward-reverse boundary
+                DSeed p = sd_[s];
+                int to_add = 1, lo = 0;
+                if (nch > 0) {
+                    int hi = nch;
+                    while (lo < hi) { int m = (lo + hi) >> 1; if (C[od[m]].pos <= p.rbeg) lo = m + 1; else hi = m; }
+                    if (lo > 0) {
+                        int ci = od[lo - 1];
+                        DChainTmp c = C[ci];
+                        i64 qend = c.last_qbeg + c.last_len, rend = c.last_rbeg + c.last_len;   // test_and_merge
+                        int res = 0;   // 0: new chain, 1: contained, 2: appended
+                        if (rid != c.rid) res = 0;
+                        else if (p.qbeg >= c.first_qbeg && p.qbeg + p.len <= qend && p.rbeg >= c.pos && p.rbeg + p.len <= rend) res = 1;
+                        else if ((c.last_rbeg < ix.l_pac || c.pos < ix.l_pac) && p.rbeg >= ix.l_pac) res = 0;
+                        else {
+                            i64 x = p.qbeg - c.last_qbeg, y = p.rbeg - c.last_rbeg;
+                            if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c.last_len < o.max_chain_gap && y - c.last_len < o.max_chain_gap) res = 2;
+                        }
+                        if (res == 2) {
+                            nx[c.tail] = s; nx[s] = -1;
+                            C[ci].tail = s; C[ci].n = c.n + 1; C[ci].last_rbeg = p.rbeg; C[ci].last_qbeg = p.qbeg; C[ci].last_len = p.len;
+                        }
+                        to_add = (res == 0);
+                    }
+                }
+                if (to_add) {
+                    for (int j = nch; j > lo; --j) od[j] = od[j - 1];
+                    od[lo] = nch;
+                    DChainTmp c;
+                    c.pos = p.rbeg; c.last_rbeg = p.rbeg; c.first_qbeg = p.qbeg; c.last_qbeg = p.qbeg; c.last_len = p.len; c.rid = rid;
+                    c.n = 1; c.head = s; c.tail = s; c.w = 0; c.kept = 0; c.first = -1; c.beg = 0; c.end = 0;
+                    C[nch] = c;
+                    nx[s] = -1;
+                    nch++;
+                }
+            }
+            for (int k = 0; k < nch; ++k) {   // mem_chain_weight, chn_beg / chn_end
+                DChainTmp c = C[k];
+                int w = 0;
+                i64 end = 0;
+                for (int s = c.head; s >= 0; s = nx[s]) {
+                    DSeed t = sd_[s];
+                    if (t.qbeg >= end) w += t.len;
+                    else if (t.qbeg + t.len > end) w += t.qbeg + t.len - (int)end;
+                    end = end > t.qbeg + t.len ? end : t.qbeg + t.len;
+                }
+                int tmp = w;
+                w = 0; end = 0;
+                for (int s = c.head; s >= 0; s = nx[s]) {
+                    DSeed t = sd_[s];
+                    if (t.rbeg >= end) w += t.len;
+                    else if (t.rbeg + t.len > end) w += (int)(t.rbeg + t.len - end);
+                    end = end > t.rbeg + t.len ? end : t.rbeg + t.len;
+                }
+                w = w < tmp ? w : tmp;
+                C[k].w = w < 1 << 30 ? w : (1 << 30) - 1;
+                C[k].beg = c.first_qbeg;
+                C[k].end = c.last_qbeg + c.last_len;
+            }
+            // mem_chain_flt
+            int n = 0;
+            for (int k = 0; k < nch; ++k) {   // chains in position order (B-tree traversal), dropping light ones
+                int id = od[k];
+                C[id].first = -1; C[id].kept = 0;
+                if (C[id].w < o.min_chain_weight) continue;
+                st[n++] = id;
+            }
+            int nk = 0;   // kept-chain list reuses od[]
+            if (n > 0) {
+                dev_introsort_small(n, st, [&](int x, int y) { return C[x].w > C[y].w; });
+                C[st[0]].kept = 3;
+                od[nk++] = 0;
+                for (int i = 1; i < n; ++i) {
+                    int large_ovlp = 0, k;
+                    DChainTmp ai = C[st[i]];
+                    for (k = 0; k < nk; ++k) {
+                        int j = od[k];
+                        DChainTmp aj = C[st[j]];
+                        int b_max = aj.beg > ai.beg ? aj.beg : ai.beg;
+                        int e_min = aj.end < ai.end ? aj.end : ai.end;
+                        if (e_min > b_max) {   // have overlap (no ALT contigs: is_alt == 0)
+                            int li = ai.end - ai.beg, lj = aj.end - aj.beg;
+                            int min_l = li < lj ? li : lj;
+                            if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {   // significant overlap
+                                large_ovlp = 1;
+                                if (aj.first < 0) C[st[j]].first = i;
+                                if (ai.w < aj.w * o.drop_ratio && aj.w - ai.w >= o.min_seed_len << 1) break;
+                            }
+                        }
+                    }
+                    if (k == nk) { od[nk++] = i; C[st[i]].kept = large_ovlp ? 2 : 3; }
+                }
+                for (int i = 0; i < nk; ++i) {
+                    int f = C[st[od[i]]].first;
+                    if (f >= 0) C[st[f]].kept = 1;
+                }
+                int i, k;
+                for (i = k = 0; i < n; ++i) {   // don't extend more than max_chain_extend .kept=1/2 chains
+                    int kp = C[st[i]].kept;
+                    if (kp == 0 || kp == 3) continue;
+                    if (++k >= o.max_chain_extend) break;
+                }
+                for (; i < n; ++i)
+                    if (C[st[i]].kept < 3) C[st[i]].kept = 0;
+            }
+            int m = 0, sstart = 0;   // emit kept chains in sorted order, each with its seed list flattened
+            for (int i = 0; i < n; ++i) {
+                DChainTmp c = C[st[i]];
+                if (c.kept == 0) continue;
+                DChain oc;
+                oc.pos = c.pos; oc.rid = c.rid; oc.n = c.n; oc.seed_start = sstart; oc.w = c.w; oc.kept = c.kept; oc.is_alt = 0;
+                oc.frac_rep = (float)l_rep[r] / len; oc.pad = st[i];
+                chains[base + m] = oc;
+                int t = 0;
+                for (int s = c.head; s >= 0; s = nx[s], ++t) cseeds[base + sstart + t] = sd_[s];
+                sstart += c.n;
+                m++;
+            }
+            n_chains[r] = m;
+        }
+    }
+    u64 hm = __ballot(heavy);
+    if (hm) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(list_count, (int32_t)__popcll(hm));
+        basep = wave_readlane(basep, 0);
+        if (heavy) list[basep + lanes_below(hm, lane)] = r;
     }
 }
