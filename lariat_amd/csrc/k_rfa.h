@@ -508,8 +508,11 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
             WAVE_SYNC();
             RFA_T(7)
             // ---- optimizer.Optimize(opt, 1, 2, 4*M): 8*M greedy molecule moves ----
-            int source = 0;
-            for (int it = 0; it < 8 * M; ++it) {
+            // The optimizer is deterministic: once M consecutive turns (every molecule tried once as the source) accept no
+            // move, the state can no longer change and the remaining turns are no-ops, so they are not executed.
+            int source = 0, idle = 0;
+            for (int it = 0; it < 8 * M && idle < M; ++it) {
+                ++idle;
                 if (T.alen[source] == 0) { source = (source + 1) % M; continue; }
                 double bs = -1.7976931348623157e308;
                 int bl = -1, bi = 0x7fffffff;
@@ -529,6 +532,7 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
                     int num, nmv;   // acceptMove: recompute the move list (every lane evaluates the winner, lane 0 records), apply in order
                     dev_fast_score_w(R, S, T, c_lo, r0, M, source, bi, improper, sLr, sFl, sLap, &num, lane == 0, &nmv);
                     WAVE_SYNC();
+                    idle = 0;
                     if (lane == 0) {
                         for (int k = 0; k < nmv; ++k) {
                             int lr = T.tdel[k], t = T.tset[k];
