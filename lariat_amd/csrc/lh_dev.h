@@ -238,13 +238,40 @@ __device__ __forceinline__ void dev_occ4(const DIndex& ix, u64 k, u64 cnt[4]) {
     if (ix.sb) { const u64* sb = ix.sb + ((k >> ix.sb_shift) << 2); cnt[0] += sb[0]; cnt[1] += sb[1]; cnt[2] += sb[2]; cnt[3] += sb[3]; }
 }
 
+// counts of one record up to and including symbol (k & 63): the popcount half of bwt_occ4
+__device__ __forceinline__ void dev_occ4_rec(const DIndex& ix, u64 k, uint4 h, uint4 d, u64 cnt[4]) {
+    int m = (int)(k & 63) + 1;
+    u64 mask = ~0ull >> (64 - m);
+    u64 hi = ((u64)d.y << 32 | d.x) & mask, lo = ((u64)d.w << 32 | d.z) & mask;
+    u64 i3 = hi & lo, i2 = hi ^ i3, i1 = lo ^ i3;
+    int n3 = __popcll(i3), n2 = __popcll(i2), n1 = __popcll(i1);
+    cnt[0] = (u64)h.x + (u64)(m - n1 - n2 - n3); cnt[1] = (u64)h.y + (u64)n1; cnt[2] = (u64)h.z + (u64)n2; cnt[3] = (u64)h.w + (u64)n3;
+    if (ix.sb) { const u64* sb = ix.sb + ((k >> ix.sb_shift) << 2); cnt[0] += sb[0]; cnt[1] += sb[1]; cnt[2] += sb[2]; cnt[3] += sb[3]; }
+}
+
+// bwt_2occ4(k, l): the two positions of an interval usually fall into the same 64-symbol record once the interval is
+// small; the record is then read once (L1 does not merge the two in-flight misses, and K1 runs at the request-rate limit
+// of the memory system, so the second request is not free).
+__device__ __forceinline__ void dev_2occ4(const DIndex& ix, u64 k, u64 l, u64 tk[4], u64 tl[4]) {
+    u64 l2 = l - (l >= ix.primary);
+    const uint4* pl = ix.occ + ((l2 >> 6) << 1);
+    uint4 hl = pl[0], dl = pl[1];
+    if (k == (u64)-1) { tk[0] = tk[1] = tk[2] = tk[3] = 0; }
+    else {
+        u64 k2 = k - (k >= ix.primary);
+        uint4 hk = hl, dk = dl;
+        if ((k2 >> 6) != (l2 >> 6)) { const uint4* pk = ix.occ + ((k2 >> 6) << 1); hk = pk[0]; dk = pk[1]; }
+        dev_occ4_rec(ix, k2, hk, dk, tk);
+    }
+    dev_occ4_rec(ix, l2, hl, dl, tl);
+}
+
 // bwt_extend restricted to the one base `c` the caller follows: returns ok[c]
 __device__ __forceinline__ DIntv dev_extend_c(const DIndex& ix, const DIntv& ik, int c, int is_back) {
     u64 tk[4], tl[4];
     u64 xa = is_back ? ik.x0 : ik.x1;   // x[!is_back]
     u64 xb = is_back ? ik.x1 : ik.x0;   // x[is_back]
-    dev_occ4(ix, xa - 1, tk);
-    dev_occ4(ix, xa - 1 + ik.x2, tl);
+    dev_2occ4(ix, xa - 1, xa - 1 + ik.x2, tk, tl);
     u64 s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
     u64 acc = xb + ((xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) ? 1 : 0);   // ok[3].x[is_back]
     u64 o3 = acc, o2 = o3 + s3, o1 = o2 + s2, o0 = o1 + s1;
