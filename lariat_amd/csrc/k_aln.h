@@ -306,11 +306,19 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                 LaneTgt tg;
                 tg.init(ix, rb, 1);
                 int nmm = 0;
-                for (int t = 0; t < lq; ++t) {
-                    int rbase = tg.base(t), qv = q[qb + t];
-                    if (rbase != qv) {
-                        if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
-                        nmm++;
+                for (int t0 = 0; t0 < lq; t0 += 16) {   // 16 query bases per round trip (the batch buffer is padded past the last read)
+                    uint32_t qw[4];
+                    __builtin_memcpy(qw, q + qb + t0, 16);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        int t = t0 + u;
+                        if (t < lq) {
+                            int rbase = tg.base(t), qv = (int)((qw[u >> 2] >> ((u & 3) * 8)) & 0xff);
+                            if (rbase != qv) {
+                                if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
+                                nmm++;
+                            }
+                        }
                     }
                 }
                 const int NM = nmm;
