@@ -105,3 +105,28 @@ def test_slab_overflow_second_pass(lib, oracle, monkeypatch):
     b = helpers.batch_of(rs)
     res = idx.context(rs.n_pairs).align_barcodes(b)
     helpers.assert_same_result(res, oidx.align_barcodes(b, threads=8), inference=True)
+
+
+def test_two_contexts_concurrently(lib, oracle):
+    """double buffering as a driver would do it: two contexts of one index (own streams, own pools) aligned from two host
+    threads at the same time give the results of running them one after the other"""
+    import threading
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    batches = [helpers.batch_of(helpers.small_reads(names, contigs, n_barcodes=6, pairs=60, junk=0.03, seed=41 + k)) for k in range(2)]
+    ctxs = [idx.context(360) for _ in range(2)]
+    seq = [ctxs[k].align_barcodes(batches[k]) for k in range(2)]
+    out = [None, None]
+
+    def work(k):
+        for _ in range(3):
+            out[k] = ctxs[k].align_barcodes(batches[k])
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        helpers.assert_same_result(out[k], seq[k], inference=True)
