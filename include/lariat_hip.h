@@ -232,6 +232,42 @@ int lh_get_seq(const lh_index* idx, int32_t rid, int64_t start, int64_t end, int
  * from a `table_bytes` table in HBM — the practical ceiling for the FM-index walks */
 int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, int64_t n_access, double* gbps, double* ms);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * N2 — 9-line barcode-sorted FASTQ ingest: go/src/fastqreader/reader.go (ReadOneLine :91-147,
+ * ReadBarcodeSet :173-260), zipread.go:62-85 (gunzip pipe), and the driver's use of a set (lariat.go:353-375 the read loop,
+ * :1088-1100 worthRunningRFA, :1483-1484 the tie-break seed).  Host-only code: no GPU is touched.
+ *
+ * A "set" is what one call of ReadBarcodeSet returns = one WorkUnit = one barcode entry of an lh_batch.  The reader's
+ * quirks are part of the contract and are reproduced: a set holds at most `cap` (30,000) pairs; a barcode without '-'
+ * (not whitelisted) is cut every `chunk` (200) pairs; the continuation of a barcode that was cut at the cap breaks at 200
+ * ("abnormal break") and is flagged incomplete; text before a '@' line is skipped as "Bad line"; a truncated final
+ * record is dropped; read 1 loses its first min(len, trim) bases (kept as trim_bases / trim_quals for the TR/TQ tags);
+ * the barcode line may be "corrected,raw". */
+typedef struct lh_ingest lh_ingest;
+
+typedef struct lh_ingest_batch {
+    lh_batch batch;              /* ready for lh_align_barcodes / lh_batch_upload (cen_* left NULL) */
+    int32_t n_sets;              /* == batch.n_barcodes */
+    const uint8_t* set_complete; /* [n_sets] ReadBarcodeSet's third result (WorkUnit.unique_barcode, lariat.go:214,374) */
+    /* per-pair text kept for the BAM stage (bamwriter.go): offsets [n_pairs+1] into byte arenas, no terminators */
+    const int64_t *name_off, *rgid_off, *qual1_off, *qual2_off, *trim_off, *bc_off, *rawbc_off, *bcqual_off, *si_off, *siqual_off;
+    const char *name, *rgid, *qual1, *qual2, *trim_bases, *trim_quals, *bc, *rawbc, *bcqual, *si, *siqual;
+    int64_t first_set_index;     /* index of batch set 0 among all sets read so far (lariat's barcode_num - 1) */
+    int32_t at_eof;              /* 1: the input is exhausted after this batch */
+    void* arena_;
+} lh_ingest_batch;
+
+/* gz input (magic 1f 8b) is read through a `gunzip -c` pipe like the reference, anything else directly.
+ * cap / chunk <= 0 select the reference's 30000 / 200. */
+int lh_ingest_open(const char* path, int32_t trim, int32_t cap, int32_t chunk, lh_ingest** out);
+/* Appends whole sets until the next one would exceed max_pairs (always at least one set; a set never straddles batches).
+ * Returns LH_OK with out->batch.n_pairs == 0 and at_eof == 1 when nothing is left. */
+int lh_ingest_next(lh_ingest* in, int64_t max_pairs, lh_ingest_batch** out);
+void lh_ingest_batch_free(lh_ingest_batch* b);
+void lh_ingest_close(lh_ingest* in);
+/* md5 of `n` bytes -> the tie-break seed lariat derives from a read name (LE u64 of digest[0:8]) */
+uint64_t lh_name_seed(const char* name, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

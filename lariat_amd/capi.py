@@ -224,6 +224,16 @@ def _declare(L):
     L.lh_index_contigs.argtypes = [C.c_void_p, c_i32p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(c_i64p), C.POINTER(c_i64p)]
     L.lh_index_l_pac.argtypes = [C.c_void_p]
     L.lh_index_l_pac.restype = C.c_int64
+    L.lh_ingest_open.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.lh_ingest_open.restype = C.c_int
+    L.lh_ingest_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(LhIngestBatch))]
+    L.lh_ingest_next.restype = C.c_int
+    L.lh_ingest_batch_free.argtypes = [C.POINTER(LhIngestBatch)]
+    L.lh_ingest_batch_free.restype = None
+    L.lh_ingest_close.argtypes = [C.c_void_p]
+    L.lh_ingest_close.restype = None
+    L.lh_name_seed.argtypes = [C.c_char_p, C.c_int64]
+    L.lh_name_seed.restype = C.c_uint64
     L.lh_index_resample_sa.argtypes = [C.c_void_p, C.c_int32]
     L.lh_index_resample_sa.restype = C.c_int
     L.lh_index_sa_interval.argtypes = [C.c_void_p]
@@ -302,6 +312,15 @@ class Library:
                                                int(arrs["sa_intv"]), sa.ctypes.data_as(c_u64p), len(sa), pac.ctypes.data_as(c_u8p), int(arrs["l_pac"]),
                                                n, offs.ctypes.data_as(c_i64p), lens.ctypes.data_as(c_i32p), names, C.byref(h)))
         return Index(self, h)
+
+    def ingest(self, path, trim=7, cap=0, chunk=0, max_pairs=1 << 20):
+        """9-line FASTQ reader with the reference's work-unit rules (fastqreader/reader.go); host only"""
+        return Ingest(self, path, trim, cap, chunk, max_pairs)
+
+    def name_seed(self, name):
+        if isinstance(name, str):
+            name = name.encode()
+        return int(self.L.lh_name_seed(name, len(name)))
 
     def index_build(self, prefix, names, contigs_nt4, threads=0):
         n = len(names)
@@ -424,9 +443,91 @@ def load_library(path=None):
     return _lib
 
 
+class LhIngestBatch(C.Structure):
+    _fields_ = ([("batch", LhBatch), ("n_sets", C.c_int32), ("set_complete", c_u8p)]
+                + [(n + "_off", c_i64p) for n in ("name", "rgid", "qual1", "qual2", "trim", "bc", "rawbc", "bcqual", "si", "siqual")]
+                + [(n, C.c_void_p) for n in ("name", "rgid", "qual1", "qual2", "trim_bases", "trim_quals", "bc", "rawbc", "bcqual", "si", "siqual")]
+                + [("first_set_index", C.c_int64), ("at_eof", C.c_int32), ("arena_", C.c_void_p)])
+
+
+class IngestBatch:
+    """one lh_ingest_batch: `.c_batch` goes to Context.upload / align_barcodes; text columns are exposed as lists of bytes"""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+        b = ptr.contents
+        self.c_batch = b.batch
+        self.c = b.batch   # so that an IngestBatch can be handed to Context.upload / align_barcodes like a Batch
+        self.n_pairs, self.n_sets = int(b.batch.n_pairs), int(b.n_sets)
+        self.first_set_index, self.at_eof = int(b.first_set_index), bool(b.at_eof)
+        self.bc_pair_off = _view(b.batch.bc_pair_off, self.n_sets + 1, np.int32).copy()
+        self.bc_do_rfa = _view(b.batch.bc_do_rfa, self.n_sets, np.uint8).copy()
+        self.set_complete = _view(b.set_complete, self.n_sets, np.uint8).copy()
+        self.seq_off = _view(b.batch.seq_off, 2 * self.n_pairs + 1, np.int64).copy()
+        self.seq = _view(b.batch.seq, int(self.seq_off[-1]), np.uint8).copy()
+        self.name_seed = _view(b.batch.name_seed, self.n_pairs, np.uint64).copy()
+
+    def column(self, name):
+        b = self.ptr.contents
+        offname = {"trim_bases": "trim_off", "trim_quals": "trim_off"}.get(name, name + "_off")
+        off = _view(getattr(b, offname), self.n_pairs + 1, np.int64)
+        base = getattr(b, name)
+        raw = C.string_at(base, int(off[-1])) if self.n_pairs and off[-1] else b""
+        return [raw[off[i]:off[i + 1]] for i in range(self.n_pairs)]
+
+    def read(self, r):
+        return self.seq[self.seq_off[r]:self.seq_off[r + 1]]
+
+    def close(self):
+        if self.ptr:
+            self.lib.L.lh_ingest_batch_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Ingest:
+    """9-line FASTQ reader (fastqreader/reader.go); iterate to get IngestBatch objects of whole barcode sets"""
+
+    def __init__(self, lib, path, trim=7, cap=0, chunk=0, max_pairs=1 << 20):
+        self.lib, self.max_pairs = lib, max_pairs
+        self.h = C.c_void_p()
+        lib.check(lib.L.lh_ingest_open(path.encode(), int(trim), int(cap), int(chunk), C.byref(self.h)))
+
+    def next(self, max_pairs=None):
+        p = C.POINTER(LhIngestBatch)()
+        self.lib.check(self.lib.L.lh_ingest_next(self.h, int(max_pairs or self.max_pairs), C.byref(p)))
+        return IngestBatch(self.lib, p)
+
+    def __iter__(self):
+        while True:
+            b = self.next()
+            if b.n_pairs == 0:
+                return
+            yield b
+            if b.at_eof:
+                return
+
+    def close(self):
+        if self.h:
+            self.lib.L.lh_ingest_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 EXPORTED_SYMBOLS = [
     "lh_last_error", "lh_device_count", "lh_opts_init", "lh_index_load", "lh_index_from_arrays", "lh_index_contigs", "lh_index_l_pac",
     "lh_index_resample_sa", "lh_index_sa_interval",
+    "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read",
 ]

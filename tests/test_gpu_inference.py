@@ -130,3 +130,27 @@ def test_two_contexts_concurrently(lib, oracle):
         t.join()
     for k in range(2):
         helpers.assert_same_result(out[k], seq[k], inference=True)
+
+
+def test_fastq_ingest_to_alignment(lib, oracle, tmp_path):
+    """the N2 reader feeding the hot path: a 9-line FASTQ written from synthetic reads, read back in batches of whole barcode
+    sets, gives the alignments of the same reads handed over as arrays (trim 7, md5 tie-break seeds, nt4 conversion)"""
+    from lariat_amd import synth
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=5, pairs=40, junk=0.03, seed=51)
+    p = tmp_path / "reads.fastq"
+    p.write_text(synth.to_fastq9(rs, trim_prefix=7))
+    direct = idx.context(rs.n_pairs).align_barcodes(helpers.batch_of(rs))
+    ctx = idx.context(rs.n_pairs)
+    r0 = 0
+    for b in lib.ingest(str(p), trim=7, max_pairs=90):
+        res = ctx.align_barcodes(b)
+        n = 2 * b.n_pairs
+        c0, c1 = int(direct.cand_off[r0]), int(direct.cand_off[r0 + n])
+        assert np.array_equal(res.cand_off, direct.cand_off[r0:r0 + n + 1] - c0)
+        for f in ("rid", "pos", "reversed", "score", "nm", "mapq", "active", "duplicate"):
+            assert np.array_equal(getattr(res, f), getattr(direct, f)[c0:c1]), f
+        r0 += n
+    assert r0 == 2 * rs.n_pairs
