@@ -268,6 +268,18 @@ void lh_ingest_close(lh_ingest* in);
 /* md5 of `n` bytes -> the tie-break seed lariat derives from a read name (LE u64 of digest[0:8]) */
 uint64_t lh_name_seed(const char* name, int64_t n);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * N1, first half — BAM record CONTENT: what go/src/inference/bamwriter.go puts into each record
+ * (DoDumpToBam :634-657 which alignments, in which order; AppendBam :286-568 flags incl. the `!is_proper && score-17 < 19`
+ * unmapping rule and its side effect on the mate's record, mate fields, TLEN, reverse-complemented SEQ/QUAL, HardClip
+ * :663-688 for the split record, and the tags RX QX TR TQ BC QT RG XS XC AC AS XM AM XT SA BX DM in the reference's
+ * order; the -debugTags set is not produced).  Host-only.  One text line per record, tab separated, BAM-native values:
+ *   QNAME FLAG RNAME|* POS0 MAPQ CIGAR|* RNEXT|* PNEXT0 TLEN SEQ|* QUAL|* TAG:TYPE:VALUE...
+ * (positions 0-based, -1 = none, as bam.Record holds them).  The binary encoding / BGZF / bucketing into files is the
+ * second half of N1.  `res` and `in` must describe the same batch; contig_names[rid] as from lh_index_contigs. */
+int lh_records_text(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, char** text, int64_t* text_len);
+void lh_records_free(char* text);
+
 #ifdef __cplusplus
 }
 #endif

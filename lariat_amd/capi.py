@@ -129,6 +129,20 @@ class Result:
             setattr(self, n, _view(getattr(r, n), self.n_reads, dt))
         self.counters = {n: int(getattr(r, n)) for n in _COUNTERS}
 
+    def as_struct(self):
+        """an LhResult whose pointers reference this object's arrays (kept alive on the struct)"""
+        r = LhResult()
+        r.n_reads, r.n_cand = self.n_reads, self.n_cand
+        keep = []
+        for name, ctype in LhResult._fields_:
+            if name in ("abi_version", "n_reads", "n_cand", "arena_") or name in _COUNTERS:
+                continue
+            arr = np.ascontiguousarray(getattr(self, name))
+            keep.append(arr)
+            setattr(r, name, arr.ctypes.data_as(ctype))
+        r._keep = keep
+        return r
+
     def cigar_of(self, i):
         return self.cigar[self.cigar_off[i]:self.cigar_off[i + 1]]
 
@@ -232,6 +246,10 @@ def _declare(L):
     L.lh_ingest_batch_free.restype = None
     L.lh_ingest_close.argtypes = [C.c_void_p]
     L.lh_ingest_close.restype = None
+    L.lh_records_text.argtypes = [C.POINTER(LhResult), C.POINTER(LhIngestBatch), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.lh_records_text.restype = C.c_int
+    L.lh_records_free.argtypes = [C.c_void_p]
+    L.lh_records_free.restype = None
     L.lh_name_seed.argtypes = [C.c_char_p, C.c_int64]
     L.lh_name_seed.restype = C.c_uint64
     L.lh_index_resample_sa.argtypes = [C.c_void_p, C.c_int32]
@@ -316,6 +334,16 @@ class Library:
     def ingest(self, path, trim=7, cap=0, chunk=0, max_pairs=1 << 20):
         """9-line FASTQ reader with the reference's work-unit rules (fastqreader/reader.go); host only"""
         return Ingest(self, path, trim, cap, chunk, max_pairs)
+
+    def records_text(self, result, ingest_batch, contig_names):
+        """BAM record content (bamwriter.go AppendBam) for one batch: `result` = Result of aligning `ingest_batch`"""
+        rs = result.as_struct()
+        names = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
+        txt, n = C.c_void_p(), C.c_int64()
+        self.check(self.L.lh_records_text(C.byref(rs), ingest_batch.ptr, len(contig_names), names, C.byref(txt), C.byref(n)))
+        out = C.string_at(txt, n.value).decode()
+        self.L.lh_records_free(txt)
+        return out
 
     def name_seed(self, name):
         if isinstance(name, str):
@@ -528,6 +556,7 @@ EXPORTED_SYMBOLS = [
     "lh_last_error", "lh_device_count", "lh_opts_init", "lh_index_load", "lh_index_from_arrays", "lh_index_contigs", "lh_index_l_pac",
     "lh_index_resample_sa", "lh_index_sa_interval",
     "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
+    "lh_records_text", "lh_records_free",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read",
 ]

@@ -154,3 +154,22 @@ def test_fastq_ingest_to_alignment(lib, oracle, tmp_path):
             assert np.array_equal(getattr(res, f), getattr(direct, f)[c0:c1]), f
         r0 += n
     assert r0 == 2 * rs.n_pairs
+
+
+def test_fastq_to_bam_records(lib, oracle, tmp_path):
+    """N2 -> K1..K8 -> N1: the BAM record content produced from the HIP result equals the one produced from the oracle's"""
+    from lariat_amd import synth
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = synth.make_reads(contigs, names, n_barcodes=4, pairs_per_barcode=50, seed=71, sub_hi=0.03, indel_rate=0.002, junk_frac=0.05)
+    p = tmp_path / "reads.fastq"
+    p.write_text(synth.to_fastq9(rs, trim_prefix=7))
+    ctx = idx.context(rs.n_pairs)
+    n = 0
+    for b in lib.ingest(str(p), trim=7, max_pairs=120):
+        got = lib.records_text(ctx.align_barcodes(b), b, names)
+        want = lib.records_text(oidx.align_barcodes(b, threads=8), b, names)
+        assert got == want
+        n += len(got.splitlines())
+    assert n >= 2 * rs.n_pairs

@@ -1,0 +1,95 @@
+"""N1 (first half) — BAM record content (lariat_amd/csrc/records.cpp) against the restatement of bamwriter.go's AppendBam in
+oracle/bam_oracle.py.  The alignments come from the CPU oracle, so this runs without a GPU; test_gpu_inference.py checks the
+same text on the HIP result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+from lariat_amd import capi, synth
+
+sys.path.insert(0, os.path.join(helpers.ROOT, "oracle"))
+import bam_oracle  # noqa: E402
+
+COLS = ("name", "rgid", "qual1", "qual2", "trim_bases", "trim_quals", "bc", "rawbc", "bcqual", "si", "siqual")
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    return capi.Library(ge.LIB)
+
+
+def write_fastq(tmp_path, rs, name="r.fastq"):
+    p = tmp_path / name
+    p.write_text(synth.to_fastq9(rs, trim_prefix=7))
+    return str(p)
+
+
+def oracle_text(res, b, contig_names):
+    cols = {c: b.column(c) for c in COLS}
+    return bam_oracle.records_text(res, cols, b.seq, b.seq_off, b.bc_pair_off, b.set_complete, contig_names)
+
+
+def test_record_content(hostlib, oracle, tmp_path):
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    # noisy reads, junk pairs (unmapped / improper records), a barcode below the RFA threshold, split candidates
+    rs = synth.make_reads(contigs, names, n_barcodes=5, pairs_per_barcode=40, seed=61, sub_lo=0.002, sub_hi=0.04, indel_rate=0.003, junk_frac=0.08)
+    for p in range(3, rs.n_pairs, 9):   # chimeric reads: the second half comes from another read's locus -> split (supplementary) records
+        a, d = 2 * p, 2 * ((p * 7 + 11) % rs.n_pairs)
+        la, ld = int(rs.seq_off[a + 1] - rs.seq_off[a]), int(rs.seq_off[d + 1] - rs.seq_off[d])
+        h = min(la, ld) // 2
+        rs.seq[rs.seq_off[a] + la - h:rs.seq_off[a] + la] = rs.seq[rs.seq_off[d] + ld - h:rs.seq_off[d] + ld]
+    path = write_fastq(tmp_path, rs)
+    n_rec = n_split = n_unmapped = 0
+    all_text = ""
+    for b in hostlib.ingest(path, trim=7, max_pairs=90):
+        res = oidx.align_barcodes(b, threads=4)
+        got = hostlib.records_text(res, b, names)
+        want = oracle_text(res, b, names)
+        assert got == want
+        all_text += got
+        lines = got.splitlines()
+        assert len(lines) >= 2 * b.n_pairs
+        for ln in lines:
+            f = ln.split("\t")
+            flag = int(f[1])
+            assert flag & 1 and bool(flag & 0x40) != bool(flag & 0x80)
+            n_split += bool(flag & 256)
+            n_unmapped += bool(flag & 4)
+            assert (f[2] == "*") == bool(flag & 4)
+            assert [t[:2] for t in f[11:13]] == ["RX", "QX"]
+        n_rec += len(lines)
+    assert n_rec > 0 and n_unmapped > 0 and n_split > 0
+    assert "SA:Z:" in all_text and "H" in "".join(ln.split("\t")[5] for ln in all_text.splitlines() if int(ln.split("\t")[1]) & 256)
+    # the tags lariat's downstream tools need
+    assert "BX:Z:" in all_text and "AS:i:" in all_text and "XS:i:" in all_text and "AM:Z:" in all_text
+
+
+def test_pair_flags_are_consistent(hostlib, oracle, tmp_path):
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = helpers.small_reads(names, contigs, n_barcodes=3, pairs=50, junk=0.05, seed=63)
+    path = write_fastq(tmp_path, rs)
+    for b in hostlib.ingest(path, trim=7):
+        res = oidx.align_barcodes(b, threads=4)
+        prim = {}
+        for ln in hostlib.records_text(res, b, names).splitlines():
+            f = ln.split("\t")
+            if not int(f[1]) & 256:
+                prim.setdefault(f[0], []).append(f)
+        for name, recs in prim.items():
+            assert len(recs) == 2
+            a, c = recs
+            fa, fc = int(a[1]), int(c[1])
+            assert bool(fa & 0x2) == bool(fc & 0x2)                      # proper pair on both or neither
+            if not fa & 0x8:
+                assert a[6] == c[2] and int(a[7]) == int(c[3])          # RNEXT/PNEXT point at the mate's record
+                assert bool(fa & 0x20) == bool(fc & 0x10)
+            if int(a[8]) != 0 or int(c[8]) != 0:
+                assert int(a[8]) == -int(c[8]) or 0 in (int(a[8]), int(c[8]))
