@@ -280,6 +280,20 @@ uint64_t lh_name_seed(const char* name, int64_t n);
 int lh_records_text(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, char** text, int64_t* text_len);
 void lh_records_free(char* text);
 
+/* N1, second half — the BAM container (bamwriter.go:46-191 CreateBAM / CreateBAMs, :281-284 AppendBams): BGZF-compressed
+ * BAM files in `dir`: bc_sorted_bam.bam (every record, input order) and the position-bucketed files
+ * %06d-<contig>_%010d_pos_bucketed.bam (contigs longer than position_chunk_size split every position_chunk_size bases,
+ * shorter contigs packed together up to that size) plus ZZZ_unmapped_pos_bucketed.bam for IsUnmapped records
+ * (lariat.go:143-148).  Header: @HD, @SQ per contig, one @RG per fully specified read group id
+ * (sample:library:gem_group:flowcell:lane), @PG lariat, and the three 10x_bam_to_fastq @CO lines when first_chunk != 0
+ * (only on the first file of each kind, as upstream).  Blocks are compressed by `threads` host threads (<= 0: all cores). */
+typedef struct lh_bam_writer lh_bam_writer;
+int lh_bam_open(const char* dir, int32_t n_contigs, const char* const* contig_names, const int64_t* contig_lens, const char* read_groups,
+                int32_t position_chunk_size, int32_t first_chunk, const char* command_line, int32_t threads, lh_bam_writer** out);
+/* appends the records of one batch (lh_records_text order) to bc_sorted_bam.bam and to their position bucket */
+int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_ingest_batch* in);
+int lh_bam_close(lh_bam_writer* w); /* flushes, writes the BGZF end-of-file blocks, frees w */
+
 #ifdef __cplusplus
 }
 #endif

@@ -248,6 +248,12 @@ def _declare(L):
     L.lh_ingest_close.restype = None
     L.lh_records_text.argtypes = [C.POINTER(LhResult), C.POINTER(LhIngestBatch), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.lh_records_text.restype = C.c_int
+    L.lh_bam_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), c_i64p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+    L.lh_bam_open.restype = C.c_int
+    L.lh_bam_append.argtypes = [C.c_void_p, C.POINTER(LhResult), C.POINTER(LhIngestBatch)]
+    L.lh_bam_append.restype = C.c_int
+    L.lh_bam_close.argtypes = [C.c_void_p]
+    L.lh_bam_close.restype = C.c_int
     L.lh_records_free.argtypes = [C.c_void_p]
     L.lh_records_free.restype = None
     L.lh_name_seed.argtypes = [C.c_char_p, C.c_int64]
@@ -334,6 +340,9 @@ class Library:
     def ingest(self, path, trim=7, cap=0, chunk=0, max_pairs=1 << 20):
         """9-line FASTQ reader with the reference's work-unit rules (fastqreader/reader.go); host only"""
         return Ingest(self, path, trim, cap, chunk, max_pairs)
+
+    def bam_writer(self, directory, contig_names, contig_lens, read_groups="", position_chunk_size=40000000, first_chunk=True, command_line="", threads=0):
+        return BamWriter(self, directory, contig_names, contig_lens, read_groups, position_chunk_size, first_chunk, command_line, threads)
 
     def records_text(self, result, ingest_batch, contig_names):
         """BAM record content (bamwriter.go AppendBam) for one batch: `result` = Result of aligning `ingest_batch`"""
@@ -518,6 +527,33 @@ class IngestBatch:
             pass
 
 
+class BamWriter:
+    """the reference's set of BAM files (bamwriter.go CreateBAMs): bc_sorted_bam.bam + position buckets + ZZZ_unmapped"""
+
+    def __init__(self, lib, directory, contig_names, contig_lens, read_groups, position_chunk_size, first_chunk, command_line, threads):
+        self.lib = lib
+        self.h = C.c_void_p()
+        names = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
+        lens = np.ascontiguousarray(contig_lens, dtype=np.int64)
+        lib.check(lib.L.lh_bam_open(directory.encode(), len(contig_names), names, lens.ctypes.data_as(c_i64p), read_groups.encode(), int(position_chunk_size),
+                                    int(bool(first_chunk)), command_line.encode(), int(threads), C.byref(self.h)))
+
+    def append(self, result, ingest_batch):
+        rs = result.as_struct()
+        self.lib.check(self.lib.L.lh_bam_append(self.h, C.byref(rs), ingest_batch.ptr))
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, None
+            self.lib.check(self.lib.L.lh_bam_close(h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Ingest:
     """9-line FASTQ reader (fastqreader/reader.go); iterate to get IngestBatch objects of whole barcode sets"""
 
@@ -556,7 +592,7 @@ EXPORTED_SYMBOLS = [
     "lh_last_error", "lh_device_count", "lh_opts_init", "lh_index_load", "lh_index_from_arrays", "lh_index_contigs", "lh_index_l_pac",
     "lh_index_resample_sa", "lh_index_sa_interval",
     "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
-    "lh_records_text", "lh_records_free",
+    "lh_records_text", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read",
 ]

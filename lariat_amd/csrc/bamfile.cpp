@@ -1,0 +1,337 @@
+// bamfile.cpp — N1, second half: BAM records and BGZF files (host only).
+// Layout of the outputs follows go/src/inference/bamwriter.go: CreateBAM (:46-130 header: references, read groups, program
+// line, @CO comments on first chunks), CreateBAMs (:139-191 file names and the packing of short contigs), AppendBams
+// (:281-284: every record goes to bc_sorted_bam.bam and to one position bucket, ZZZ_unmapped for IsUnmapped records).
+// The record fields come from lh_records_text (records.cpp), so the text and the binary form cannot drift apart; the
+// encoding itself is the SAM/BAM specification's (little-endian record, 4-bit bases, reg2bin, BGZF blocks of <= 0xff00
+// bytes with the BC extra field, empty end-of-file block).
+#include <zlib.h>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/lariat_hip.h"
+
+extern "C" int lh_set_error_(int code, const char* msg);
+
+namespace {
+
+const size_t BGZF_DATA = 0xff00;
+
+void put32(std::string& s, uint32_t v) { char b[4] = {(char)v, (char)(v >> 8), (char)(v >> 16), (char)(v >> 24)}; s.append(b, 4); }
+void put16(std::string& s, uint16_t v) { char b[2] = {(char)v, (char)(v >> 8)}; s.append(b, 2); }
+
+// one BGZF block (a gzip member with the BC extra subfield) around `n` bytes
+bool bgzf_block(const char* data, size_t n, int level, std::string& out) {
+    uint8_t buf[0x10000 + 64];
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = (Bytef*)data; zs.avail_in = (uInt)n;
+    zs.next_out = buf; zs.avail_out = sizeof buf;
+    int rc = deflate(&zs, Z_FINISH);
+    size_t clen = sizeof buf - zs.avail_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || clen + 26 > 0x10000) return false;
+    const uint8_t hdr[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
+    out.append((const char*)hdr, 12);
+    out += 'B'; out += 'C'; put16(out, 2); put16(out, (uint16_t)(clen + 25));
+    out.append((const char*)buf, clen);
+    put32(out, (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef*)data, (uInt)n));
+    put32(out, (uint32_t)n);
+    return true;
+}
+
+struct Out {
+    std::string path;
+    FILE* f = nullptr;
+    std::string pending;   // uncompressed BAM bytes not yet written
+};
+
+int reg2bin(int64_t beg, int64_t end) {   // SAM spec section 5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+}   // namespace
+
+struct lh_bam_writer {
+    std::vector<std::string> names;
+    std::vector<int64_t> lens;
+    std::map<std::string, int> rid_of;
+    std::vector<Out> outs;                       // 0 = bc_sorted, last = unmapped
+    std::vector<std::vector<int>> bucket;        // [contig][chunk] -> outs index
+    int64_t chunk = 40000000;
+    int level = Z_DEFAULT_COMPRESSION, threads = 1;
+    bool failed = false;
+};
+
+namespace {
+
+std::string header_bytes(const lh_bam_writer* w, const char* read_groups, bool comments, const char* cl) {
+    std::string text = "@HD\tVN:1.5\tSO:unknown\n";
+    for (size_t i = 0; i < w->names.size(); ++i) text += "@SQ\tSN:" + w->names[i] + "\tLN:" + std::to_string(w->lens[i]) + "\tAS:" + w->names[i] + "\tSP:human\n";
+    std::string rgs = read_groups ? read_groups : "";
+    size_t p = 0;
+    while (p <= rgs.size()) {   // strings.Split(read_groups, ","): one @RG per id with >= 5 ':' fields (bamwriter.go:77-104)
+        size_t q = rgs.find(',', p);
+        if (q == std::string::npos) q = rgs.size();
+        std::string id = rgs.substr(p, q - p);
+        std::vector<std::string> f;
+        size_t a = 0;
+        while (a <= id.size()) { size_t b = id.find(':', a); if (b == std::string::npos) b = id.size(); f.push_back(id.substr(a, b - a)); a = b + 1; }
+        if (!id.empty() && f.size() >= 5) text += "@RG\tID:" + id + "\tLB:" + f[1] + "." + f[2] + "\tPL:ILLUMINA\tPU:" + id + "\tSM:" + f[0] + "\n";
+        p = q + 1;
+    }
+    text += std::string("@PG\tID:lariat\tPN:longranger.lariat\tCL:") + (cl ? cl : "") + "\tVN:lariat_amd\n";
+    if (comments) text += "@CO\t10x_bam_to_fastq:R1(RX:QX,TR:TQ,SEQ:QUAL)\n@CO\t10x_bam_to_fastq:R2(SEQ:QUAL)\n@CO\t10x_bam_to_fastq:I1(BC:QT)\n";
+    std::string h = "BAM\1";
+    put32(h, (uint32_t)text.size());
+    h += text;
+    put32(h, (uint32_t)w->names.size());
+    for (size_t i = 0; i < w->names.size(); ++i) {
+        put32(h, (uint32_t)w->names[i].size() + 1);
+        h += w->names[i]; h += '\0';
+        put32(h, (uint32_t)w->lens[i]);
+    }
+    return h;
+}
+
+// one text line of lh_records_text -> one BAM record appended to `rec`; returns the position bucket (outs index)
+int encode(const lh_bam_writer* w, const char* line, size_t n, std::string& rec) {
+    std::vector<std::pair<const char*, size_t>> f;
+    const char* p = line;
+    const char* e = line + n;
+    while (p <= e) {
+        const char* t = (const char*)memchr(p, '\t', (size_t)(e - p));
+        if (!t) t = e;
+        f.emplace_back(p, (size_t)(t - p));
+        p = t + 1;
+    }
+    if (f.size() < 11) return -1;
+    auto str = [&](int i) { return std::string(f[i].first, f[i].second); };
+    auto ref_id = [&](int i) -> int32_t {
+        if (f[i].second == 1 && f[i].first[0] == '*') return -1;
+        auto it = w->rid_of.find(str(i));
+        return it == w->rid_of.end() ? -1 : it->second;
+    };
+    const int flag = atoi(str(1).c_str());
+    const int32_t rid = ref_id(2), mrid = ref_id(6);
+    const int64_t pos = atoll(str(3).c_str()), mpos = atoll(str(7).c_str()), tlen = atoll(str(8).c_str());
+    const int mapq = atoi(str(4).c_str());
+    std::vector<uint32_t> cig;
+    int64_t reflen = 0;
+    if (!(f[5].second == 1 && f[5].first[0] == '*')) {
+        uint32_t len = 0;
+        for (size_t i = 0; i < f[5].second; ++i) {
+            char ch = f[5].first[i];
+            if (ch >= '0' && ch <= '9') len = len * 10 + (uint32_t)(ch - '0');
+            else {
+                int op = ch == 'M' ? 0 : ch == 'I' ? 1 : ch == 'D' ? 2 : ch == 'N' ? 3 : ch == 'S' ? 4 : ch == 'H' ? 5 : 6;
+                cig.push_back(len << 4 | (uint32_t)op);
+                if (op == 0 || op == 2 || op == 3) reflen += len;
+                len = 0;
+            }
+        }
+    }
+    std::string seq = (f[9].second == 1 && f[9].first[0] == '*') ? std::string() : str(9);
+    std::string qual = (f[10].second == 1 && f[10].first[0] == '*') ? std::string() : str(10);
+    std::string body;
+    put32(body, (uint32_t)rid);
+    put32(body, (uint32_t)(int32_t)pos);
+    const uint32_t lname = (uint32_t)f[0].second + 1;
+    const int bin = pos < 0 ? 4680 : reg2bin(pos, pos + (reflen > 0 ? reflen : 1));
+    put32(body, (uint32_t)bin << 16 | (uint32_t)(mapq & 0xff) << 8 | (lname & 0xff));
+    put32(body, (uint32_t)flag << 16 | (uint32_t)(cig.size() & 0xffff));
+    put32(body, (uint32_t)seq.size());
+    put32(body, (uint32_t)mrid);
+    put32(body, (uint32_t)(int32_t)mpos);
+    put32(body, (uint32_t)(int32_t)tlen);
+    body.append(f[0].first, f[0].second); body += '\0';
+    for (uint32_t c : cig) put32(body, c);
+    static const char* code = "=ACMGRSVTWYHKDBN";
+    for (size_t i = 0; i < seq.size(); i += 2) {
+        auto nyb = [&](char ch) { const char* q = strchr(code, ch); return q ? (int)(q - code) : 15; };
+        int hi = nyb(seq[i]), lo = i + 1 < seq.size() ? nyb(seq[i + 1]) : 0;
+        body += (char)(hi << 4 | lo);
+    }
+    if (qual.size() == seq.size()) for (char ch : qual) body += (char)(ch - 33);   // fixQual
+    else body.append(seq.size(), (char)0xff);
+    for (size_t i = 11; i < f.size(); ++i) {   // TAG:TYPE:VALUE
+        if (f[i].second < 5) continue;
+        const char* t = f[i].first;
+        body += t[0]; body += t[1];
+        if (t[3] == 'i') { body += 'i'; put32(body, (uint32_t)(int32_t)atoll(std::string(t + 5, f[i].second - 5).c_str())); }
+        else { body += 'Z'; body.append(t + 5, f[i].second - 5); body += '\0'; }
+    }
+    put32(rec, (uint32_t)body.size());
+    rec += body;
+    // position bucket (AppendBams): IsUnmapped records carry pos -1 after AppendBam's edit
+    if (pos < 0 || rid < 0) return (int)w->outs.size() - 1;
+    size_t ch = (size_t)(pos / w->chunk);
+    const std::vector<int>& b = w->bucket[(size_t)rid];
+    return b[ch < b.size() ? ch : b.size() - 1];
+}
+
+// compresses and writes every complete block of every file (all of it when `all`), blocks in parallel
+bool flush(lh_bam_writer* w, bool all) {
+    struct Job { int out; size_t off, n; std::string z; bool ok = true; };
+    std::vector<Job> jobs;
+    for (size_t o = 0; o < w->outs.size(); ++o) {
+        const std::string& s = w->outs[o].pending;
+        size_t off = 0;
+        while (s.size() - off >= BGZF_DATA || (all && off < s.size())) {
+            size_t n = s.size() - off < BGZF_DATA ? s.size() - off : BGZF_DATA;
+            Job j; j.out = (int)o; j.off = off; j.n = n;
+            jobs.push_back(std::move(j));
+            off += n;
+        }
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i = next++; i < jobs.size(); i = next++) jobs[i].ok = bgzf_block(w->outs[(size_t)jobs[i].out].pending.data() + jobs[i].off, jobs[i].n, w->level, jobs[i].z);
+    };
+    int nt = w->threads < 1 ? 1 : w->threads;
+    if ((size_t)nt > jobs.size()) nt = (int)jobs.size();
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    std::vector<size_t> done(w->outs.size(), 0);
+    for (Job& j : jobs) {
+        if (!j.ok) return false;
+        Out& o = w->outs[(size_t)j.out];
+        if (fwrite(j.z.data(), 1, j.z.size(), o.f) != j.z.size()) return false;
+        done[(size_t)j.out] = j.off + j.n;
+    }
+    for (size_t o = 0; o < w->outs.size(); ++o) if (done[o]) w->outs[o].pending.erase(0, done[o]);
+    return true;
+}
+
+}   // namespace
+
+extern "C" int lh_bam_open(const char* dir, int32_t n_contigs, const char* const* contig_names, const int64_t* contig_lens, const char* read_groups,
+                           int32_t position_chunk_size, int32_t first_chunk, const char* command_line, int32_t threads, lh_bam_writer** out) {
+    if (!dir || !contig_names || !contig_lens || !out || n_contigs <= 0) return lh_set_error_(LH_E_ARG, "lh_bam_open: bad argument");
+    lh_bam_writer* w = new lh_bam_writer();
+    for (int i = 0; i < n_contigs; ++i) { w->names.push_back(contig_names[i]); w->lens.push_back(contig_lens[i]); w->rid_of[contig_names[i]] = i; }
+    if (position_chunk_size > 0) w->chunk = position_chunk_size;
+    w->threads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (const char* lv = getenv("LH_BAM_LEVEL")) w->level = atoi(lv);
+    std::vector<bool> co;   // which files carry the @CO lines
+    auto add = [&](const std::string& name, bool comments) { Out o; o.path = std::string(dir) + "/" + name; w->outs.push_back(o); co.push_back(comments); return (int)w->outs.size() - 1; };
+    add("bc_sorted_bam.bam", first_chunk != 0);
+    // CreateBAMs (bamwriter.go:139-191)
+    bool chr_first = first_chunk != 0;
+    int last = -1;
+    int64_t running = 0;
+    w->bucket.resize((size_t)n_contigs);
+    for (int i = 0; i < n_contigs; ++i) {
+        int64_t size = w->lens[(size_t)i];
+        int nchunks = (int)std::ceil((double)size / (double)w->chunk);
+        char idx[16];
+        snprintf(idx, sizeof idx, "%06d", i);
+        if (nchunks > 1) {
+            for (int c = 0; c < nchunks; ++c) {
+                char offs[24];
+                snprintf(offs, sizeof offs, "%010lld", (long long)c * (long long)w->chunk);
+                w->bucket[(size_t)i].push_back(add(std::string(idx) + "-" + w->names[(size_t)i] + "_" + offs + "_pos_bucketed.bam", chr_first));
+                chr_first = false;
+            }
+        } else {
+            if (running == 0 || running + size > w->chunk) {
+                last = add(std::string(idx) + "-" + w->names[(size_t)i] + "_0000000000_pos_bucketed.bam", chr_first);
+                chr_first = false;
+                running = size;
+            } else running += size;
+            w->bucket[(size_t)i].push_back(last);
+        }
+    }
+    add("ZZZ_unmapped_pos_bucketed.bam", first_chunk != 0);
+    for (size_t o = 0; o < w->outs.size(); ++o) {
+        w->outs[o].f = fopen(w->outs[o].path.c_str(), "wb");
+        if (!w->outs[o].f) {
+            std::string m = "cannot create " + w->outs[o].path;
+            for (Out& x : w->outs) if (x.f) fclose(x.f);
+            delete w;
+            return lh_set_error_(LH_E_IO, m.c_str());
+        }
+        w->outs[o].pending = header_bytes(w, read_groups, co[o], command_line);
+    }
+    *out = w;
+    return LH_OK;
+}
+
+extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_ingest_batch* in) {
+    if (!w || !res || !in) return lh_set_error_(LH_E_ARG, "lh_bam_append: null argument");
+    std::vector<const char*> names;
+    for (auto& s : w->names) names.push_back(s.c_str());
+    char* text = nullptr;
+    int64_t n = 0;
+    int rc = lh_records_text(res, in, (int32_t)names.size(), names.data(), &text, &n);
+    if (rc) return rc;
+    // records are encoded by several host threads over ranges of lines; per-file byte strings are joined in range order
+    int nt = w->threads < 1 ? 1 : w->threads;
+    if ((int64_t)nt > n / 65536 + 1) nt = (int)(n / 65536 + 1);
+    std::vector<const char*> cut((size_t)nt + 1);
+    cut[0] = text; cut[(size_t)nt] = text + n;
+    for (int t = 1; t < nt; ++t) {
+        const char* q = text + n * t / nt;
+        const char* nl = (const char*)memchr(q, '\n', (size_t)(text + n - q));
+        cut[(size_t)t] = nl ? nl + 1 : text + n;
+    }
+    std::vector<std::vector<std::string>> local((size_t)nt, std::vector<std::string>(w->outs.size()));
+    std::vector<int> bad((size_t)nt, 0);
+    auto work = [&](int t) {
+        std::string rec;
+        const char* p = cut[(size_t)t];
+        const char* e = cut[(size_t)t + 1];
+        while (p < e) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) nl = e;
+            rec.clear();
+            int b = encode(w, p, (size_t)(nl - p), rec);
+            if (b < 0) { bad[(size_t)t] = 1; return; }
+            local[(size_t)t][0] += rec;          // BarcodeSortedBam
+            local[(size_t)t][(size_t)b] += rec;  // its position bucket
+            p = nl + 1;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    for (int t = 0; t < nt; ++t) {
+        if (bad[(size_t)t]) { lh_records_free(text); return lh_set_error_(LH_E_ARG, "lh_bam_append: malformed record line"); }
+        for (size_t o = 0; o < w->outs.size(); ++o) w->outs[o].pending += local[(size_t)t][o];
+    }
+    lh_records_free(text);
+    if (!flush(w, false)) { w->failed = true; return lh_set_error_(LH_E_IO, "lh_bam_append: compression or write failed"); }
+    return LH_OK;
+}
+
+extern "C" int lh_bam_close(lh_bam_writer* w) {
+    if (!w) return LH_OK;
+    bool ok = !w->failed && flush(w, true);
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (Out& o : w->outs)
+        if (o.f) {
+            if (fwrite(eof_block, 1, 28, o.f) != 28) ok = false;
+            if (fclose(o.f)) ok = false;
+        }
+    delete w;
+    return ok ? LH_OK : lh_set_error_(LH_E_IO, "lh_bam_close: write failed");
+}

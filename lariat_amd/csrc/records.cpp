@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/lariat_hip.h"
 
@@ -44,7 +45,7 @@ const char* contig(const Ctx& c, int64_t a) {
 void put_int(std::string& s, long long v) { char b[32]; snprintf(b, sizeof b, "%lld", v); s += b; }
 
 // AppendBam(aln, primary, debugTags = false, attach_bx)
-void append_bam(Ctx& c, int64_t read, int64_t aln, int64_t primary, bool attach_bx) {
+void append_bam(Ctx& c, std::string& o, int64_t read, int64_t aln, int64_t primary, bool attach_bx) {
     const lh_result* r = c.r;
     const lh_ingest_batch* in = c.in;
     const int64_t pair = read >> 1;
@@ -108,7 +109,6 @@ void append_bam(Ctx& c, int64_t read, int64_t aln, int64_t primary, bool attach_
         seq = seq.substr(start, end - start);
         qual = qual.substr(qs, qe > qs ? qe - qs : 0);
     }
-    std::string& o = c.out;
     o += col(in->name, in->name_off, pair); o += '\t';
     put_int(o, flags); o += '\t';
     o += ref ? ref : "*"; o += '\t';
@@ -183,16 +183,38 @@ extern "C" int lh_records_text(const lh_result* res, const lh_ingest_batch* in, 
     c.r = res; c.in = in; c.n_contigs = n_contigs; c.names = contig_names;
     c.pos.assign(res->pos, res->pos + res->n_cand);
     c.mapq.assign(res->mapq, res->mapq + res->n_cand);
-    c.out.reserve((size_t)res->n_reads * 600);
-    int32_t set = 0;
-    for (int64_t read = 0; read < res->n_reads; ++read) {   // DoDumpToBam: reads in read_id order, the active alignment then its split
-        while (set + 1 < in->n_sets && (read >> 1) >= in->batch.bc_pair_off[set + 1]) ++set;
-        const bool attach_bx = in->set_complete[set] != 0;   // Data.attach_bx = WorkUnit.unique_barcode (lariat.go:493,546)
-        const int64_t a = res->active_idx[read];
-        if (a < 0) return lh_set_error_(LH_E_ARG, "lh_records_text: a read has no active alignment (inference was not run?)");
-        append_bam(c, read, a, a, attach_bx);
-        if (res->split_idx[read] >= 0) append_bam(c, read, res->split_idx[read], a, attach_bx);
-    }
+    for (int64_t read = 0; read < res->n_reads; ++read)
+        if (res->active_idx[read] < 0) return lh_set_error_(LH_E_ARG, "lh_records_text: a read has no active alignment (inference was not run?)");
+    // AppendBam's edits stay inside a pair (an alignment, its mate, their splits), so pairs are independent: ranges of pairs
+    // are rendered by several host threads and concatenated in order.
+    const int64_t n_pairs = in->batch.n_pairs;
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("LH_HOST_THREADS")) nt = atoi(e);
+    if (nt < 1) nt = 1;
+    if ((int64_t)nt > (n_pairs + 255) / 256) nt = (int)((n_pairs + 255) / 256);
+    if (nt < 1) nt = 1;
+    std::vector<std::string> part((size_t)nt);
+    auto work = [&](int t) {
+        const int64_t p0 = n_pairs * t / nt, p1 = n_pairs * (t + 1) / nt;
+        std::string& o = part[(size_t)t];
+        o.reserve((size_t)(p1 - p0) * 1300);
+        int32_t set = 0;
+        for (int64_t read = 2 * p0; read < 2 * p1; ++read) {   // DoDumpToBam: reads in read_id order, the active alignment then its split
+            while (set + 1 < in->n_sets && (read >> 1) >= in->batch.bc_pair_off[set + 1]) ++set;
+            const bool attach_bx = in->set_complete[set] != 0;   // Data.attach_bx = WorkUnit.unique_barcode (lariat.go:493,546)
+            const int64_t a = res->active_idx[read];
+            append_bam(c, o, read, a, a, attach_bx);
+            if (res->split_idx[read] >= 0) append_bam(c, o, read, res->split_idx[read], a, attach_bx);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    size_t total = 0;
+    for (auto& o : part) total += o.size();
+    c.out.reserve(total);
+    for (auto& o : part) c.out += o;
     char* buf = (char*)malloc(c.out.size() + 1);
     if (!buf) return lh_set_error_(LH_E_ARG, "out of memory");
     memcpy(buf, c.out.data(), c.out.size());

@@ -93,3 +93,55 @@ def test_pair_flags_are_consistent(hostlib, oracle, tmp_path):
                 assert bool(fa & 0x20) == bool(fc & 0x10)
             if int(a[8]) != 0 or int(c[8]) != 0:
                 assert int(a[8]) == -int(c[8]) or 0 in (int(a[8]), int(c[8]))
+
+
+def test_bam_files_round_trip(hostlib, oracle, tmp_path):
+    """the container: every record line comes back from bc_sorted_bam.bam, each record sits in exactly one position bucket
+    chosen as AppendBams does, file names and short-contig packing follow CreateBAMs, BGZF blocks are well formed"""
+    import bam_reader
+    names, contigs = helpers.small_genome()   # 300 kb, 200 kb, 100 kb
+    lens = [len(c) for c in contigs]
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = synth.make_reads(contigs, names, n_barcodes=4, pairs_per_barcode=60, seed=67, sub_hi=0.03, indel_rate=0.002, junk_frac=0.06)
+    path = write_fastq(tmp_path, rs)
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    chunk = 150000   # chrA (300 kb) and chrB (200 kb) split into two files each, chrC (100 kb) gets one
+    w = hostlib.bam_writer(str(outdir), names, lens, read_groups="s:lib:1:fc:1,bad", position_chunk_size=chunk, first_chunk=True, command_line="lariat_amd test", threads=3)
+    want = []
+    for b in hostlib.ingest(path, trim=7, max_pairs=100):
+        res = oidx.align_barcodes(b, threads=4)
+        want += hostlib.records_text(res, b, names).splitlines()
+        w.append(res, b)
+    w.close()
+    files = sorted(os.listdir(outdir))
+    assert files == ["000000-chrA_0000000000_pos_bucketed.bam", "000000-chrA_0000150000_pos_bucketed.bam", "000001-chrB_0000000000_pos_bucketed.bam",
+                     "000001-chrB_0000150000_pos_bucketed.bam", "000002-chrC_0000000000_pos_bucketed.bam", "ZZZ_unmapped_pos_bucketed.bam", "bc_sorted_bam.bam"]
+    text, refs, lines = bam_reader.read_bam(str(outdir / "bc_sorted_bam.bam"))
+    assert refs == list(zip(names, lens))
+    assert [ln for ln, _ in lines] == want
+    assert text.count("@SQ") == 3 and "@RG\tID:s:lib:1:fc:1\tLB:lib.1\tPL:ILLUMINA\tPU:s:lib:1:fc:1\tSM:s" in text and "ID:bad" not in text
+    assert "@PG\tID:lariat\tPN:longranger.lariat\tCL:lariat_amd test" in text and text.count("@CO") == 3
+    seen = []
+    for f in files[:-1]:
+        t, _, ls = bam_reader.read_bam(str(outdir / f))
+        for ln, bin_ in ls:
+            fld = ln.split("\t")
+            if f.startswith("ZZZ"):
+                assert int(fld[3]) == -1 and bin_ == 4680
+            else:
+                contig, off = f.split("-", 1)[1].rsplit("_", 3)[0], int(f.split("_")[-3])
+                assert fld[2] == contig and off <= int(fld[3]) < off + chunk
+            seen.append(ln)
+        assert (t.count("@CO") == 3) == (f.startswith("000000-chrA_0000000000") or f.startswith("ZZZ"))
+    assert sorted(seen) == sorted(want)
+
+
+def test_bam_short_contig_packing(hostlib, tmp_path):
+    """CreateBAMs packs consecutive short contigs into one file until position_chunk_size would be exceeded"""
+    d = tmp_path / "o"
+    d.mkdir()
+    w = hostlib.bam_writer(str(d), ["a", "b", "c", "d", "e"], [40, 50, 30, 250, 20], position_chunk_size=100, first_chunk=False)
+    w.close()
+    assert sorted(os.listdir(d)) == ["000000-a_0000000000_pos_bucketed.bam", "000002-c_0000000000_pos_bucketed.bam", "000003-d_0000000000_pos_bucketed.bam",
+                                     "000003-d_0000000100_pos_bucketed.bam", "000003-d_0000000200_pos_bucketed.bam", "ZZZ_unmapped_pos_bucketed.bam", "bc_sorted_bam.bam"]
