@@ -49,11 +49,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # LH_BENCH_SHARE_GPU=1 (development aid for 1-GPU boxes): all ranks use device 0 and the control collectives run over gloo,
+    # which exercises everything of the N>1 path except RCCL itself
+    share = os.environ.get("LH_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -72,7 +80,7 @@ def main():
     names = ["chr20"]
     os.makedirs(a.index_dir, exist_ok=True)
     prefix = os.path.join(a.index_dir, "chr20like_%d.fa" % glen)
-    if local_rank == 0 and not os.path.exists(prefix + ".done"):
+    if (rank == 0 if share else local_rank == 0) and not os.path.exists(prefix + ".done"):
         lib.index_build(prefix, names, contigs, threads=0)
         open(prefix + ".done", "w").write("ok\n")
     if dist is not None:
@@ -113,7 +121,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
