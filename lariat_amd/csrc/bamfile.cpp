@@ -7,6 +7,7 @@
 // bytes with the BC extra field, empty end-of-file block).
 #include <zlib.h>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -275,12 +276,16 @@ extern "C" int lh_bam_open(const char* dir, int32_t n_contigs, const char* const
 
 extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_ingest_batch* in) {
     if (!w || !res || !in) return lh_set_error_(LH_E_ARG, "lh_bam_append: null argument");
+    const bool timing = getenv("LH_BAM_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     std::vector<const char*> names;
     for (auto& s : w->names) names.push_back(s.c_str());
     char* text = nullptr;
     int64_t n = 0;
     int rc = lh_records_text(res, in, (int32_t)names.size(), names.data(), &text, &n);
     if (rc) return rc;
+    double t1 = now();
     // records are encoded by several host threads over ranges of lines; per-file byte strings are joined in range order
     int nt = w->threads < 1 ? 1 : w->threads;
     if ((int64_t)nt > n / 65536 + 1) nt = (int)(n / 65536 + 1);
@@ -314,12 +319,15 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
         work(0);
         for (auto& t : th) t.join();
     }
+    double t2 = now();
     for (int t = 0; t < nt; ++t) {
         if (bad[(size_t)t]) { lh_records_free(text); return lh_set_error_(LH_E_ARG, "lh_bam_append: malformed record line"); }
         for (size_t o = 0; o < w->outs.size(); ++o) w->outs[o].pending += local[(size_t)t][o];
     }
     lh_records_free(text);
+    double t3 = now();
     if (!flush(w, false)) { w->failed = true; return lh_set_error_(LH_E_IO, "lh_bam_append: compression or write failed"); }
+    if (timing) fprintf(stderr, "[lh_bam_append] text %.3f s, encode %.3f s, join %.3f s, compress+write %.3f s (%d threads)\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, nt);
     return LH_OK;
 }
 

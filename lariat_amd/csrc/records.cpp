@@ -42,7 +42,14 @@ const char* contig(const Ctx& c, int64_t a) {
     return (rid >= 0 && rid < c.n_contigs) ? c.names[rid] : nullptr;
 }
 
-void put_int(std::string& s, long long v) { char b[32]; snprintf(b, sizeof b, "%lld", v); s += b; }
+void put_int(std::string& s, long long v) {   // decimal, without the cost of snprintf (a record holds ~60 numbers)
+    char b[24];
+    int n = 0;
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) b[n++] = '-';
+    while (n) s += b[--n];
+}
 
 // AppendBam(aln, primary, debugTags = false, attach_bx)
 void append_bam(Ctx& c, std::string& o, int64_t read, int64_t aln, int64_t primary, bool attach_bx) {
