@@ -20,6 +20,7 @@
 #include "../../include/lariat_hip.h"
 
 extern "C" int lh_set_error_(int code, const char* msg);
+int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, std::vector<std::string>& part);
 
 namespace {
 
@@ -29,16 +30,21 @@ void put32(std::string& s, uint32_t v) { char b[4] = {(char)v, (char)(v >> 8), (
 void put16(std::string& s, uint16_t v) { char b[2] = {(char)v, (char)(v >> 8)}; s.append(b, 2); }
 
 // one BGZF block (a gzip member with the BC extra subfield) around `n` bytes
-bool bgzf_block(const char* data, size_t n, int level, std::string& out) {
-    uint8_t buf[0x10000 + 64];
+struct Deflater {   // one per compressing thread: deflateInit2 allocates ~256 KB, too much to repeat per 64-KB block
     z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    bool ok;
+    explicit Deflater(int level) { memset(&zs, 0, sizeof zs); ok = deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK; }
+    ~Deflater() { if (ok) deflateEnd(&zs); }
+};
+
+bool bgzf_block(Deflater& d, const char* data, size_t n, std::string& out) {
+    uint8_t buf[0x10000 + 64];
+    if (!d.ok || deflateReset(&d.zs) != Z_OK) return false;
+    z_stream& zs = d.zs;
     zs.next_in = (Bytef*)data; zs.avail_in = (uInt)n;
     zs.next_out = buf; zs.avail_out = sizeof buf;
     int rc = deflate(&zs, Z_FINISH);
     size_t clen = sizeof buf - zs.avail_out;
-    deflateEnd(&zs);
     if (rc != Z_STREAM_END || clen + 26 > 0x10000) return false;
     const uint8_t hdr[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
     out.append((const char*)hdr, 12);
@@ -201,7 +207,8 @@ bool flush(lh_bam_writer* w, bool all) {
     }
     std::atomic<size_t> next{0};
     auto work = [&]() {
-        for (size_t i = next++; i < jobs.size(); i = next++) jobs[i].ok = bgzf_block(w->outs[(size_t)jobs[i].out].pending.data() + jobs[i].off, jobs[i].n, w->level, jobs[i].z);
+        Deflater d(w->level);
+        for (size_t i = next++; i < jobs.size(); i = next++) jobs[i].ok = bgzf_block(d, w->outs[(size_t)jobs[i].out].pending.data() + jobs[i].off, jobs[i].n, jobs[i].z);
     };
     int nt = w->threads < 1 ? 1 : w->threads;
     if ((size_t)nt > jobs.size()) nt = (int)jobs.size();
@@ -281,27 +288,18 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
     double t0 = now();
     std::vector<const char*> names;
     for (auto& s : w->names) names.push_back(s.c_str());
-    char* text = nullptr;
-    int64_t n = 0;
-    int rc = lh_records_text(res, in, (int32_t)names.size(), names.data(), &text, &n);
+    std::vector<std::string> part;
+    int rc = lh_records_parts_(res, in, (int32_t)names.size(), names.data(), part);
     if (rc) return rc;
     double t1 = now();
-    // records are encoded by several host threads over ranges of lines; per-file byte strings are joined in range order
-    int nt = w->threads < 1 ? 1 : w->threads;
-    if ((int64_t)nt > n / 65536 + 1) nt = (int)(n / 65536 + 1);
-    std::vector<const char*> cut((size_t)nt + 1);
-    cut[0] = text; cut[(size_t)nt] = text + n;
-    for (int t = 1; t < nt; ++t) {
-        const char* q = text + n * t / nt;
-        const char* nl = (const char*)memchr(q, '\n', (size_t)(text + n - q));
-        cut[(size_t)t] = nl ? nl + 1 : text + n;
-    }
+    // every block of lines (one per range of pairs) is encoded by its own host thread; per-file byte strings are joined in order
+    const int nt = (int)part.size();
     std::vector<std::vector<std::string>> local((size_t)nt, std::vector<std::string>(w->outs.size()));
     std::vector<int> bad((size_t)nt, 0);
     auto work = [&](int t) {
         std::string rec;
-        const char* p = cut[(size_t)t];
-        const char* e = cut[(size_t)t + 1];
+        const char* p = part[(size_t)t].data();
+        const char* e = p + part[(size_t)t].size();
         while (p < e) {
             const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
             if (!nl) nl = e;
@@ -321,10 +319,9 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
     }
     double t2 = now();
     for (int t = 0; t < nt; ++t) {
-        if (bad[(size_t)t]) { lh_records_free(text); return lh_set_error_(LH_E_ARG, "lh_bam_append: malformed record line"); }
+        if (bad[(size_t)t]) return lh_set_error_(LH_E_ARG, "lh_bam_append: malformed record line");
         for (size_t o = 0; o < w->outs.size(); ++o) w->outs[o].pending += local[(size_t)t][o];
     }
-    lh_records_free(text);
     double t3 = now();
     if (!flush(w, false)) { w->failed = true; return lh_set_error_(LH_E_IO, "lh_bam_append: compression or write failed"); }
     if (timing) fprintf(stderr, "[lh_bam_append] text %.3f s, encode %.3f s, join %.3f s, compress+write %.3f s (%d threads)\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, nt);

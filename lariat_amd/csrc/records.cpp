@@ -183,8 +183,9 @@ void append_bam(Ctx& c, std::string& o, int64_t read, int64_t aln, int64_t prima
 
 }   // namespace
 
-extern "C" int lh_records_text(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, char** text, int64_t* text_len) {
-    if (!res || !in || !text || !text_len) return lh_set_error_(LH_E_ARG, "lh_records_text: null argument");
+// the records of a batch as one text block per range of pairs (used as is by bamfile.cpp, joined by lh_records_text)
+int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, std::vector<std::string>& part) {
+    if (!res || !in) return lh_set_error_(LH_E_ARG, "lh_records_text: null argument");
     if (res->n_reads != 2 * in->batch.n_pairs) return lh_set_error_(LH_E_ARG, "lh_records_text: result and batch describe different reads");
     Ctx c;
     c.r = res; c.in = in; c.n_contigs = n_contigs; c.names = contig_names;
@@ -200,7 +201,7 @@ extern "C" int lh_records_text(const lh_result* res, const lh_ingest_batch* in, 
     if (nt < 1) nt = 1;
     if ((int64_t)nt > (n_pairs + 255) / 256) nt = (int)((n_pairs + 255) / 256);
     if (nt < 1) nt = 1;
-    std::vector<std::string> part((size_t)nt);
+    part.assign((size_t)nt, std::string());
     auto work = [&](int t) {
         const int64_t p0 = n_pairs * t / nt, p1 = n_pairs * (t + 1) / nt;
         std::string& o = part[(size_t)t];
@@ -218,15 +219,22 @@ extern "C" int lh_records_text(const lh_result* res, const lh_ingest_batch* in, 
     for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
     work(0);
     for (auto& t : th) t.join();
+    return LH_OK;
+}
+
+extern "C" int lh_records_text(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, char** text, int64_t* text_len) {
+    if (!text || !text_len) return lh_set_error_(LH_E_ARG, "lh_records_text: null argument");
+    std::vector<std::string> part;
+    int rc = lh_records_parts_(res, in, n_contigs, contig_names, part);
+    if (rc) return rc;
     size_t total = 0;
     for (auto& o : part) total += o.size();
-    c.out.reserve(total);
-    for (auto& o : part) c.out += o;
-    char* buf = (char*)malloc(c.out.size() + 1);
+    char* buf = (char*)malloc(total + 1);
     if (!buf) return lh_set_error_(LH_E_ARG, "out of memory");
-    memcpy(buf, c.out.data(), c.out.size());
-    buf[c.out.size()] = 0;
-    *text = buf; *text_len = (int64_t)c.out.size();
+    size_t at = 0;
+    for (auto& o : part) { memcpy(buf + at, o.data(), o.size()); at += o.size(); }
+    buf[total] = 0;
+    *text = buf; *text_len = (int64_t)total;
     return LH_OK;
 }
 
