@@ -97,3 +97,29 @@ def test_long_noisy_reads(lib, oracle):
     helpers.assert_same_result(res, ores, inference=True)
     for k in ("n_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"):
         assert res.counters[k] == ores.counters[k], k
+
+
+def test_pools_grow_on_demand(lib, oracle):
+    """a repeat-dense 62 kb genome gives far more than the 32 seeds / 6 candidates per read the pools start with: the seed,
+    region and candidate pools are re-sized from the device-side totals instead of failing (found by tools/fuzz_gpu.py, seed 2892)"""
+    from lariat_amd import synth
+    seed = 2892
+    rng = np.random.default_rng(seed)
+    ncont = int(rng.integers(1, 5))
+    lens = [int(rng.integers(60000, 400000)) for _ in range(ncont)]
+    names = ["c%d" % i for i in range(ncont)]
+    contigs = synth.make_genome(lens, seed=seed, n_dup=int(rng.integers(0, 25)), dup_len=int(rng.integers(500, 6000)), dup_identity=float(rng.uniform(0.97, 1.0)),
+                                n_rep_family=int(rng.integers(0, 6)), rep_len=int(rng.integers(100, 400)), rep_copies=int(rng.integers(5, 60)))
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    if rng.random() < 0.3:
+        idx.resample_sa(int(rng.choice([2, 8, 32])))
+    l1, l2 = int(rng.integers(50, 240)), int(rng.integers(50, 240))
+    rs = synth.make_reads(contigs, names, n_barcodes=int(rng.integers(1, 12)), pairs_per_barcode=int(rng.integers(1, 120)), seed=seed + 7, len1=l1, len2=l2,
+                          sub_lo=0.0, sub_hi=float(rng.uniform(0.0, 0.06)), indel_rate=float(rng.choice([0.0, 0.001, 0.01])), junk_frac=float(rng.choice([0.0, 0.05, 0.3])))
+    b = helpers.batch_of(rs)
+    ctx = idx.context(rs.n_pairs)
+    d = ctx.stage_dump(b)
+    assert d.seed_off[-1] > 32 * 2 * rs.n_pairs   # really beyond the initial pool
+    helpers.assert_same_dump(d, oidx.stage_dump(b), helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b, threads=8), inference=True)

@@ -1,0 +1,48 @@
+"""differential fuzzing of the HIP path against the oracle over random genomes / read sets / options (development aid; the
+pytest suite holds the fixed cases).  Stops at the first difference and prints the seed that reproduces it."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import helpers, oracle_py
+from lariat_amd import capi, synth
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+lib = capi.load_library()
+oracle = oracle_py.load()
+t_end = time.time() + budget
+it = 0
+while time.time() < t_end:
+    seed = seed0 + it
+    rng = np.random.default_rng(seed)
+    ncont = int(rng.integers(1, 5))
+    lens = [int(rng.integers(60000, 400000)) for _ in range(ncont)]
+    names = ["c%d" % i for i in range(ncont)]
+    contigs = synth.make_genome(lens, seed=seed, n_dup=int(rng.integers(0, 25)), dup_len=int(rng.integers(500, 6000)), dup_identity=float(rng.uniform(0.97, 1.0)),
+                                n_rep_family=int(rng.integers(0, 6)), rep_len=int(rng.integers(100, 400)), rep_copies=int(rng.integers(5, 60)))
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    if rng.random() < 0.3:
+        idx.resample_sa(int(rng.choice([2, 8, 32])))
+    l1, l2 = int(rng.integers(50, 240)), int(rng.integers(50, 240))
+    rs = synth.make_reads(contigs, names, n_barcodes=int(rng.integers(1, 12)), pairs_per_barcode=int(rng.integers(1, 120)), seed=seed + 7, len1=l1, len2=l2,
+                          sub_lo=0.0, sub_hi=float(rng.uniform(0.0, 0.06)), indel_rate=float(rng.choice([0.0, 0.001, 0.01])), junk_frac=float(rng.choice([0.0, 0.05, 0.3])))
+    if rng.random() < 0.5:   # sprinkle ambiguous bases
+        k = rng.integers(0, len(rs.seq), size=max(1, len(rs.seq) // int(rng.integers(20, 400))))
+        rs.seq[k] = 4
+    rfa = (rng.random(len(rs.bc_pair_off) - 1) < 0.8).astype(np.uint8)
+    b = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed, bc_do_rfa=rfa)
+    kw = {}
+    if rng.random() < 0.3:
+        kw = dict(b=int(rng.integers(2, 7)), o_del=int(rng.integers(3, 9)), o_ins=int(rng.integers(3, 9)), e_del=int(rng.integers(1, 3)), e_ins=int(rng.integers(1, 3)),
+                  w=int(rng.choice([20, 100])), zdrop=int(rng.choice([50, 100])), min_seed_len=int(rng.choice([15, 19, 25])))
+    try:
+        ctx = idx.context(rs.n_pairs)
+        helpers.assert_same_dump(ctx.stage_dump(b, lib.opts(**kw)), oidx.stage_dump(b, oracle.opts(**kw)), helpers.DUMP_FRONT + helpers.DUMP_REGS)
+        helpers.assert_same_result(ctx.align_barcodes(b, lib.opts(**kw)), oidx.align_barcodes(b, oracle.opts(**kw), threads=16), inference=True)
+    except Exception as e:
+        print("DIFF at seed %d (contigs %s, reads %dx%d/%d, opts %s): %s" % (seed, lens, l1, l2, rs.n_pairs, kw, str(e)[:600]), flush=True)
+        sys.exit(1)
+    it += 1
+print("fuzz ok: %d cases from seed %d in %.0f s" % (it, seed0, budget))
