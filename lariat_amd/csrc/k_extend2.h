@@ -15,7 +15,8 @@
 
 // primary buckets: 0 = reads with many chains / seeds (handed to the wave-per-read kernel, which is parallel over seeds and
 // columns); 1..32 = by the length of the LONGER side of the first extension, longest first: 1..16 need 256 LDS columns,
-// 17..24 128, 25..32 64.  Each primary bucket has LH_EXT_SUB sub-buckets by the length of the SHORTER side, so that the
+// 17..24 128, 25..32 64 (the LDS footprint sets how many waves a CU holds: 2 / 5 / 10).  Finer classes (96, 32) were measured
+// slower: every class is a launch with its own tail, and more reads outgrow a tighter class and are redone.  Each primary bucket has LH_EXT_SUB sub-buckets by the length of the SHORTER side, so that the
 // lanes of a wave sweep similar windows on both sides of the seed.
 #define LH_EXT_PRIMARY 33
 #define LH_EXT_SUB 8
@@ -160,8 +161,8 @@ struct LaneTgt {   // the reference bases of an extension, read 16 at a time fro
 #define EH_Q(v) ((int)((v) >> 29))
 #define EH_PACK(q, e, h) ((uint32_t)(q) << 29 | (uint32_t)(e) << 16 | (uint32_t)(h))
 
-// ksw_extend2 for one lane.  Column j's query base is qn-nibble (qoff + qstep*j); row i's target base is tg.base(i).
-__device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint32_t* qn, uint32_t* ehl, int lane, int qoff, int qstep, int qlen, LaneTgt& tg, int tlen, int w,
+// ksw_extend2 for one lane.  Column j's query base is q[qoff + qstep*j]; row i's target base is tg.base(i).
+__device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t* q, uint32_t* ehl, int lane, int qoff, int qstep, int qlen, LaneTgt& tg, int tlen, int w,
                                                    int end_bonus, int zdrop, int h0, u64* cells) {
     const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -175,8 +176,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint32_
             else v = hprev > e_ins ? hprev - e_ins : 0;
             if (j >= 2 && hprev == 0) v = 0;
             hprev = v;
-            int qi = qoff + qstep * j;
-            int qv = j < qlen ? (int)((qn[(qi >> 3) * 64 + lane] >> ((qi & 7) * 4)) & 0xF) : 4;
+            int qv = j < qlen ? (int)q[qoff + qstep * j] : 4;   // the read's nt4 bytes, once per extension
             EHW(j) = EH_PACK(qv > 4 ? 4 : qv, 0, v);
         }
     }
@@ -257,7 +257,6 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                                                      const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
                                                      const int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, const i64* __restrict__ chain_rmax,
                                                      const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs, DCounters* __restrict__ ctr) {
-    __shared__ uint32_t qn[32 * 64];
     __shared__ uint32_t ehl[EHW_ * 64];
     const int lane = LANE();
     int first = range[0], last = range[1];
@@ -267,21 +266,7 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
     i64 off = 0;
     int l_query = 0;
     if (r >= 0) { off = seq_off[r]; l_query = (int)(seq_off[r + 1] - off); if (l_query > LH_MAXLEN) l_query = 0; }
-    for (int L = 0; L < 64; ++L) {   // the wave stages the 64 queries, 4 bits per base
-        i64 offL = shfl_i64(off, L);
-        int lnL = wave_readlane(l_query, L);
-        uint32_t wv = 0;
-        if (4 * lane < lnL) __builtin_memcpy(&wv, seq + offL + 4 * lane, 4);
-        uint32_t nb16 = 0;
-        for (int b = 0; b < 4; ++b) {
-            uint32_t v = (wv >> (8 * b)) & 0xff;
-            v = (4 * lane + b < lnL && v < 4) ? v : 4;
-            nb16 |= v << (4 * b);
-        }
-        uint32_t other = __shfl_xor(nb16, 1);
-        if (!(lane & 1)) qn[(lane >> 1) * 64 + L] = nb16 | other << 16;
-    }
-    EMU_SYNC();
+    const uint8_t* q = seq + off;
     u64 cells = 0;
     if (r >= 0) {
         i64 base = seed_off[r];
@@ -348,7 +333,7 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                         aw = o.w << i;
                         LaneTgt tg;
                         tg.init(ix, tc0, tstep);
-                        e = lane_ksw_extend2(o, qn, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells);
+                        e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells);
                         a.score = e.score;
                         if (a.score == prev || e.max_off < (aw >> 1) + (aw >> 2)) break;
                     }

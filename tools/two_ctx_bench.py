@@ -19,7 +19,11 @@ for s in subs:
 o = lib.opts()
 for rep in range(3):
     t = time.perf_counter()
-    th = [threading.Thread(target=c.align_resident, args=(o,)) for c in ctxs]
+    skew = float(os.environ.get("SKEW_MS", "0")) * 1e-3
+    def run(k):
+        if k: time.sleep(skew * k)
+        ctxs[k].align_resident(o)
+    th = [threading.Thread(target=run, args=(k,)) for k in range(len(ctxs))]
     [x.start() for x in th]; [x.join() for x in th]
     dt = time.perf_counter() - t
     print("parts=%d rep %d: %.1f ms  %.2f M pairs/s" % (parts, rep, dt * 1e3, rs.n_pairs / dt / 1e6), flush=True)
