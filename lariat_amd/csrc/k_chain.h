@@ -196,6 +196,8 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
 // klib's ks_introsort for n <= 16: one median-of-3 partition step, then insertion sort (ranges of <= 16 elements are
 // never pushed on its stack).  Per-lane control flow: callable from lane-per-read kernels.
 #define LH_CHAIN_LANE_MAX 16
+#define LH_EXT_COMPLEX_SEEDS 6   // K4 buckets (k_extend2.h): reads with more seeds go to the wave-per-read extension kernel
+#define LH_EXT_SUB 8             // sub-buckets per primary bucket
 template <class T, class Lt> __device__ inline void dev_introsort_small(int n, T* a, Lt lt) {
     T rp, swap_tmp;
     if (n < 1) return;
@@ -232,13 +234,16 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
                                                     const int32_t* __restrict__ l_rep, int32_t* __restrict__ s_next, DChainTmp* __restrict__ ct,
                                                     int32_t* __restrict__ ord, int32_t* __restrict__ srt, DChain* __restrict__ chains,
                                                     DSeed* __restrict__ cseeds, int32_t* __restrict__ n_chains, int32_t* __restrict__ status,
-                                                    int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
+                                                    int32_t* __restrict__ list, int32_t* __restrict__ list_count,
+                                                    int32_t* __restrict__ sdone, i64* __restrict__ chain_rmax, int32_t* __restrict__ ext_key, DCounters* __restrict__ ctr) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     int heavy = 0;
+    u64 win = 0;
+    int nch_done = 0;
     if (r < n_reads) {
         const i64 base = seed_off[r];
         const int S = (int)(seed_off[r + 1] - base);
-        if (seed_off[r + 1] > pool_cap) { n_chains[r] = 0; atomicOr(&status[r], LH_ST_POOL_OVERFLOW); }
+        if (seed_off[r + 1] > pool_cap) { n_chains[r] = 0; ext_key[r] = 32 * LH_EXT_SUB; atomicOr(&status[r], LH_ST_POOL_OVERFLOW); }
         else if (S > LH_CHAIN_LANE_MAX) heavy = 1;
         else {
             const int len = (int)(seq_off[r + 1] - seq_off[r]);
@@ -370,7 +375,63 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
                 m++;
             }
             n_chains[r] = m;
+            // K4's pre-pass for this read (k_ext_prep does it for the reads of the wave kernel): per kept chain the reference
+            // window of mem_chain2aln and the order in which its seeds are extended; per read the bucket of k_extend_lane.
+            // ord[] / srt[] are free again: srt[] receives the seed order, sdone[] the "extended" flags.
+            {
+                int l_query = len > LH_MAXLEN ? 0 : len;
+                const i64 l_pac = ix.l_pac;
+                int longest = 0, shorter = 0, nseeds = 0;
+                for (int ci = 0; ci < m; ++ci) {
+                    DChain c = chains[base + ci];
+                    const DSeed* sd = cseeds + base + c.seed_start;
+                    int32_t* so = srt + base + c.seed_start;
+                    int32_t* done = sdone + base + c.seed_start;
+                    const int n = c.n;
+                    nseeds += n;
+                    if (n == 0) continue;
+                    i64 r0 = l_pac << 1, r1 = 0;
+                    for (int i = 0; i < n; ++i) {
+                        DSeed t = sd[i];
+                        i64 b = t.rbeg - (t.qbeg + dev_cal_max_gap(o, t.qbeg));
+                        i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_cal_max_gap(o, l_query - t.qbeg - t.len));
+                        r0 = r0 < b ? r0 : b;
+                        r1 = r1 > e ? r1 : e;
+                    }
+                    i64 rmax0 = r0 > 0 ? r0 : 0, rmax1 = r1 < l_pac << 1 ? r1 : l_pac << 1;
+                    DSeed s0 = sd[0];
+                    if (rmax0 < l_pac && l_pac < rmax1) {   // crossing the forward-reverse boundary; then choose one side
+                        if (s0.rbeg < l_pac) rmax1 = l_pac;
+                        else rmax0 = l_pac;
+                    }
+                    dev_fetch_clamp(ix, &rmax0, s0.rbeg, &rmax1);
+                    win += (u64)(rmax1 - rmax0);
+                    chain_rmax[2 * (base + ci)] = rmax0; chain_rmax[2 * (base + ci) + 1] = rmax1;
+                    for (int i = 0; i < n; ++i) {   // by seed score (= len) then index, ascending
+                        DSeed t = sd[i];
+                        int rank = 0;
+                        for (int u = 0; u < n; ++u) { DSeed x = sd[u]; rank += (x.len < t.len) || (x.len == t.len && u < i); }
+                        so[rank] = i;
+                        done[i] = 1;
+                        if (ci == 0 && rank == n - 1) {
+                            int lt = t.qbeg, rt = l_query - t.qbeg - t.len;
+                            longest = lt > rt ? lt : rt; shorter = lt > rt ? rt : lt;
+                        }
+                    }
+                }
+                int prim = nseeds > LH_EXT_COMPLEX_SEEDS ? 0 : 32 - (longest >> 3 < 31 ? longest >> 3 : 31);
+                int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
+                ext_key[r] = prim * LH_EXT_SUB + sub;
+                nch_done = m;
+            }
         }
+    }
+    if (ctr) {
+        unsigned w32 = (unsigned)win;   // < 2^32 window bases per read
+        u64 wtot = (u64)(uint32_t)wave_sum_i32((int)(w32 >> 16)) << 16;
+        wtot += (u64)(uint32_t)wave_sum_i32((int)(w32 & 0xffff));
+        int ctot = wave_sum_i32(nch_done);
+        if (lane == 0 && (wtot || ctot)) { atomicAdd(&LH_CTR(ctr)->win_bases, wtot); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)ctot); }
     }
     u64 hm = __ballot(heavy);
     if (hm) {

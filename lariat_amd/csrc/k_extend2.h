@@ -19,9 +19,7 @@
 // slower: every class is a launch with its own tail, and more reads outgrow a tighter class and are redone.  Each primary bucket has LH_EXT_SUB sub-buckets by the length of the SHORTER side, so that the
 // lanes of a wave sweep similar windows on both sides of the seed.
 #define LH_EXT_PRIMARY 33
-#define LH_EXT_SUB 8
 #define LH_EXT_BINS (LH_EXT_PRIMARY * LH_EXT_SUB)
-#define LH_EXT_COMPLEX_SEEDS 6
 struct DExtBins {
     int32_t count[LH_EXT_BINS], cursor[LH_EXT_BINS];
     int32_t range[12];   // [first,last) pairs into the bucket-sorted order: complex, 256, 128, 64 columns; range[8..9] = the deferred list
@@ -31,9 +29,11 @@ struct DExtBins {
 __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
                                                   const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
                                                   int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, i64* __restrict__ chain_rmax, int32_t* __restrict__ key,
-                                                  DCounters* __restrict__ ctr) {
-    int r = blockIdx.x, lane = LANE();
-    if (r >= n_reads) return;
+                                                  DCounters* __restrict__ ctr, const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
+    const int lane = LANE();
+    const int n_items = *list_count;   // the reads chained by the wave kernel; k_chain_lane prepares its own reads
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int r = list[item];
     int l_query = (int)(seq_off[r + 1] - seq_off[r]);
     if (l_query > LH_MAXLEN) l_query = 0;
     i64 base = seed_off[r];
@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, int n_reads
         int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
         key[r] = prim * LH_EXT_SUB + sub;
         if (ctr) { atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }
+    }
     }
 }
 
