@@ -250,9 +250,11 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
 // ---- one lane per read: candidates without DP are finished here, the others are listed for k_aln ----
 __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                    const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, i64 cand_cap,
-                                                   int32_t* __restrict__ status, int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count) {
+                                                   int32_t* __restrict__ status, int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count,
+                                                   DCounters* __restrict__ ctr) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     const int live = r < n_reads;
+    unsigned proven_cells = 0;   // cells of global DPs whose outcome is known without running them (see below)
     int n = 0, n_slow = 0, all_slow = 0;
     uint32_t slow_mask = 0;   // candidates ci < 32 that need DP; reads with more regions are listed entirely
     i64 c0 = 0;
@@ -290,7 +292,16 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                 w2 = w2 > tmp ? w2 : tmp;
                 if (w2 > o.w) w2 = w2 < ar.w ? w2 : ar.w;
                 w2 = w2 < o.w << 2 ? w2 : o.w << 2;
-                if (!(valid && lq == rlen && w2 == 0)) { slow_mask |= 1u << ci; n_slow++; continue; }
+                if (!(valid && lq == rlen)) { slow_mask |= 1u << ci; n_slow++; continue; }
+                if (w2 != 0) {
+                    // Equal spans but an inferred band > 0 (BWA's test is only "fewer than two gaps' worth of penalty lost").  The
+                    // banded global alignment is still the plain diagonal whenever no path with gaps can beat it: such a path has
+                    // g >= 1 inserted and g deleted bases, so it scores at most (L-g)*a - (o_ins + g*e_ins) - (o_del + g*e_del),
+                    // largest at g = 1.  If the diagonal's own score S0 reaches that bound the DP ends on the diagonal (ties are
+                    // resolved towards the diagonal in ksw_global2: d = M >= E ? 0 : 1, then h >= F), every retry of mem_reg2aln
+                    // returns the same score, and the CIGAR is lq M.  With the default scoring this settles 3 mismatches
+                    // (bound: mm*(a+b) <= a + oe_ins + oe_del).  S0 needs the bases, so it is checked after the compare loop.
+                }
                 // no gap: CIGAR = [clip] lq M [clip]; one pass over the bases gives NM and lariat's mismatch loci.
                 // The aligned pairs are q[qb + t] vs the base at fwd||rev coordinate rb + t (the wave kernel's oriented views
                 // pair the same bases in the opposite order on the reverse strand).
@@ -305,7 +316,7 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                 int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
                 LaneTgt tg;
                 tg.init(ix, rb, 1);
-                int nmm = 0;
+                int nmm = 0, n_amb = 0;   // n_amb: mismatching pairs with an ambiguous base (scored -1, not -b)
                 for (int t0 = 0; t0 < lq; t0 += 16) {   // 16 query bases per round trip (the batch buffer is padded past the last read)
                     uint32_t qw[4];
                     __builtin_memcpy(qw, q + qb + t0, 16);
@@ -317,13 +328,37 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                             if (rbase != qv) {
                                 if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
                                 nmm++;
+                                n_amb += qv > 3;
                             }
                         }
                     }
                 }
                 const int NM = nmm;
+                if (w2 != 0) {
+                    const int S0 = lq * o.a - (nmm - n_amb) * (o.a + o.b) - n_amb * (o.a + 1);
+                    const int bound = (lq - 1) * o.a - (o.o_ins + o.e_ins) - (o.o_del + o.e_del);
+                    if (S0 < bound) { slow_mask |= 1u << ci; n_slow++; continue; }   // a gapped path could win: run the DP (k_aln)
+                    // the DP cells mem_reg2aln would have evaluated (telemetry stays comparable with the reference's work)
+                    int wq = w2, it = 0, last_sc = -(1 << 30);
+                    do {
+                        wq = wq < o.w << 2 ? wq : o.w << 2;
+                        int max_ins = (int)((double)(((lq + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
+                        int max_del = (int)((double)(((lq + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
+                        int max_gap = max_ins > max_del ? max_ins : max_del;
+                        max_gap = max_gap > 1 ? max_gap : 1;
+                        int w = (max_gap + 1) >> 1;
+                        w = w < wq ? w : wq;
+                        w = w > 3 ? w : 3;
+                        for (int i = 0; i < rlen; ++i) {
+                            int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
+                            if (end > beg) proven_cells += (unsigned)(end - beg);
+                        }
+                        if (S0 == last_sc || wq == o.w << 2) break;
+                        last_sc = S0;
+                        wq <<= 1;
+                    } while (++it < 3 && S0 < ar.truesc - o.a);
+                }
                 int mm_ovf = 0;
-                if (nmm > LH_MAX_MM) { mm_ovf = 1; nmm = LH_MAX_MM; }
                 int clip5 = 0, clip3 = 0, no = 0;
                 if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
                 uint32_t* cgo = R.cigar + (size_t)c * LH_MAX_CIGAR;
@@ -344,6 +379,11 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                 if (mm_ovf) atomicOr(&status[r], LH_ST_MM_OVERFLOW);
             }
         }
+    }
+    if (ctr) {
+        u64 tot = (u64)(uint32_t)wave_sum_i32((int)(proven_cells >> 16)) << 16;
+        tot += (u64)(uint32_t)wave_sum_i32((int)(proven_cells & 0xffff));
+        if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->glob_cells, tot);
     }
     // the wave reserves list space once (same-address atomics are slow), then every lane writes its own items
     int incl = wave_scan_add_i32(n_slow);
