@@ -155,6 +155,9 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = n ? aligned_alloc(256, (n + 255) / 256 * 256) : nullptr; return (n && !*p) ? 2 : 0; }
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
+#define hipHostMallocDefault 0
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return 0; }
