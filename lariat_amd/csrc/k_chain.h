@@ -198,6 +198,16 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
 #define LH_CHAIN_LANE_MAX 16
 #define LH_EXT_COMPLEX_SEEDS 6   // K4 buckets (k_extend2.h): reads with more seeds go to the wave-per-read extension kernel
 #define LH_EXT_SUB 8             // sub-buckets per primary bucket
+// primary bucket of a read: 0 = many seeds (wave kernel); 1..16 first extension >= 128 columns (longest first), 17..24 64..127,
+// 25 = no DP expected but >= 64 columns (LDS class 128 in case a later extension needs one); 26..33 < 64 columns; 34 = no DP
+// expected, < 64 columns
+#define LH_EXT_PRIMARY 35
+__device__ __forceinline__ int lh_ext_bucket(int nseeds, int longest, int cheap) {
+    if (nseeds > LH_EXT_COMPLEX_SEEDS) return 0;
+    int L = longest >> 3 < 31 ? longest >> 3 : 31;
+    if (cheap) return L >= 8 ? 25 : 34;
+    return L >= 8 ? 32 - L : 33 - L;
+}
 template <class T, class Lt> __device__ inline void dev_introsort_small(int n, T* a, Lt lt) {
     T rp, swap_tmp;
     if (n < 1) return;
@@ -235,7 +245,8 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
                                                     int32_t* __restrict__ ord, int32_t* __restrict__ srt, DChain* __restrict__ chains,
                                                     DSeed* __restrict__ cseeds, int32_t* __restrict__ n_chains, int32_t* __restrict__ status,
                                                     int32_t* __restrict__ list, int32_t* __restrict__ list_count,
-                                                    int32_t* __restrict__ sdone, i64* __restrict__ chain_rmax, int32_t* __restrict__ ext_key, DCounters* __restrict__ ctr) {
+                                                    int32_t* __restrict__ sdone, i64* __restrict__ chain_rmax, int32_t* __restrict__ ext_key, DCounters* __restrict__ ctr,
+                                                    const uint8_t* __restrict__ seq) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     int heavy = 0;
     u64 win = 0;
@@ -243,7 +254,7 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
     if (r < n_reads) {
         const i64 base = seed_off[r];
         const int S = (int)(seed_off[r + 1] - base);
-        if (seed_off[r + 1] > pool_cap) { n_chains[r] = 0; ext_key[r] = 32 * LH_EXT_SUB; atomicOr(&status[r], LH_ST_POOL_OVERFLOW); }
+        if (seed_off[r + 1] > pool_cap) { n_chains[r] = 0; ext_key[r] = 34 * LH_EXT_SUB; atomicOr(&status[r], LH_ST_POOL_OVERFLOW); }
         else if (S > LH_CHAIN_LANE_MAX) heavy = 1;
         else {
             const int len = (int)(seq_off[r + 1] - seq_off[r]);
@@ -381,7 +392,10 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
             {
                 int l_query = len > LH_MAXLEN ? 0 : len;
                 const i64 l_pac = ix.l_pac;
-                int longest = 0, shorter = 0, nseeds = 0;
+                int longest = 0, shorter = 0, nseeds = 0, have_top = 0;
+                DSeed top;
+                i64 top_r0 = 0, top_r1 = 0;
+                top.rbeg = 0; top.qbeg = 0; top.len = 0;
                 for (int ci = 0; ci < m; ++ci) {
                     DChain c = chains[base + ci];
                     const DSeed* sd = cseeds + base + c.seed_start;
@@ -416,10 +430,33 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
                         if (ci == 0 && rank == n - 1) {
                             int lt = t.qbeg, rt = l_query - t.qbeg - t.len;
                             longest = lt > rt ? lt : rt; shorter = lt > rt ? rt : lt;
+                            top = t; top_r0 = rmax0; top_r1 = rmax1; have_top = 1;
                         }
                     }
                 }
-                int prim = nseeds > LH_EXT_COMPLEX_SEEDS ? 0 : 32 - (longest >> 3 < 31 ? longest >> 3 : 31);
+                // Is the first seed's extension provably ungapped on both sides (k_extend2.h: diagonal penalties below one gap's
+                // cost)?  Such reads usually need no DP at all; they get their own bucket so that whole waves skip it.
+                int cheap = 0;
+                if (have_top && nseeds <= LH_EXT_COMPLEX_SEEDS) {
+                    const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
+                    const uint8_t* q = seq + seq_off[r];
+                    cheap = 1;
+                    for (int side = 0; side < 2 && cheap; ++side) {
+                        int qlen = side ? l_query - top.qbeg - top.len : top.qbeg;
+                        i64 tlen = side ? top_r1 - (top.rbeg + top.len) : top.rbeg - top_r0;
+                        if (qlen == 0) continue;
+                        if (tlen < qlen) { cheap = 0; break; }
+                        LaneTgt tg;
+                        tg.init(ix, side ? top.rbeg + top.len : top.rbeg - 1, side ? 1 : -1);
+                        int P = 0;
+                        for (int k = 0; k < qlen; ++k) {
+                            int qv = q[side ? top.qbeg + top.len + k : top.qbeg - 1 - k], tb = tg.base(k);
+                            P += qv > 3 ? o.a + 1 : (tb == qv ? 0 : o.a + o.b);
+                            if (P >= thr) { cheap = 0; break; }
+                        }
+                    }
+                }
+                int prim = lh_ext_bucket(nseeds, longest, cheap);
                 int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
                 ext_key[r] = prim * LH_EXT_SUB + sub;
                 nch_done = m;

@@ -13,12 +13,13 @@
 #pragma once
 #include "k_extend.h"
 
-// primary buckets: 0 = reads with many chains / seeds (handed to the wave-per-read kernel, which is parallel over seeds and
-// columns); 1..32 = by the length of the LONGER side of the first extension, longest first: 1..16 need 256 LDS columns,
-// 17..24 128, 25..32 64 (the LDS footprint sets how many waves a CU holds: 2 / 5 / 10).  Finer classes (96, 32) were measured
-// slower: every class is a launch with its own tail, and more reads outgrow a tighter class and are redone.  Each primary bucket has LH_EXT_SUB sub-buckets by the length of the SHORTER side, so that the
-// lanes of a wave sweep similar windows on both sides of the seed.
-#define LH_EXT_PRIMARY 33
+// Buckets (lh_ext_bucket in k_chain.h): 0 = reads with many chains / seeds (handed to the wave-per-read kernel, which is
+// parallel over seeds and columns); then by the length of the LONGER side of the first extension, longest first, in three LDS
+// classes of 256 / 128 / 64 columns (the LDS footprint sets how many waves a CU holds: 2 / 5 / 10); reads whose first
+// extension is provably ungapped on both sides (no DP expected) have their own bucket at the end of the 128 and of the 64
+// class, so that whole waves skip the DP.  Finer classes (96, 32) were measured slower: every class is a launch with its own
+// tail, and more reads outgrow a tighter class and are redone.  Each primary bucket has LH_EXT_SUB sub-buckets by the length
+// of the SHORTER side, so that the lanes of a wave sweep similar windows on both sides of the seed.
 #define LH_EXT_BINS (LH_EXT_PRIMARY * LH_EXT_SUB)
 struct DExtBins {
     int32_t count[LH_EXT_BINS], cursor[LH_EXT_BINS];
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, int n_reads
     }
     longest = wave_max_i32(longest); shorter = wave_max_i32(shorter);
     if (lane == 0) {
-        int prim = nseeds > LH_EXT_COMPLEX_SEEDS ? 0 : 32 - (longest >> 3 < 31 ? longest >> 3 : 31);   // longest extensions first
+        int prim = lh_ext_bucket(nseeds, longest, 0);   // longest extensions first
         int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
         key[r] = prim * LH_EXT_SUB + sub;
         if (ctr) { atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(64) k_ext_offsets(DExtBins* __restrict__ bins)
             if (b == 0) bins->range[0] = acc;
             if (b == 1 * LH_EXT_SUB) { bins->range[1] = acc; bins->range[2] = acc; }
             if (b == 17 * LH_EXT_SUB) { bins->range[3] = acc; bins->range[4] = acc; }
-            if (b == 25 * LH_EXT_SUB) { bins->range[5] = acc; bins->range[6] = acc; }
+            if (b == 26 * LH_EXT_SUB) { bins->range[5] = acc; bins->range[6] = acc; }   // class 128 runs buckets 17..25, class 64 buckets 26..34
             bins->cursor[b] = acc; acc += bins->count[b];
         }
         bins->range[7] = acc; bins->range[8] = 0; bins->range[9] = 0;
@@ -135,27 +136,6 @@ __global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t*
         if (k[u] >= 0) order[basep[k[u]] + rank[u]] = r;
     }
 }
-
-struct LaneTgt {   // the reference bases of an extension, read 16 at a time from the 2-bit forward array
-    const uint32_t* pac32;
-    i64 idx0, widx;
-    int dir, comp;
-    uint32_t w;
-    __device__ __forceinline__ void init(const DIndex& ix, i64 p0, int tstep) {
-        pac32 = (const uint32_t*)ix.pac;
-        int fwd = p0 < ix.l_pac;
-        idx0 = fwd ? p0 : (ix.l_pac << 1) - 1 - p0;
-        dir = fwd ? tstep : -tstep;
-        comp = fwd ? 0 : 3;
-        widx = -1; w = 0;
-    }
-    __device__ __forceinline__ int base(int i) {
-        i64 ii = idx0 + (i64)dir * i;
-        i64 wi = ii >> 4;
-        if (wi != widx) { w = pac32[wi]; widx = wi; }
-        return (int)((w >> (8 * (int)((ii >> 2) & 3) + (int)((~ii & 3) << 1))) & 3) ^ comp;
-    }
-};
 
 #define EH_H(v) ((int)((v) & 0xffffu))
 #define EH_E(v) ((int)(((v) >> 16) & 0x1fffu))
@@ -328,8 +308,35 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                     ExtRes e;
                     e.score = -1; e.qle = e.tle = e.gtle = 0; e.gscore = -1; e.max_off = 0;
                     int aw = o.w;
-                    if (qlen >= EHW_) { deferred = 1; break; }
-                    for (int i = 0; i < 2; ++i) {   // MAX_BAND_TRY
+                    // ksw_extend2 without the DP when it is provably the ungapped extension.  A cell off the diagonal is reached
+                    // through at least one gap and at most min(i,j)+1 aligned pairs: H(i,j) <= h0 + (min(i,j)+1)*a - min(oe_ins,
+                    // oe_del).  If the penalties lost along the diagonal (a+b per mismatch, a+1 per ambiguous base) stay below
+                    // that gap cost over the whole query, every row's maximum is its diagonal cell, strictly: max / qle / tle
+                    // come from the diagonal's running score (first maximum), max_off is 0, the band is not retried, and
+                    // gscore = the diagonal's last value at gtle = qlen (all other cells of the last column are smaller).
+                    // With the default scoring that is any extension with at most one mismatch: most of them.
+                    int proven = 0;
+                    if (tlen >= qlen) {
+                        const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
+                        LaneTgt tg;
+                        tg.init(ix, tc0, tstep);
+                        int P = 0, sc_run = h0, mx = h0, mxk = -1, k = 0;
+                        for (; k < qlen; ++k) {
+                            int qv = q[qoff + qstep * k], tb = tg.base(k);
+                            int sc = qv > 3 ? -1 : (tb == qv ? o.a : -o.b);
+                            P += o.a - sc;
+                            if (P >= thr) break;
+                            sc_run += sc;
+                            if (sc_run > mx) { mx = sc_run; mxk = k; }
+                        }
+                        if (k == qlen) {
+                            e.score = mx; e.qle = mxk + 1; e.tle = mxk + 1; e.gscore = sc_run; e.gtle = qlen; e.max_off = 0;
+                            a.score = e.score;
+                            proven = 1;
+                        }
+                    }
+                    if (!proven && qlen >= EHW_) { deferred = 1; break; }
+                    for (int i = 0; i < 2 && !proven; ++i) {   // MAX_BAND_TRY
                         int prev = a.score;
                         aw = o.w << i;
                         LaneTgt tg;

@@ -315,6 +315,28 @@ __device__ __forceinline__ int dev_pac(const uint8_t* pac, i64 l) { return pac[l
 __device__ __forceinline__ int dev_ref_base(const DIndex& ix, i64 p) {
     return p < ix.l_pac ? dev_pac(ix.pac, p) : 3 - dev_pac(ix.pac, (ix.l_pac << 1) - 1 - p);
 }
+// the reference bases of one lane's extension / alignment, read 16 at a time from the 2-bit forward array
+struct LaneTgt {
+    const uint32_t* pac32;
+    i64 idx0, widx;
+    int dir, comp;
+    uint32_t w;
+    __device__ __forceinline__ void init(const DIndex& ix, i64 p0, int tstep) {
+        pac32 = (const uint32_t*)ix.pac;
+        int fwd = p0 < ix.l_pac;
+        idx0 = fwd ? p0 : (ix.l_pac << 1) - 1 - p0;
+        dir = fwd ? tstep : -tstep;
+        comp = fwd ? 0 : 3;
+        widx = -1; w = 0;
+    }
+    __device__ __forceinline__ int base(int i) {
+        i64 ii = idx0 + (i64)dir * i;
+        i64 wi = ii >> 4;
+        if (wi != widx) { w = pac32[wi]; widx = wi; }
+        return (int)((w >> (8 * (int)((ii >> 2) & 3) + (int)((~ii & 3) << 1))) & 3) ^ comp;
+    }
+};
+
 __device__ __forceinline__ int dev_pos2rid(const DIndex& ix, i64 pos_f) {
     int left, mid, right;
     if (pos_f >= ix.l_pac) return -1;

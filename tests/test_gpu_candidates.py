@@ -52,8 +52,10 @@ def test_candidates_synthetic(lib, oracle, seed, junk):
     res = ctx.align_barcodes(b, lib.opts(run_inference=0))
     ores = oidx.align_barcodes(b, oracle.opts(run_inference=0), threads=8)
     helpers.assert_same_result(res, ores, inference=False)
-    for k in ("n_ext", "n_sa", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"):
+    for k in ("n_ext", "n_sa", "glob_cells", "n_rescue", "rescue_cells"):
         assert res.counters[k] == ores.counters[k], k
+    # ext_cells counts the DP cells the device evaluated: extensions that are provably ungapped (k_extend2.h) skip their DP
+    assert 0 < res.counters["ext_cells"] <= ores.counters["ext_cells"]
     # the suffix array is re-sampled densely on load (every row for a genome this small): no BWT walk is left in bwt_sa
     assert idx.sa_interval == 1 and res.counters["n_lf"] == 0
     # back at the .sa file's interval (sub-sampling path) the walk lengths are the oracle's, and nothing else changes
@@ -95,8 +97,9 @@ def test_long_noisy_reads(lib, oracle):
     res = ctx.align_barcodes(b)
     ores = oidx.align_barcodes(b, threads=8)
     helpers.assert_same_result(res, ores, inference=True)
-    for k in ("n_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"):
+    for k in ("n_ext", "glob_cells", "n_rescue", "rescue_cells"):
         assert res.counters[k] == ores.counters[k], k
+    assert res.counters["ext_cells"] <= ores.counters["ext_cells"]
 
 
 def test_pools_grow_on_demand(lib, oracle):
