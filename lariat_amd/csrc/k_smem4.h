@@ -12,6 +12,12 @@
 // no lane waits for the slowest read of a batch.  The arithmetic and the order of list operations per read are exactly
 // those of bwt_smem1a / bwt_seed_strategy1: only the interleaving across reads differs.
 //
+//  - UNIQUE RUNS: once a match has a single occurrence (interval size 1), extending it is comparing the read with the text at
+//    that occurrence.  With a fully resident suffix array the lane looks the position up once (sa[x0]) and then advances
+//    eight bases per turn by XOR-ing 4-bit packed read and text words, instead of one base per turn through two
+//    occurrence records; the interval bound that changes meanwhile (x1 forward, x0 backward) is read back once from the
+//    inverse suffix array when the run ends (the other bound provably stays put while the size is 1).  Used for the
+//    forward extension of bwt_smem1a and for backward rows with one surviving interval: most of a read's steps.
 //  - query: 4-bit packed in LDS (8 bases per word, word w of lane L at qn[w*64+L]), staged by the whole wave
 //  - prev/curr interval lists: 16-B packed entries in an HBM slab interleaved by thread; the entry the next row starts
 //    with stays in registers (and is never written to the slab: most backward rows have a single survivor) and the
@@ -37,6 +43,8 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_REQ_FWD 2
 #define S4_REQ_BWD 3
 #define S4_REQ_P3 4
+#define S4_REQ_FRUN 5    // unique run, forward / backward: active states that need no bwt_extend
+#define S4_REQ_BRUN 6
 #define S4_BWD_EMIT 8    // states >= 8 are transitions handled without an extension (section B of the main loop)
 #define S4_BWD_INIT 9
 #define S4_BWD_EMIT0 10
@@ -45,6 +53,14 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_P2_NEXT 13
 #define S4_P3_SCAN 14
 #define S4_READ_DONE 15
+#define S4_FRUN_INIT 16  // unique runs: each global read is issued in one turn and used in the next (its latency hides behind the turn's extensions)
+#define S4_FRUN_INIT2 17
+#define S4_FRUN_END 18
+#define S4_FRUN_END2 19
+#define S4_BRUN_INIT 20
+#define S4_BRUN_INIT2 21
+#define S4_BRUN_END 22
+#define S4_BRUN_END2 23
 
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
@@ -66,8 +82,23 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
     int cinfo = 0, ec = 0, i = 0, x = 0, j = 0, ncurr = 0, nprev = 0, rev = 0, min_intv = 1, have_mem = 0, last_mem_start = 0, ret = 0, phase = 0, curA = 1;
     PEnt ce, pn;
     ce.lo = ce.hi = pn.lo = pn.hi = 0;
+    i64 run_p = 0;            // unique run: text position of the match's first base
+    u64 ld64 = 0;             // a suffix-array / inverse-array value in flight
+    uint32_t tw_lo = 0, tw_hi = 0, tw_sh = 0;   // the text words of the run's current 8-base window
+    const bool runs = ix.isa != nullptr;
     unsigned n_ext_total = 0;
 #define QB(i_) ((int)((qn[((i_) >> 3) * 64 + lane] >> (((i_) & 7) * 4)) & 0xF))
+    // eight read bases from index s_ on (s_ may be negative or run past the read: those read as 4 = never equal to a text base)
+#define Q8(s_, out_)                                                                                         \
+    {                                                                                                        \
+        int w_ = (s_) >> 3, sh_ = ((s_) & 7) * 4;                                                            \
+        uint32_t lo_ = (w_ >= 0 && w_ < 32) ? qn[w_ * 64 + lane] : 0x44444444u;                              \
+        uint32_t hi_ = (w_ + 1 >= 0 && w_ + 1 < 32) ? qn[(w_ + 1) * 64 + lane] : 0x44444444u;                \
+        out_ = sh_ ? (lo_ >> sh_) | (hi_ << (32 - sh_)) : lo_;                                               \
+    }
+    // issue the reads of the eight text bases from position p_ on (p_ >= -8); T8() assembles them once they have arrived
+#define T8_LOAD(p_) { i64 w_ = (p_) >> 3; tw_sh = (uint32_t)((p_) & 7) * 4; tw_lo = ix.tn[w_]; tw_hi = ix.tn[w_ + 1]; }
+#define T8() (tw_sh ? (tw_lo >> tw_sh) | (tw_hi << (32 - tw_sh)) : tw_lo)
 #define CURR (curA ? LA : LB)
 #define PREV (curA ? LB : LA)
     // forward extension: the next base decides between another bwt_extend and the end of the forward list
@@ -104,6 +135,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
         ncurr = 0; last_size = 0; j = 0;                                                                     \
         c0 = PE_X0(ce); c1 = PE_X1(ce); c2 = PE_X2(ce); cinfo = PE_INFO(ce);                                 \
         if (c_ > 3) st = S4_BWD_EMIT0;   /* nothing extends: only the first (longest) entry can be a new MEM */ \
+        else if (runs && nprev == 1 && c2 == 1 && min_intv == 1) st = S4_BRUN_INIT;   /* one unique match left */ \
         else {                                                                                               \
             ec = c_; st = S4_REQ_BWD;                                                                        \
             if (nprev > 1) pn = PREV[(uint32_t)(rev ? nprev - 2 : 1) * T];                                   \
@@ -185,7 +217,26 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
         }
         // ---- B. transitions between the loops of mem_collect_intv (rare per lane; the blocks are ordered so that the
         //         usual chains finish in one pass) ----
-        while (__any(st >= 8)) {
+    if (st >= S4_FRUN_INIT) {   // unique runs: ONE step of their load / use chains per turn: a value read here is used in the next turn
+            if (st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; st = S4_FRUN_INIT2; }
+            else if (st == S4_FRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p + (i - x)) st = S4_REQ_FRUN; }
+            else if (st == S4_FRUN_END) { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }   // the reverse strand's copy of the match
+            else if (st == S4_FRUN_END2) {   // the unique interval closes the forward list (it is the list's last entry: kept in ce only)
+                c1 = ld64;
+                ce = pe_pack(c0, c1, c2, cinfo);
+                ncurr++;
+                st = S4_BWD_INIT;
+            }
+            else if (st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
+            else if (st == S4_BRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p - 8) st = S4_REQ_BRUN; }
+            else if (st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
+            else {   // S4_BRUN_END2: the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
+                c0 = ld64;
+                if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
+                st = S4_SMEM_DONE;
+            }
+        }
+        while (__any(st >= 8 && st < S4_FRUN_INIT)) {
             if (st == S4_BWD_EMIT) {
                 EMIT_MEM()
                 BWD_ADVANCE()
@@ -245,7 +296,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
         // ---- D. the shared program point: one bwt_extend per requesting lane ----
         DIntv ok;
         ok.x0 = ok.x1 = ok.x2 = ok.info = 0;
-        if (st >= S4_REQ_FWD) {
+        if (st >= S4_REQ_FWD && st <= S4_REQ_P3) {
             DIntv a;
             a.x0 = c0; a.x1 = c1; a.x2 = c2; a.info = 0;
             ok = dev_extend_c(ix, a, ec, st == S4_REQ_BWD);
@@ -261,7 +312,8 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
             }
             if (st == S4_REQ_FWD) {
                 c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i;
-                FWD_ADVANCE()
+                if (runs && c2 == 1 && min_intv == 1) st = S4_FRUN_INIT;   // a single occurrence: follow it through the text
+                else FWD_ADVANCE()
             }
         } else if (st == S4_REQ_BWD) {
             if (ok.x2 < (u64)min_intv) {
@@ -274,6 +326,31 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 last_size = ok.x2;
             }
             if (st == S4_REQ_BWD) BWD_ADVANCE()
+        } else if (st == S4_REQ_FRUN) {   // forward unique run: up to eight successful bwt_extend steps at once
+            uint32_t q8, xr;
+            Q8(i, q8)
+            xr = q8 ^ T8();
+            int n = xr ? (__ffs((int)xr) - 1) >> 2 : 8;
+            n_ext_total += (unsigned)n;
+            i += n;
+            if (n == 8) T8_LOAD(run_p + (i - x))
+            else {   // read exhausted, ambiguous base, text exhausted or a mismatch: the run's interval is the forward list's last entry
+                if (i < len && QB(i) <= 3) n_ext_total++;   // the bwt_extend that returned an empty interval
+                cinfo = i;
+                st = S4_FRUN_END;
+            }
+        } else if (st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
+            uint32_t q8, xr;
+            Q8(i - 7, q8)
+            xr = q8 ^ T8();
+            int n = xr ? __clz((int)xr) >> 2 : 8;
+            n_ext_total += (unsigned)n;
+            i -= n; run_p -= n;
+            if (n == 8) T8_LOAD(run_p - 8)
+            else {
+                if (i >= 0 && QB(i) <= 3) n_ext_total++;   // the bwt_extend that returned an empty interval
+                st = S4_BRUN_END;
+            }
         } else if (st == S4_REQ_P3) {
             if (ok.x2 < (u64)o.max_mem_intv && i - x >= o.min_seed_len) {
                 if (ok.x2 > 0) {
@@ -288,6 +365,9 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
         }
     }
 #undef QB
+#undef Q8
+#undef T8_LOAD
+#undef T8
 #undef CURR
 #undef PREV
 #undef START_SMEM1
