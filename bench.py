@@ -27,7 +27,7 @@ import numpy as np
 
 # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB -> B), collected separately and committed
 # under profiles/ (see DESIGN.md section 4 for the calibration of FETCH_SIZE on this access pattern); None = not measured.
-TRAFFIC = {"k_smem3": (1.455e8 + 5.255e7) * 1024.0, "k_smem4": (9.425e7 + 1.556e7) * 1024.0}   # profiles/r01_pmc_summary_v4_tcc.txt
+TRAFFIC = {"k_smem3": (1.455e8 + 5.255e7) * 1024.0, "k_smem4": (8.226e7 + 1.549e7) * 1024.0}   # profiles/r01_pmc_summary_v7.txt
 
 
 def main():
