@@ -61,6 +61,9 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_BRUN_INIT2 21
 #define S4_BRUN_END 22
 #define S4_BRUN_END2 23
+#define S4_P3_JUMP 24    // pass 3: the walk's first 12 bases come from the 12-mer table
+#define S4_P3_JUMP2 25
+#define LH_KMER 12
 
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
@@ -227,6 +230,13 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 ncurr++;
                 st = S4_BWD_INIT;
             }
+            else if (st == S4_P3_JUMP) { pn = ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
+            else if (st == S4_P3_JUMP2) {   // as if the 11 bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
+                c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn);
+                n_ext_total += LH_KMER - 1;
+                i = x + LH_KMER;
+                P3_ADVANCE()
+            }
             else if (st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
             else if (st == S4_BRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p - 8) st = S4_REQ_BRUN; }
             else if (st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
@@ -279,7 +289,23 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                     int b = QB(x);
                     c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1;
                     i = x + 1;
-                    P3_ADVANCE()
+                    int jumped = 0;
+                    if (ix.kmer12 && x + LH_KMER <= len && o.min_seed_len >= LH_KMER) {
+                        uint32_t w0, w1;
+                        Q8(x, w0)
+                        Q8(x + 8, w1)
+                        w1 &= 0xffffu;   // bases x+8 .. x+11
+                        if (!((w0 | w1) & 0x44444444u)) {   // no ambiguous base among the twelve
+                            // 4-bit -> 2-bit per base (base k of the 12-mer ends up at bits 2k..2k+1)
+                            uint32_t t0 = w0 & 0x33333333u, t1 = w1 & 0x3333u;
+                            t0 = (t0 | t0 >> 2) & 0x0f0f0f0fu; t0 = (t0 | t0 >> 4) & 0x00ff00ffu; t0 = (t0 | t0 >> 8) & 0xffffu;
+                            t1 = (t1 | t1 >> 2) & 0x0f0fu; t1 = (t1 | t1 >> 4) & 0xffu;
+                            ld64 = t0 | t1 << 16;
+                            st = S4_P3_JUMP;
+                            jumped = 1;
+                        }
+                    }
+                    if (!jumped) P3_ADVANCE()
                 }
             }
             if (st == S4_READ_DONE) {
@@ -296,6 +322,10 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
         // ---- D. the shared program point: one bwt_extend per requesting lane ----
         DIntv ok;
         ok.x0 = ok.x1 = ok.x2 = ok.info = 0;
+#ifdef LH_SMEM_PROF   // development aid: FM-index extensions actually performed, by loop (lh_dbg[16..19] in units of 1024)
+        { int k_ = st == S4_REQ_FWD ? (phase == 1 ? 16 : 18) : st == S4_REQ_BWD ? (phase == 1 ? 17 : 18) : st == S4_REQ_P3 ? 19 : -1;
+          for (int kk_ = 16; kk_ < 20; ++kk_) { int n_ = (int)__popcll(__ballot(k_ == kk_)); if (lane == 0 && n_) atomicAdd(&lh_dbg[kk_ + 4], n_); } }
+#endif
         if (st >= S4_REQ_FWD && st <= S4_REQ_P3) {
             DIntv a;
             a.x0 = c0; a.x1 = c1; a.x2 = c2; a.info = 0;

@@ -94,6 +94,8 @@ struct DIndex {
     // to follow a UNIQUE match through the text instead of through the FM-index (k_smem4.h).
     const u64* isa;
     const uint32_t* tn;
+    // the bi-interval of every 12-mer (packed like K1's list entries, 16 B each): bwt_seed_strategy1's walks start there
+    const void* kmer12;
     const u64* sa;           // sampled SA, sa[0] = -1
     const uint8_t* pac;      // 2-bit forward reference, MSB first
     const i64* contig_off;   // [n_contigs]
