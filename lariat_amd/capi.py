@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "liblariat_hip.so")
+LIB_PATH = os.environ.get("LARIAT_HIP_LIB") or os.path.join(_HERE, "_build", "liblariat_hip.so")
 
 LH_OK = 0
 LH_ABI_VERSION = 1

@@ -65,6 +65,9 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_P3_JUMP2 25
 #define LH_KMER 12
 
+#ifndef LH_SLOW_BATCH
+#define LH_SLOW_BATCH 1
+#endif
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
 #endif
@@ -174,7 +177,11 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
     }
     for (;;) {
         // ---- A. lanes without a read take the next ones of the wave's chunk; the wave stages their bases in LDS ----
-        u64 need = __ballot(st == S4_FETCH);
+        // Lanes that left the extension loops wait until LH_SLOW_BATCH of them have gathered (or nothing else is in flight):
+        // the divergent blocks of A and B then run for many lanes at once instead of for one or two in every turn.
+        const bool slow_turn = __popcll(__ballot(st == S4_FETCH || (st >= 8 && st < S4_FRUN_INIT))) >= LH_SLOW_BATCH ||
+                               !__any((st >= S4_REQ_FWD && st < 8) || st >= S4_FRUN_INIT);
+        u64 need = slow_turn ? __ballot(st == S4_FETCH) : 0;
         if (need) {
             int cnt = __popcll(need), newbase = 0;
             if (chunk_next + cnt > chunk_end) {
@@ -246,7 +253,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 st = S4_SMEM_DONE;
             }
         }
-        while (__any(st >= 8 && st < S4_FRUN_INIT)) {
+        while (slow_turn && __any(st >= 8 && st < S4_FRUN_INIT)) {
             if (st == S4_BWD_EMIT) {
                 EMIT_MEM()
                 BWD_ADVANCE()
@@ -315,7 +322,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
             }
         }
         // ---- C. anything left to extend? ----
-        if (!__any(st >= S4_REQ_FWD)) {
+        if (!__any(st >= S4_REQ_FWD && st < 8)) {   // parked lanes advance in A / B of the next turn
             if (!__any(st != S4_DONE)) break;
             continue;
         }

@@ -173,3 +173,26 @@ def test_fastq_to_bam_records(lib, oracle, tmp_path):
         assert got == want
         n += len(got.splitlines())
     assert n >= 2 * rs.n_pairs
+
+
+def test_simulated_accounting_on_hip_result(lib, oracle, tmp_path):
+    """N4: lariat's -simulated counters and the check.py report, computed from the HIP result, equal those from the oracle's"""
+    from lariat_amd import simulated, synth
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = synth.make_reads(contigs, names, n_barcodes=5, pairs_per_barcode=40, seed=79, junk_frac=0.05)
+    p = tmp_path / "reads.fastq"
+    p.write_text(synth.to_fastq9(rs, trim_prefix=7))
+    ctx = idx.context(rs.n_pairs)
+    sg, so = simulated.SimulatedStats(), simulated.SimulatedStats()
+    tg, to = [], []
+    for b in lib.ingest(str(p), trim=7):
+        nm = b.column("name")
+        rg, ro = ctx.align_barcodes(b), oidx.align_barcodes(b, threads=8)
+        sg.add(rg, nm, b.bc_pair_off, b.bc_do_rfa)
+        so.add(ro, nm, b.bc_pair_off, b.bc_do_rfa)
+        tg += lib.records_text(rg, b, names).splitlines()
+        to += lib.records_text(ro, b, names).splitlines()
+    assert sg.as_dict() == so.as_dict() and sg.total > 0
+    assert simulated.check_report(tg, mate_aware=True) == simulated.check_report(to, mate_aware=True)
