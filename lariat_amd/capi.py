@@ -445,11 +445,20 @@ class Context:
         self.lib.L.lh_result_free(res)
         return out
 
-    def align_barcodes(self, batch, opts=None):
+    def download_raw(self):
+        """lh_result_download + lh_result_free without the numpy copies of `Result`: what a cgo / C host pays, since it reads
+        the library-owned SoA block in place.  Returns (n_reads, n_cand)."""
+        res = C.POINTER(LhResult)()
+        self.lib.check(self.lib.L.lh_result_download(self.h, C.byref(res)))
+        n = (int(res.contents.n_reads), int(res.contents.n_cand))
+        self.lib.L.lh_result_free(res)
+        return n
+
+    def align_barcodes(self, batch, opts=None, raw=False):
         opts = opts or self.lib.opts()
         self.upload(batch)
         self.align_resident(opts)
-        return self.download()
+        return self.download_raw() if raw else self.download()
 
     def timings(self):
         n = C.c_int32()

@@ -66,7 +66,7 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define LH_KMER 12
 
 #ifndef LH_SLOW_BATCH
-#define LH_SLOW_BATCH 1
+#define LH_SLOW_BATCH 8
 #endif
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
@@ -92,6 +92,11 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
     u64 ld64 = 0;             // a suffix-array / inverse-array value in flight
     uint32_t tw_lo = 0, tw_hi = 0, tw_sh = 0;   // the text words of the run's current 8-base window
     const bool runs = ix.isa != nullptr;
+    // sweep filter (see FWD_PUSH_OK): the key of the LH_BLOOM_K read bases that end where the current forward interval ends,
+    // the filter word read for it, the bits it must have; filt_from = first interval end for which that window is all bases
+    const bool filt = ix.bloom1 != nullptr && o.min_seed_len >= LH_BLOOM_K;
+    u64 wkey = 0, bword = 0, bmask = 0;
+    int filt_from = 0;
     unsigned n_ext_total = 0;
 #define QB(i_) ((int)((qn[((i_) >> 3) * 64 + lane] >> (((i_) & 7) * 4)) & 0xF))
     // eight read bases from index s_ on (s_ may be negative or run past the read: those read as 4 = never equal to a text base)
@@ -117,11 +122,45 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
             st = S4_BWD_INIT;                                                                                \
         } else { ec = 3 - b_; st = S4_REQ_FWD; }                                                             \
     }
+    // Sweep filter.  The backward sweep of bwt_smem1a extends EVERY interval of the forward list to the left until it dies,
+    // but an interval [x, e) of the list can only give a MEM of min_seed_len bases or more if the LH_BLOOM_K-mer that ends
+    // at e occurs min_intv times in the text: whatever the sweep emits for it contains that k-mer and has at least min_intv
+    // occurrences.  If the filter (all k-mers for min_intv == 1, k-mers occurring twice or more otherwise) says it does not,
+    // the interval is left out of the list: its rows would only have produced MEMs shorter than min_seed_len, which are
+    // not kept, and the rows of the other intervals do not depend on it (an interval dies no later than the shorter ones
+    // after it; only the first to die in a row is looked at; an interval that merged with a dropped one has the same rows
+    // from there on).  A false positive of the filter only means the interval is swept as before.  The list's last
+    // interval is always kept.  bword / bmask belong to the CURRENT interval; they are read one turn before they are used.
+#define BLOOM_ISSUE()                                                                                        \
+    {                                                                                                        \
+        bword = 0; bmask = filt ? 1 : 0;   /* no filter: keep; window not all bases (or read start): drop */ \
+        if (filt && cinfo >= filt_from) {                                                                    \
+            uint32_t w_;                                                                                     \
+            if (min_intv == 1) { dev_bloom_slot(wkey, ix.bloom1_words, &w_, &bmask); bword = ix.bloom1[w_]; } \
+            else { dev_bloom_slot(wkey, ix.bloom2_words, &w_, &bmask); bword = ix.bloom2[w_]; }              \
+        }                                                                                                    \
+    }
+#define FWD_PUSH_OK() ((bword & bmask) == bmask)
 #define START_SMEM1()                                                                                        \
     {                                                                                                        \
         int s_ = QB(x);                                                                                      \
         c0 = ix.L2[s_] + 1; c2 = ix.L2[s_ + 1] - ix.L2[s_]; c1 = ix.L2[3 - s_] + 1; cinfo = x + 1;          \
         ncurr = 0; i = x + 1; curA = 1;                                                                      \
+        if (filt) {   /* the LH_BLOOM_K bases that end at x (positions before the read count as non-bases) */ \
+            uint32_t w0_, w1_, w2_;                                                                          \
+            Q8(x - 18, w0_) Q8(x - 10, w1_) Q8(x - 2, w2_)                                                   \
+            w2_ &= 0xfffu;                                                                                   \
+            uint32_t n0_ = w0_ & 0x44444444u, n1_ = w1_ & 0x44444444u, n2_ = w2_ & 0x444u;                   \
+            int last_ = n2_ ? x - 2 + ((31 - __clz((int)n2_)) >> 2) : n1_ ? x - 10 + ((31 - __clz((int)n1_)) >> 2) \
+                      : n0_ ? x - 18 + ((31 - __clz((int)n0_)) >> 2) : x - 19;   /* last non-base at or before x */ \
+            filt_from = last_ + 1 + LH_BLOOM_K;                                                              \
+            uint32_t t0_ = w0_ & 0x33333333u, t1_ = w1_ & 0x33333333u, t2_ = w2_ & 0x333u;                   \
+            t0_ = (t0_ | t0_ >> 2) & 0x0f0f0f0fu; t0_ = (t0_ | t0_ >> 4) & 0x00ff00ffu; t0_ = (t0_ | t0_ >> 8) & 0xffffu; \
+            t1_ = (t1_ | t1_ >> 2) & 0x0f0f0f0fu; t1_ = (t1_ | t1_ >> 4) & 0x00ff00ffu; t1_ = (t1_ | t1_ >> 8) & 0xffffu; \
+            t2_ = (t2_ | t2_ >> 2) & 0x0f0fu; t2_ = (t2_ | t2_ >> 4) & 0x3fu;                                \
+            wkey = (u64)t0_ | (u64)t1_ << 16 | (u64)t2_ << 32;                                               \
+        }                                                                                                    \
+        BLOOM_ISSUE()                                                                                        \
         FWD_ADVANCE()                                                                                        \
     }
     // pass 3: next base of the forward-only walk
@@ -343,14 +382,14 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
         if (st == S4_REQ_FWD) {
             if (ok.x2 != c2) {
                 ce = pe_pack(c0, c1, c2, cinfo);
-                if (ok.x2 < (u64)min_intv) st = S4_BWD_INIT;   // the interval is too small to be extended further: ce is the list's last entry
-                else CURR[(uint32_t)ncurr * T] = ce;
-                ncurr++;
+                if (ok.x2 < (u64)min_intv) { st = S4_BWD_INIT; ncurr++; }   // the interval is too small to be extended further: ce is the list's last entry
+                else if (FWD_PUSH_OK()) { CURR[(uint32_t)ncurr * T] = ce; ncurr++; }
             }
             if (st == S4_REQ_FWD) {
                 c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i;
-                if (runs && c2 == 1 && min_intv == 1) st = S4_FRUN_INIT;   // a single occurrence: follow it through the text
-                else FWD_ADVANCE()
+                wkey = wkey >> 2 | (u64)(3 - ec) << (2 * LH_BLOOM_K - 2);   // the base just matched enters the window
+                if (runs && c2 == 1 && min_intv == 1) st = S4_FRUN_INIT;   // a single occurrence: follow it through the text (it ends the list: no filter)
+                else { BLOOM_ISSUE() FWD_ADVANCE() }
             }
         } else if (st == S4_REQ_BWD) {
             if (ok.x2 < (u64)min_intv) {
@@ -408,6 +447,8 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
 #undef CURR
 #undef PREV
 #undef START_SMEM1
+#undef BLOOM_ISSUE
+#undef FWD_PUSH_OK
 #undef FWD_ADVANCE
 #undef P3_ADVANCE
 #undef BWD_ROW_BODY

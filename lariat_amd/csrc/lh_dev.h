@@ -96,6 +96,11 @@ struct DIndex {
     const uint32_t* tn;
     // the bi-interval of every 12-mer (packed like K1's list entries, 16 B each): bwt_seed_strategy1's walks start there
     const void* kmer12;
+    // sweep filters (k_smem4.h), only next to isa / tn: blocked Bloom filters (one 64-bit word, 4 bits per key) over the
+    // LH_BLOOM_K-mers of the text fwd||rev: bloom1 = every k-mer that occurs, bloom2 = every k-mer that occurs at least twice
+    const u64* bloom1;
+    const u64* bloom2;
+    uint32_t bloom1_words, bloom2_words;
     const u64* sa;           // sampled SA, sa[0] = -1
     const uint8_t* pac;      // 2-bit forward reference, MSB first
     const i64* contig_off;   // [n_contigs]
@@ -227,6 +232,17 @@ template <int K> __device__ __forceinline__ uint32_t dpp_quad_bcast(uint32_t v) 
 #endif
 template <int K> __device__ __forceinline__ u64 dpp_quad_bcast_u64(u64 v) { return (u64)dpp_quad_bcast<K>((uint32_t)(v >> 32)) << 32 | dpp_quad_bcast<K>((uint32_t)v); }
 __device__ __forceinline__ u64 dpp_ror8_u64(u64 v) { return (u64)dpp_ror8((uint32_t)(v >> 32)) << 32 | dpp_ror8((uint32_t)v); }
+
+// ------------------------------------------------------------------ k-mer membership filters
+#define LH_BLOOM_K 19   // = bwa's default min_seed_len: the filters are only consulted when opts.min_seed_len >= LH_BLOOM_K
+// key: base j of the k-mer (j = 0 the first one) at bits 2j..2j+1
+__device__ __forceinline__ void dev_bloom_slot(u64 key, uint32_t n_words, uint32_t* word, u64* mask) {
+    u64 h = key * 0x9E3779B97F4A7C15ull;
+    *word = __umulhi((uint32_t)(h >> 32), n_words);
+    uint32_t g = (uint32_t)(h >> 16) * 0x85EBCA6Bu;
+    g ^= g >> 15;
+    *mask = 1ull << (g & 63) | 1ull << ((g >> 6) & 63) | 1ull << ((g >> 12) & 63) | 1ull << ((g >> 18) & 63);
+}
 
 // ------------------------------------------------------------------ FM-index primitives (restated from BWA bwt.c)
 // packed per-base counts of the 16 symbols of w under the 2-bit-position mask `valid` (0x55555555 = all 16)
