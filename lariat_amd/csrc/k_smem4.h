@@ -71,10 +71,15 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
 #endif
-__global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+// MODE 0: the three passes of mem_collect_intv in one kernel; 1: passes 1 and 2 only; 2: pass 3 only, appended to the
+// intervals a MODE 1 launch left (pass 3 depends on the read alone, and the intervals are sorted afterwards: running it as
+// its own small kernel — a quarter of the instructions per turn, twice the waves — gives the same interval array).
+template <int MODE>
+__global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
                                                int32_t* __restrict__ next_read, DCounters* __restrict__ ctr) {
     __shared__ uint32_t qn[32 * 64];
+    constexpr bool DO12 = MODE != 2, DO3 = MODE != 1;
     const int lane = LANE();
     const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)lane;
     PEnt* const LA = slab + t;                                    // entry e of list A at LA[e * T]
@@ -94,7 +99,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
     const bool runs = ix.isa != nullptr;
     // sweep filter (see FWD_PUSH_OK): the key of the LH_BLOOM_K read bases that end where the current forward interval ends,
     // the filter word read for it, the bits it must have; filt_from = first interval end for which that window is all bases
-    const bool filt = ix.bloom1 != nullptr && o.min_seed_len >= LH_BLOOM_K;
+    const bool filt = DO12 && ix.bloom1 != nullptr && o.min_seed_len >= LH_BLOOM_K;
     u64 wkey = 0, bword = 0, bmask = 0;
     int filt_from = 0;
     unsigned n_ext_total = 0;
@@ -260,63 +265,64 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 r = rr; len = ln; rst = 0; on = 0; ovf = 0; p2mask = 0;
                 if (len > LH_MAXLEN) { rst |= LH_ST_TOO_LONG; len = 0; }
                 out = intv_out + (size_t)r * LH_MAX_INTV;
-                if (len >= o.min_seed_len) { x = 0; phase = 1; st = S4_P1_SCAN; }
+                if (!DO12) { on = n_intv[r]; rst |= status[r]; }   // continue behind the intervals of passes 1 and 2
+                if (len >= o.min_seed_len) { x = 0; phase = 1; st = DO12 ? S4_P1_SCAN : S4_P3_SCAN; }
                 else st = S4_READ_DONE;
             }
         }
         // ---- B. transitions between the loops of mem_collect_intv (rare per lane; the blocks are ordered so that the
         //         usual chains finish in one pass) ----
     if (st >= S4_FRUN_INIT) {   // unique runs: ONE step of their load / use chains per turn: a value read here is used in the next turn
-            if (st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; st = S4_FRUN_INIT2; }
-            else if (st == S4_FRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p + (i - x)) st = S4_REQ_FRUN; }
-            else if (st == S4_FRUN_END) { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }   // the reverse strand's copy of the match
-            else if (st == S4_FRUN_END2) {   // the unique interval closes the forward list (it is the list's last entry: kept in ce only)
+            if (DO12 && st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; st = S4_FRUN_INIT2; }
+            else if (DO12 && st == S4_FRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p + (i - x)) st = S4_REQ_FRUN; }
+            else if (DO12 && st == S4_FRUN_END) { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }   // the reverse strand's copy of the match
+            else if (DO12 && st == S4_FRUN_END2) {   // the unique interval closes the forward list (it is the list's last entry: kept in ce only)
                 c1 = ld64;
                 ce = pe_pack(c0, c1, c2, cinfo);
                 ncurr++;
                 st = S4_BWD_INIT;
             }
-            else if (st == S4_P3_JUMP) { pn = ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
-            else if (st == S4_P3_JUMP2) {   // as if the 11 bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
+            else if (DO3 && st == S4_P3_JUMP) { pn = ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
+            else if (DO3 && st == S4_P3_JUMP2) {   // as if the 11 bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
                 c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn);
                 n_ext_total += LH_KMER - 1;
                 i = x + LH_KMER;
                 P3_ADVANCE()
             }
-            else if (st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
-            else if (st == S4_BRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p - 8) st = S4_REQ_BRUN; }
-            else if (st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
-            else {   // S4_BRUN_END2: the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
+            else if (DO12 && st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
+            else if (DO12 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p - 8) st = S4_REQ_BRUN; }
+            else if (DO12 && st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
+            else if (DO12) {   // S4_BRUN_END2: the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
                 c0 = ld64;
                 if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
                 st = S4_SMEM_DONE;
             }
         }
         while (slow_turn && __any(st >= 8 && st < S4_FRUN_INIT)) {
-            if (st == S4_BWD_EMIT) {
+            if (DO12 && st == S4_BWD_EMIT) {
                 EMIT_MEM()
                 BWD_ADVANCE()
             }
-            if (st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
+            if (DO12 && st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
                 ret = cinfo; curA ^= 1; nprev = ncurr; rev = 1; have_mem = 0; last_mem_start = 0; i = x - 1;
                 BWD_ROW_BODY()
             }
-            if (st == S4_BWD_EMIT0) {
+            if (DO12 && st == S4_BWD_EMIT0) {
                 if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
                 st = S4_SMEM_DONE;
             }
-            if (st == S4_SMEM_DONE) {
+            if (DO12 && st == S4_SMEM_DONE) {
                 if (phase == 1) { x = ret; st = S4_P1_SCAN; }
                 else st = S4_P2_NEXT;
             }
-            if (st == S4_P1_SCAN) {   // first pass: all SMEMs
+            if (DO12 && st == S4_P1_SCAN) {   // first pass: all SMEMs
                 while (x < len && QB(x) > 3) ++x;
                 if (x >= len) { phase = 2; st = S4_P2_NEXT; }
                 else { min_intv = 1; START_SMEM1() }
             }
-            if (st == S4_P2_NEXT) {   // second pass: re-seed inside long, rare SMEMs of the first pass
+            if (DO12 && st == S4_P2_NEXT) {   // second pass: re-seed inside long, rare SMEMs of the first pass
                 st = S4_P3_SCAN; x = 0;
-                if (o.max_mem_intv <= 0) st = S4_READ_DONE;
+                if (!DO3 || o.max_mem_intv <= 0) st = S4_READ_DONE;
                 while (p2mask) {
                     int k = __ffsll((unsigned long long)p2mask) - 1;
                     p2mask &= p2mask - 1;
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                     break;
                 }
             }
-            while (st == S4_P3_SCAN) {   // third pass: LAST-like forward-only seeds (bwt_seed_strategy1)
+            while (DO3 && st == S4_P3_SCAN) {   // third pass: LAST-like forward-only seeds (bwt_seed_strategy1)
                 while (x < len && QB(x) > 3) ++x;
                 if (x >= len) st = S4_READ_DONE;
                 else {
@@ -379,7 +385,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
             n_ext_total++;
         }
         // ---- E. bookkeeping of the loop the lane is in, and its next request ----
-        if (st == S4_REQ_FWD) {
+        if (DO12 && st == S4_REQ_FWD) {
             if (ok.x2 != c2) {
                 ce = pe_pack(c0, c1, c2, cinfo);
                 if (ok.x2 < (u64)min_intv) { st = S4_BWD_INIT; ncurr++; }   // the interval is too small to be extended further: ce is the list's last entry
@@ -391,7 +397,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 if (runs && c2 == 1 && min_intv == 1) st = S4_FRUN_INIT;   // a single occurrence: follow it through the text (it ends the list: no filter)
                 else { BLOOM_ISSUE() FWD_ADVANCE() }
             }
-        } else if (st == S4_REQ_BWD) {
+        } else if (DO12 && st == S4_REQ_BWD) {
             if (ok.x2 < (u64)min_intv) {
                 if (ncurr == 0 && (!have_mem || i + 1 < last_mem_start)) st = S4_BWD_EMIT;   // no longer match survived, not contained in the previous MEM
             } else if (ncurr == 0 || ok.x2 != last_size) {
@@ -402,7 +408,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 last_size = ok.x2;
             }
             if (st == S4_REQ_BWD) BWD_ADVANCE()
-        } else if (st == S4_REQ_FRUN) {   // forward unique run: up to eight successful bwt_extend steps at once
+        } else if (DO12 && st == S4_REQ_FRUN) {   // forward unique run: up to eight successful bwt_extend steps at once
             uint32_t q8, xr;
             Q8(i, q8)
             xr = q8 ^ T8();
@@ -415,7 +421,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 cinfo = i;
                 st = S4_FRUN_END;
             }
-        } else if (st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
+        } else if (DO12 && st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
             uint32_t q8, xr;
             Q8(i - 7, q8)
             xr = q8 ^ T8();
@@ -427,7 +433,7 @@ __global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_smem4(DIndex ix, DOpts o
                 if (i >= 0 && QB(i) <= 3) n_ext_total++;   // the bwt_extend that returned an empty interval
                 st = S4_BRUN_END;
             }
-        } else if (st == S4_REQ_P3) {
+        } else if (DO3 && st == S4_REQ_P3) {
             if (ok.x2 < (u64)o.max_mem_intv && i - x >= o.min_seed_len) {
                 if (ok.x2 > 0) {
                     if (on >= LH_MAX_INTV) ovf = 1;

@@ -34,3 +34,4 @@ for i in range(a.reps):
     ctx.align_resident(o)
     dt = time.time() - t
     print("rep %d: %.1f ms  %.0f pairs/s  %s" % (i, dt * 1e3, rs.n_pairs / dt, ["%s=%.2f" % x for x in ctx.timings()]), flush=True)
+print("counters", ctx.download().counters, flush=True)
