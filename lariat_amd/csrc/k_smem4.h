@@ -71,15 +71,16 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
 #endif
-// MODE 0: the three passes of mem_collect_intv in one kernel; 1: passes 1 and 2 only; 2: pass 3 only, appended to the
-// intervals a MODE 1 launch left (pass 3 depends on the read alone, and the intervals are sorted afterwards: running it as
+// MODE 0: the three passes of mem_collect_intv in one kernel; 1: passes 1 and 2; 3: pass 1; 4: pass 2 (re-seeding inside the
+// long SMEMs pass 1 left, recognised from the stored intervals); 2: pass 3 only, appended to the
+// intervals the earlier launches left (pass 3 depends on the read alone, and the intervals are sorted afterwards: running it as
 // its own small kernel — a quarter of the instructions per turn, twice the waves — gives the same interval array).
 template <int MODE>
 __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
                                                int32_t* __restrict__ next_read, DCounters* __restrict__ ctr) {
     __shared__ uint32_t qn[32 * 64];
-    constexpr bool DO12 = MODE != 2, DO3 = MODE != 1;
+    constexpr bool DO1 = MODE == 0 || MODE == 1 || MODE == 3, DO2 = MODE == 0 || MODE == 1 || MODE == 4, DO12 = DO1 || DO2, DO3 = MODE == 0 || MODE == 2;
     const int lane = LANE();
     const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)lane;
     PEnt* const LA = slab + t;                                    // entry e of list A at LA[e * T]
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     i64 run_p = 0;            // unique run: text position of the match's first base
     u64 ld64 = 0;             // a suffix-array / inverse-array value in flight
     uint32_t tw_lo = 0, tw_hi = 0, tw_sh = 0;   // the text words of the run's current 8-base window
-    const bool runs = ix.isa != nullptr;
+    const bool runs = DO1 && ix.isa != nullptr;   // unique runs need min_intv == 1: pass 1 only
     // sweep filter (see FWD_PUSH_OK): the key of the LH_BLOOM_K read bases that end where the current forward interval ends,
     // the filter word read for it, the bits it must have; filt_from = first interval end for which that window is all bases
     const bool filt = DO12 && ix.bloom1 != nullptr && o.min_seed_len >= LH_BLOOM_K;
@@ -265,18 +266,24 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 r = rr; len = ln; rst = 0; on = 0; ovf = 0; p2mask = 0;
                 if (len > LH_MAXLEN) { rst |= LH_ST_TOO_LONG; len = 0; }
                 out = intv_out + (size_t)r * LH_MAX_INTV;
-                if (!DO12) { on = n_intv[r]; rst |= status[r]; }   // continue behind the intervals of passes 1 and 2
-                if (len >= o.min_seed_len) { x = 0; phase = 1; st = DO12 ? S4_P1_SCAN : S4_P3_SCAN; }
+                if (!DO1) { on = n_intv[r]; rst |= status[r]; }   // continue behind the intervals of the earlier passes
+                if (len >= o.min_seed_len) { x = 0; phase = DO1 ? 1 : 2; st = DO1 ? S4_P1_SCAN : DO2 ? S4_P2_NEXT : S4_P3_SCAN; }
                 else st = S4_READ_DONE;
+                if (!DO1 && DO2 && st == S4_P2_NEXT) {   // the long, rare SMEMs among pass 1's intervals (EMIT_MEM's test)
+                    for (int k = 0; k < on; ++k) {
+                        DIntv p = out[k];
+                        if ((int)(uint32_t)p.info - (int)(p.info >> 32) >= split_len && p.x2 <= (u64)o.split_width) p2mask |= 1ull << k;
+                    }
+                }
             }
         }
         // ---- B. transitions between the loops of mem_collect_intv (rare per lane; the blocks are ordered so that the
         //         usual chains finish in one pass) ----
     if (st >= S4_FRUN_INIT) {   // unique runs: ONE step of their load / use chains per turn: a value read here is used in the next turn
-            if (DO12 && st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; st = S4_FRUN_INIT2; }
-            else if (DO12 && st == S4_FRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p + (i - x)) st = S4_REQ_FRUN; }
-            else if (DO12 && st == S4_FRUN_END) { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }   // the reverse strand's copy of the match
-            else if (DO12 && st == S4_FRUN_END2) {   // the unique interval closes the forward list (it is the list's last entry: kept in ce only)
+            if (DO1 && st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; st = S4_FRUN_INIT2; }
+            else if (DO1 && st == S4_FRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p + (i - x)) st = S4_REQ_FRUN; }
+            else if (DO1 && st == S4_FRUN_END) { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }   // the reverse strand's copy of the match
+            else if (DO1 && st == S4_FRUN_END2) {   // the unique interval closes the forward list (it is the list's last entry: kept in ce only)
                 c1 = ld64;
                 ce = pe_pack(c0, c1, c2, cinfo);
                 ncurr++;
@@ -289,10 +296,10 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 i = x + LH_KMER;
                 P3_ADVANCE()
             }
-            else if (DO12 && st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
-            else if (DO12 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p - 8) st = S4_REQ_BRUN; }
-            else if (DO12 && st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
-            else if (DO12) {   // S4_BRUN_END2: the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
+            else if (DO1 && st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
+            else if (DO1 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p - 8) st = S4_REQ_BRUN; }
+            else if (DO1 && st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
+            else if (DO1) {   // S4_BRUN_END2: the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
                 c0 = ld64;
                 if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
                 st = S4_SMEM_DONE;
@@ -315,12 +322,12 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 if (phase == 1) { x = ret; st = S4_P1_SCAN; }
                 else st = S4_P2_NEXT;
             }
-            if (DO12 && st == S4_P1_SCAN) {   // first pass: all SMEMs
+            if (DO1 && st == S4_P1_SCAN) {   // first pass: all SMEMs
                 while (x < len && QB(x) > 3) ++x;
-                if (x >= len) { phase = 2; st = S4_P2_NEXT; }
+                if (x >= len) { phase = 2; st = DO2 ? S4_P2_NEXT : S4_READ_DONE; }
                 else { min_intv = 1; START_SMEM1() }
             }
-            if (DO12 && st == S4_P2_NEXT) {   // second pass: re-seed inside long, rare SMEMs of the first pass
+            if (DO2 && st == S4_P2_NEXT) {   // second pass: re-seed inside long, rare SMEMs of the first pass
                 st = S4_P3_SCAN; x = 0;
                 if (!DO3 || o.max_mem_intv <= 0) st = S4_READ_DONE;
                 while (p2mask) {
@@ -408,7 +415,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 last_size = ok.x2;
             }
             if (st == S4_REQ_BWD) BWD_ADVANCE()
-        } else if (DO12 && st == S4_REQ_FRUN) {   // forward unique run: up to eight successful bwt_extend steps at once
+        } else if (DO1 && st == S4_REQ_FRUN) {   // forward unique run: up to eight successful bwt_extend steps at once
             uint32_t q8, xr;
             Q8(i, q8)
             xr = q8 ^ T8();
@@ -421,7 +428,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 cinfo = i;
                 st = S4_FRUN_END;
             }
-        } else if (DO12 && st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
+        } else if (DO1 && st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
             uint32_t q8, xr;
             Q8(i - 7, q8)
             xr = q8 ^ T8();
