@@ -202,6 +202,10 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
 // 25 = no DP expected but >= 64 columns (LDS class 128 in case a later extension needs one); 26..33 < 64 columns; 34 = no DP
 // expected, < 64 columns
 #define LH_EXT_PRIMARY 35
+#define LH_EXT_HEAVY_COLS 32     // a full-band extension of this many query columns or more is "heavy" for the lane kernel
+#ifndef LH_NARROW_MAX_LOSS
+#define LH_NARROW_MAX_LOSS 26    // diagonal loss up to which k_extend_lane tries its narrow band (5 mismatches with the default scoring)
+#endif
 __device__ __forceinline__ int lh_ext_bucket(int nseeds, int longest, int cheap) {
     if (nseeds > LH_EXT_COMPLEX_SEEDS) return 0;
     int L = longest >> 3 < 31 ? longest >> 3 : 31;
@@ -436,7 +440,10 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
                 }
                 // Is the first seed's extension provably ungapped on both sides (k_extend2.h: diagonal penalties below one gap's
                 // cost)?  Such reads usually need no DP at all; they get their own bucket so that whole waves skip it.
-                int cheap = 0;
+                // And is one of them long and outside what k_extend_lane's narrow band covers (diagonal loss of LH_NARROW_MAX_LOSS or
+                // more, e.g. behind an indel)?  One full-band DP keeps a whole wave of the lane kernel busy for ~1 ms: those reads go
+                // to the wave-per-read kernel with the complex ones.  Routing only: K4 decides again from the same scan.
+                int cheap = 0, heavy = 0;
                 if (have_top && nseeds <= LH_EXT_COMPLEX_SEEDS) {
                     const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
                     const uint8_t* q = seq + seq_off[r];
@@ -445,18 +452,21 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
                         int qlen = side ? l_query - top.qbeg - top.len : top.qbeg;
                         i64 tlen = side ? top_r1 - (top.rbeg + top.len) : top.rbeg - top_r0;
                         if (qlen == 0) continue;
-                        if (tlen < qlen) { cheap = 0; break; }
+                        if (tlen < qlen) { cheap = 0; heavy |= qlen >= LH_EXT_HEAVY_COLS; continue; }
                         LaneTgt tg;
                         tg.init(ix, side ? top.rbeg + top.len : top.rbeg - 1, side ? 1 : -1);
-                        int P = 0;
+                        int P = 0, run = top.len * o.a;
                         for (int k = 0; k < qlen; ++k) {
                             int qv = q[side ? top.qbeg + top.len + k : top.qbeg - 1 - k], tb = tg.base(k);
-                            P += qv > 3 ? o.a + 1 : (tb == qv ? 0 : o.a + o.b);
-                            if (P >= thr) { cheap = 0; break; }
+                            int loss = qv > 3 ? o.a + 1 : (tb == qv ? 0 : o.a + o.b);
+                            P += loss; run += o.a - loss;
+                            if (P >= thr) cheap = 0;
+                            if (P >= LH_NARROW_MAX_LOSS || run <= 0) { heavy |= qlen >= LH_EXT_HEAVY_COLS; break; }
+                            if (!cheap && qlen < LH_EXT_HEAVY_COLS) break;   // nothing left to learn from a short side
                         }
                     }
                 }
-                int prim = lh_ext_bucket(nseeds, longest, cheap);
+                int prim = lh_ext_bucket(heavy ? LH_EXT_COMPLEX_SEEDS + 1 : nseeds, longest, cheap);
                 int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
                 ext_key[r] = prim * LH_EXT_SUB + sub;
                 nch_done = m;

@@ -23,7 +23,7 @@
 #define LH_EXT_BINS (LH_EXT_PRIMARY * LH_EXT_SUB)
 struct DExtBins {
     int32_t count[LH_EXT_BINS], cursor[LH_EXT_BINS];
-    int32_t range[12];   // [first,last) pairs into the bucket-sorted order: complex, 256, 128, 64 columns; range[8..9] = the deferred list
+    int32_t range[16];   // [first,last) pairs into the bucket-sorted order: complex, 256, 128, 64 columns; range[8..9] = the deferred list
 };
 
 // ---- pre-pass, one wave per read: per chain the reference window [rmax0,rmax1) and the seed order; per read the bucket ----
@@ -112,10 +112,13 @@ __global__ void __launch_bounds__(64) k_ext_offsets(DExtBins* __restrict__ bins)
             if (b == 0) bins->range[0] = acc;
             if (b == 1 * LH_EXT_SUB) { bins->range[1] = acc; bins->range[2] = acc; }
             if (b == 17 * LH_EXT_SUB) { bins->range[3] = acc; bins->range[4] = acc; }
-            if (b == 26 * LH_EXT_SUB) { bins->range[5] = acc; bins->range[6] = acc; }   // class 128 runs buckets 17..25, class 64 buckets 26..34
+            // class 128 runs buckets 17..24, class 64 buckets 26..33; buckets 25 and 34 (no DP expected) run without LDS: range[10..13]
+            if (b == 25 * LH_EXT_SUB) { bins->range[5] = acc; bins->range[10] = acc; }
+            if (b == 26 * LH_EXT_SUB) { bins->range[11] = acc; bins->range[6] = acc; }
+            if (b == 34 * LH_EXT_SUB) { bins->range[7] = acc; bins->range[12] = acc; }
             bins->cursor[b] = acc; acc += bins->count[b];
         }
-        bins->range[7] = acc; bins->range[8] = 0; bins->range[9] = 0;
+        bins->range[13] = acc; bins->range[8] = 0; bins->range[9] = 0;
     }
 }
 __global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins, int32_t* __restrict__ order) {
@@ -143,11 +146,19 @@ __global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t*
 #define EH_PACK(q, e, h) ((uint32_t)(q) << 29 | (uint32_t)(e) << 16 | (uint32_t)(h))
 
 // ksw_extend2 for one lane.  Column j's query base is q[qoff + qstep*j]; row i's target base is tg.base(i).
+#ifdef LH_K4_PROF   // development aid: wave-clock ticks per part of k_extend_lane, summed over lanes (lh_dbg[24 + part], in units of 2^16)
+#define K4_T0() long long k4t_ = wall_clock64();
+#define K4_T(s_) { long long n_ = wall_clock64(); atomicAdd(&lh_dbg[24 + (s_)], (int)((n_ - k4t_) >> 6)); k4t_ = n_; }
+#else
+#define K4_T0()
+#define K4_T(s_)
+#endif
 __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t* q, uint32_t* ehl, int lane, int qoff, int qstep, int qlen, LaneTgt& tg, int tlen, int w,
                                                    int end_bonus, int zdrop, int h0, u64* cells) {
     const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
 #define EHW(j_) ehl[(j_) * 64 + lane]
+    K4_T0()
     {   // fill the first row
         int hprev = h0;
         for (int j = 0; j <= qlen; ++j) {
@@ -161,6 +172,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
             EHW(j) = EH_PACK(qv > 4 ? 4 : qv, 0, v);
         }
     }
+    K4_T(1)
     int maxsc = a_ > 0 ? a_ : 0;   // max entry of mat (a, -b, -1)
     int max_ins = (int)((double)(qlen * maxsc + end_bonus - o_ins) / e_ins + 1.);
     max_ins = max_ins > 1 ? max_ins : 1;
@@ -222,6 +234,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
         end = j + 2 < qlen ? j + 2 : qlen;
     }
 #undef EHW
+    K4_T(2)
     if (cells) *cells += ncell;
     ExtRes r;
     r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
@@ -238,7 +251,7 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                                                      const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
                                                      const int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, const i64* __restrict__ chain_rmax,
                                                      const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs, DCounters* __restrict__ ctr) {
-    __shared__ uint32_t ehl[EHW_ * 64];
+    __shared__ uint32_t ehl[EHW_ ? EHW_ * 64 : 1];   // EHW_ = 0: no DP at all, a read that needs one is deferred
     const int lane = LANE();
     int first = range[0], last = range[1];
     int g = first + blockIdx.x * 64 + lane;
@@ -249,6 +262,9 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
     if (r >= 0) { off = seq_off[r]; l_query = (int)(seq_off[r + 1] - off); if (l_query > LH_MAXLEN) l_query = 0; }
     const uint8_t* q = seq + off;
     u64 cells = 0;
+#ifdef LH_K4_PROF
+    long long k4all_ = wall_clock64();
+#endif
     if (r >= 0) {
         i64 base = seed_off[r];
         DReg* av = regs + reg_off[r];
@@ -315,9 +331,18 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                     // come from the diagonal's running score (first maximum), max_off is 0, the band is not retried, and
                     // gscore = the diagonal's last value at gtle = qlen (all other cells of the last column are smaller).
                     // With the default scoring that is any extension with at most one mismatch: most of them.
-                    int proven = 0;
+                    // When the diagonal loses more than that, the DP is still run, but in a band that is provably wide enough:
+                    // a cell more than B off the diagonal is reached through a gap of more than B bases, so it stays below
+                    // h0 + (min(i,j)+1)*a - gap_cost(B+1); a cell inside the band whose value depends on such a cell went
+                    // through a second gap as well.  If the whole diagonal loses less than gap_cost(B+1) and never drops to 0,
+                    // all those cells are strictly below their row's diagonal cell (and below the diagonal's end in the last
+                    // column): row maxima, their columns, gscore / gtle and max_off of ksw_extend2(w) and of ksw_extend2(B)
+                    // are the same, zdrop (> the loss) cannot fire, the band is not retried.  The region keeps w = opt->w.
+                    int proven = 0, narrow = 0;
+                    K4_T0()
                     if (tlen >= qlen) {
                         const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
+                        const int p_cap = o.zdrop > 0 && o.zdrop < LH_NARROW_MAX_LOSS ? o.zdrop : LH_NARROW_MAX_LOSS;
                         LaneTgt tg;
                         tg.init(ix, tc0, tstep);
                         int P = 0, sc_run = h0, mx = h0, mxk = -1, k = 0;
@@ -325,23 +350,27 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                             int qv = q[qoff + qstep * k], tb = tg.base(k);
                             int sc = qv > 3 ? -1 : (tb == qv ? o.a : -o.b);
                             P += o.a - sc;
-                            if (P >= thr) break;
                             sc_run += sc;
+                            if (P >= p_cap || sc_run <= 0) break;
                             if (sc_run > mx) { mx = sc_run; mxk = k; }
                         }
-                        if (k == qlen) {
+                        if (k == qlen && P < thr) {
                             e.score = mx; e.qle = mxk + 1; e.tle = mxk + 1; e.gscore = sc_run; e.gtle = qlen; e.max_off = 0;
                             a.score = e.score;
                             proven = 1;
+                        } else if (k == qlen) {
+                            narrow = 1;
+                            while (o.o_ins + o.e_ins * (narrow + 1) <= P || o.o_del + o.e_del * (narrow + 1) <= P) ++narrow;
                         }
                     }
+                    K4_T(3)
                     if (!proven && qlen >= EHW_) { deferred = 1; break; }
                     for (int i = 0; i < 2 && !proven; ++i) {   // MAX_BAND_TRY
                         int prev = a.score;
                         aw = o.w << i;
                         LaneTgt tg;
                         tg.init(ix, tc0, tstep);
-                        e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells);
+                        e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, narrow && narrow < aw ? narrow : aw, bonus, o.zdrop, h0, &cells);
                         a.score = e.score;
                         if (a.score == prev || e.max_off < (aw >> 1) + (aw >> 2)) break;
                     }
@@ -371,6 +400,9 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
         if (!deferred) n_regs[r] = n_av;
         else { defer_list[atomicAdd(defer_count, 1)] = r; cells = 0; }   // the read is redone from scratch: its cells are counted there
     }
+#ifdef LH_K4_PROF
+    if (r >= 0 && EHW_ == 128) atomicAdd(&lh_dbg[24], (int)((wall_clock64() - k4all_) >> 6));
+#endif
     if (ctr) {
         uint32_t lo = (uint32_t)cells;   // < 2^32 cells per read
         u64 tot = (u64)(uint32_t)wave_sum_i32((int)(lo >> 16)) << 16;
