@@ -66,6 +66,16 @@ def test_candidates_synthetic(lib, oracle, seed, junk):
         del os.environ["LH_NO_SWEEP_FILTER"]
     helpers.assert_same_result(res_nf, ores, inference=False)
     assert res_nf.counters["n_ext"] == ores.counters["n_ext"]
+    # the three passes in ONE kernel (k_smem4_t<0>, what bench.py's reference-count pass launches): same results, same count
+    os.environ["LH_NO_SWEEP_FILTER"] = "1"
+    os.environ["LH_SMEM4_FUSED"] = "1"
+    try:
+        res_fu = ctx.align_barcodes(b, lib.opts(run_inference=0))
+    finally:
+        del os.environ["LH_NO_SWEEP_FILTER"]
+        del os.environ["LH_SMEM4_FUSED"]
+    helpers.assert_same_result(res_fu, ores, inference=False)
+    assert res_fu.counters["n_ext"] == ores.counters["n_ext"]
     # ext_cells counts the DP cells the device evaluated: extensions that are provably ungapped (k_extend2.h) skip their DP
     assert 0 < res.counters["ext_cells"] <= ores.counters["ext_cells"]
     # the suffix array is re-sampled densely on load (every row for a genome this small): no BWT walk is left in bwt_sa
