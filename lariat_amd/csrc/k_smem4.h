@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     ce.lo = ce.hi = pn.lo = pn.hi = 0;
     i64 run_p = 0;            // unique run: text position of the match's first base
     u64 ld64 = 0;             // a suffix-array / inverse-array value in flight
-    uint32_t tw_lo = 0, tw_hi = 0, tw_sh = 0;   // the text words of the run's current 8-base window
+    uint32_t tw0 = 0, tw1 = 0, tw2 = 0, tw_sh = 0;   // the text words of the run's current 16-base window
     const bool runs = DO1 && ix.isa != nullptr;   // unique runs need min_intv == 1: pass 1 only
     // sweep filter (see FWD_PUSH_OK): the key of the LH_BLOOM_K read bases that end where the current forward interval ends,
     // the filter word read for it, the bits it must have; filt_from = first interval end for which that window is all bases
@@ -113,9 +113,11 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         uint32_t hi_ = (w_ + 1 >= 0 && w_ + 1 < 32) ? qn[(w_ + 1) * 64 + lane] : 0x44444444u;                \
         out_ = sh_ ? (lo_ >> sh_) | (hi_ << (32 - sh_)) : lo_;                                               \
     }
-    // issue the reads of the eight text bases from position p_ on (p_ >= -8); T8() assembles them once they have arrived
-#define T8_LOAD(p_) { i64 w_ = (p_) >> 3; tw_sh = (uint32_t)((p_) & 7) * 4; tw_lo = ix.tn[w_]; tw_hi = ix.tn[w_ + 1]; }
-#define T8() (tw_sh ? (tw_lo >> tw_sh) | (tw_hi << (32 - tw_sh)) : tw_lo)
+    // issue the reads of the sixteen text bases from position p_ on (p_ >= -16); T16_A() / T16_B() assemble the first / the second
+    // eight once they have arrived
+#define T16_LOAD(p_) { i64 w_ = (p_) >> 3; tw_sh = (uint32_t)((p_) & 7) * 4; tw0 = ix.tn[w_]; tw1 = ix.tn[w_ + 1]; tw2 = ix.tn[w_ + 2]; }
+#define T16_A() (tw_sh ? (tw0 >> tw_sh) | (tw1 << (32 - tw_sh)) : tw0)
+#define T16_B() (tw_sh ? (tw1 >> tw_sh) | (tw2 << (32 - tw_sh)) : tw1)
 #define CURR (curA ? LA : LB)
 #define PREV (curA ? LB : LA)
     // forward extension: the next base decides between another bwt_extend and the end of the forward list
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         //         usual chains finish in one pass) ----
     if (st >= S4_FRUN_INIT) {   // unique runs: ONE step of their load / use chains per turn: a value read here is used in the next turn
             if (DO1 && st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; st = S4_FRUN_INIT2; }
-            else if (DO1 && st == S4_FRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p + (i - x)) st = S4_REQ_FRUN; }
+            else if (DO1 && st == S4_FRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p + (i - x)) st = S4_REQ_FRUN; }
             else if (DO1 && st == S4_FRUN_END) { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }   // the reverse strand's copy of the match
             else if (DO1 && st == S4_FRUN_END2) {   // the unique interval closes the forward list (it is the list's last entry: kept in ce only)
                 c1 = ld64;
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 P3_ADVANCE()
             }
             else if (DO1 && st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
-            else if (DO1 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T8_LOAD(run_p - 8) st = S4_REQ_BRUN; }
+            else if (DO1 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }
             else if (DO1 && st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
             else if (DO1) {   // S4_BRUN_END2: the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
                 c0 = ld64;
@@ -381,6 +383,13 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         // ---- D. the shared program point: one bwt_extend per requesting lane ----
         DIntv ok;
         ok.x0 = ok.x1 = ok.x2 = ok.info = 0;
+#ifdef LH_SMEM_TURNS   // development aid: lanes per state class over all turns of the pass-1 instance (lh_dbg[8..15])
+        if (MODE == 3) {
+            int cls_ = st == S4_REQ_FWD ? 0 : st == S4_REQ_BWD ? 1 : st == S4_REQ_FRUN ? 2 : st == S4_REQ_BRUN ? 3 : st >= S4_FRUN_INIT ? 4 : st >= 8 ? 5 : 6;
+            for (int kk_ = 0; kk_ < 7; ++kk_) { int n_ = (int)__popcll(__ballot(cls_ == kk_)); if (lane == 0 && n_) atomicAdd(&lh_dbg[8 + kk_], n_); }
+            if (lane == 0) atomicAdd(&lh_dbg[15], 1);
+        }
+#endif
 #ifdef LH_SMEM_PROF   // development aid: FM-index extensions actually performed, by loop (lh_dbg[16..19] in units of 1024)
         { int k_ = st == S4_REQ_FWD ? (phase == 1 ? 16 : 18) : st == S4_REQ_BWD ? (phase == 1 ? 17 : 18) : st == S4_REQ_P3 ? 19 : -1;
           for (int kk_ = 16; kk_ < 20; ++kk_) { int n_ = (int)__popcll(__ballot(k_ == kk_)); if (lane == 0 && n_) atomicAdd(&lh_dbg[kk_ + 4], n_); } }
@@ -415,27 +424,29 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 last_size = ok.x2;
             }
             if (st == S4_REQ_BWD) BWD_ADVANCE()
-        } else if (DO1 && st == S4_REQ_FRUN) {   // forward unique run: up to eight successful bwt_extend steps at once
-            uint32_t q8, xr;
-            Q8(i, q8)
-            xr = q8 ^ T8();
-            int n = xr ? (__ffs((int)xr) - 1) >> 2 : 8;
+        } else if (DO1 && st == S4_REQ_FRUN) {   // forward unique run: up to sixteen successful bwt_extend steps at once
+            uint32_t qa, qb;
+            Q8(i, qa)
+            Q8(i + 8, qb)
+            uint32_t xa = qa ^ T16_A(), xb = qb ^ T16_B();
+            int n = xa ? (__ffs((int)xa) - 1) >> 2 : 8 + (xb ? (__ffs((int)xb) - 1) >> 2 : 8);
             n_ext_total += (unsigned)n;
             i += n;
-            if (n == 8) T8_LOAD(run_p + (i - x))
+            if (n == 16) T16_LOAD(run_p + (i - x))
             else {   // read exhausted, ambiguous base, text exhausted or a mismatch: the run's interval is the forward list's last entry
                 if (i < len && QB(i) <= 3) n_ext_total++;   // the bwt_extend that returned an empty interval
                 cinfo = i;
                 st = S4_FRUN_END;
             }
         } else if (DO1 && st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
-            uint32_t q8, xr;
-            Q8(i - 7, q8)
-            xr = q8 ^ T8();
-            int n = xr ? __clz((int)xr) >> 2 : 8;
+            uint32_t qa, qb;
+            Q8(i - 15, qa)
+            Q8(i - 7, qb)
+            uint32_t xa = qa ^ T16_A(), xb = qb ^ T16_B();
+            int n = xb ? __clz((int)xb) >> 2 : 8 + (xa ? __clz((int)xa) >> 2 : 8);
             n_ext_total += (unsigned)n;
             i -= n; run_p -= n;
-            if (n == 8) T8_LOAD(run_p - 8)
+            if (n == 16) T16_LOAD(run_p - 16)
             else {
                 if (i >= 0 && QB(i) <= 3) n_ext_total++;   // the bwt_extend that returned an empty interval
                 st = S4_BRUN_END;
@@ -455,8 +466,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     }
 #undef QB
 #undef Q8
-#undef T8_LOAD
-#undef T8
+#undef T16_LOAD
+#undef T16_A
+#undef T16_B
 #undef CURR
 #undef PREV
 #undef START_SMEM1

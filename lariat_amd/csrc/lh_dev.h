@@ -90,7 +90,7 @@ struct DIndex {
     const u64* sb;           // absolute counts at every 2^sb_shift-th symbol (the u32 counts are relative to them); null if there is one super-block
     int32_t sb_shift;        // 31 (LH_SB_SHIFT overrides it for tests)
     // only with a fully resident suffix array (sa_intv == 1), else null: the inverse suffix array and the text fwd||rev with 4 bits
-    // per base (8 per word, base p at bits 4*(p&7) of word p>>3; padded with 0xF, one word before and two after).  K1 uses them
+    // per base (8 per word, base p at bits 4*(p&7) of word p>>3; padded with 0xF, two words before and three after).  K1 uses them
     // to follow a UNIQUE match through the text instead of through the FM-index (k_smem4.h).
     const u64* isa;
     const uint32_t* tn;
