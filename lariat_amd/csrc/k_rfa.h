@@ -359,7 +359,33 @@ __global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const 
         WAVE_SYNC();
         RFA_T(2)
         // sort.Sort(ByPosition) per contig (lariat.go:1545-1547), one lane per contig; keys staged in LDS when they fit
-        if (NCf <= LH_RFA_SORT_LDS) {
+        if (NCf <= LH_RFA_SORT_LDS && ncont <= 8) {
+            // Few contigs: the wave sorts one contig at a time by ranking (every lane counts the smaller keys of its elements).
+            // Go's sort is unstable, but with all keys different there is only one sorted order; a contig with two equal
+            // positions is sorted again by the serial restatement of Go's algorithm.
+            for (int i = lane; i < NCf; i += 64) { sidx[i] = T.plist[i]; spos[i] = R.pos[c_lo + T.plist[i]]; }
+            WAVE_SYNC();
+            for (int k = 0; k < ncont; ++k) {
+                int b0 = T.coff[k], n = T.coff[k + 1] - b0;
+                i64* kp = spos + b0;
+                int32_t* ip = sidx + b0;
+                int tie = 0;
+                for (int e = lane; e < n; e += 64) {
+                    i64 key = kp[e];
+                    int rank = 0;
+                    for (int j = 0; j < n; ++j) { i64 kj = kp[j]; rank += kj < key; tie |= (kj == key) & (j != e); }
+                    T.plist[b0 + rank] = ip[e];
+                }
+                if (__any(tie)) {
+                    WAVE_SYNC();
+                    if (lane == 0)
+                        dev_gosort(n, [&](int i, int j) { return kp[i] < kp[j]; },
+                                   [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; });
+                    WAVE_SYNC();
+                    for (int e = lane; e < n; e += 64) T.plist[b0 + e] = ip[e];
+                }
+            }
+        } else if (NCf <= LH_RFA_SORT_LDS) {
             for (int i = lane; i < NCf; i += 64) { sidx[i] = T.plist[i]; spos[i] = R.pos[c_lo + T.plist[i]]; }
             WAVE_SYNC();
             for (int k = lane; k < ncont; k += 64) {
