@@ -27,7 +27,7 @@ import numpy as np
 
 # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB -> B), collected separately and committed
 # under profiles/ (see DESIGN.md section 4 for the calibration of FETCH_SIZE on this access pattern); None = not measured.
-TRAFFIC = {"k_smem3": (1.455e8 + 5.255e7) * 1024.0, "k_smem4": (1.269e7 + 2.56e6 + 8.322e6 + 1.257e6 + 1.141e5 + 4.325e5) * 1024.0}   # FETCH_SIZE + WRITE_SIZE (KB) of the three K1 launches, profiles/r01_pmc_summary_v9.txt
+TRAFFIC = {"k_smem3": (1.455e8 + 5.255e7) * 1024.0, "k_smem4": (1.204e7 + 2.556e6 + 8.317e6 + 1.26e6 + 1.172e5 + 4.328e5) * 1024.0}   # FETCH_SIZE + WRITE_SIZE (KB) of the three K1 launches, profiles/r01_pmc_summary_v10.txt
 
 
 def main():

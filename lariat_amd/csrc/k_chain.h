@@ -466,6 +466,9 @@ __global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_rea
                         }
                     }
                 }
+                #ifdef LH_EXT_MULTI_TO_WAVE
+                { int nz_ = 0; for (int ci = 0; ci < m; ++ci) nz_ += chains[base + ci].n > 0; heavy |= nz_ >= 2; }
+#endif
                 int prim = lh_ext_bucket(heavy ? LH_EXT_COMPLEX_SEEDS + 1 : nseeds, longest, cheap);
                 int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
                 ext_key[r] = prim * LH_EXT_SUB + sub;

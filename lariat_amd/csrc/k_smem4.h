@@ -66,7 +66,7 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define LH_KMER 12
 
 #ifndef LH_SLOW_BATCH
-#define LH_SLOW_BATCH 8
+#define LH_SLOW_BATCH 4
 #endif
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
