@@ -1,6 +1,6 @@
 """development aid: the k_rfa slab-overflow path on the GPU with per-launch logging (LH_DEBUG_SYNC=1)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ["LH_RFA_SLAB_KB"] = os.environ.get("LH_RFA_SLAB_KB", "8")
 import helpers, oracle_py

@@ -1,7 +1,7 @@
 """bit-exact comparison of the HIP path with the oracle at bench scale (BASELINE.json configs[1] shape): every candidate field,
 CIGAR, mismatch locus, RFA pick, MAPQ (development aid; the pytest suite compares at sizes the oracle finishes in seconds)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import helpers, oracle_py

@@ -1,7 +1,7 @@
 """differential fuzzing of the HIP path against the oracle over random genomes / read sets / options (development aid; the
 pytest suite holds the fixed cases).  Stops at the first difference and prints the seed that reproduces it."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import helpers, oracle_py

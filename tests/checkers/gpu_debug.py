@@ -1,6 +1,6 @@
 """development aid: run one synthetic case through the HIP path with per-kernel syncs, compare with the oracle"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import helpers, oracle_py

@@ -1,6 +1,6 @@
 """host-side throughput of the 9-line FASTQ reader (lh_ingest_*) against the Python restatement of reader.go"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 from lariat_amd import capi, synth

@@ -126,7 +126,7 @@ def test_long_noisy_reads(lib, oracle):
 
 def test_pools_grow_on_demand(lib, oracle):
     """a repeat-dense 62 kb genome gives far more than the 32 seeds / 6 candidates per read the pools start with: the seed,
-    region and candidate pools are re-sized from the device-side totals instead of failing (found by tools/fuzz_gpu.py, seed 2892)"""
+    region and candidate pools are re-sized from the device-side totals instead of failing (found by tests/checkers/fuzz_gpu.py, seed 2892)"""
     from lariat_amd import synth
     seed = 2892
     rng = np.random.default_rng(seed)
