@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(64) k_ext_offsets(DExtBins* __restrict__ bins)
             if (b == 34 * LH_EXT_SUB) { bins->range[7] = acc; bins->range[12] = acc; }
             bins->cursor[b] = acc; acc += bins->count[b];
         }
-        bins->range[13] = acc; bins->range[8] = 0; bins->range[9] = 0;
+        bins->range[13] = acc; bins->range[8] = 0; bins->range[9] = 0; bins->range[14] = 0; bins->range[15] = 0;   // [14..15]: the no-DP class's own deferred list
     }
 }
 __global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins, int32_t* __restrict__ order) {
