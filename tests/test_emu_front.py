@@ -87,3 +87,28 @@ def test_emu_long_noisy_reads(emu, oracle):
     b = helpers.batch_of(rs)
     res = idx.context(rs.n_pairs).align_barcodes(b)
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
+
+
+def test_emu_k1_launch_variants_and_sweep_filter(emu, oracle, monkeypatch):
+    """K1 as three launches (default), two (LH_SMEM4_P12) or one (LH_SMEM4_FUSED), with and without the sweep filter: the same
+    intervals / seeds / chains as the oracle every time; the filter executes fewer bwt_extend calls, without it the count is
+    the reference's"""
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=2, pairs=25, junk=0.05, seed=41)
+    rs.seq[np.arange(7, len(rs.seq), 211)] = 4   # ambiguous bases: the filter's window logic
+    b = helpers.batch_of(rs)
+    want = oidx.stage_dump(b)
+    want_ext = oidx.align_barcodes(b, oracle.opts(run_inference=0)).counters["n_ext"]
+    ctx = idx.context(rs.n_pairs)
+    seen = {}
+    for env in ({}, {"LH_SMEM4_P12": "1"}, {"LH_SMEM4_FUSED": "1"}, {"LH_NO_SWEEP_FILTER": "1"}, {"LH_NO_SWEEP_FILTER": "1", "LH_SMEM4_FUSED": "1"}):
+        for k in ("LH_SMEM4_P12", "LH_SMEM4_FUSED", "LH_NO_SWEEP_FILTER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        helpers.assert_same_dump(ctx.stage_dump(b), want, helpers.DUMP_FRONT)
+        seen[tuple(sorted(env))] = ctx.align_barcodes(b, emu.opts(run_inference=0)).counters["n_ext"]
+    assert seen[("LH_NO_SWEEP_FILTER",)] == want_ext == seen[("LH_NO_SWEEP_FILTER", "LH_SMEM4_FUSED")]
+    assert seen[()] == seen[("LH_SMEM4_P12",)] == seen[("LH_SMEM4_FUSED",)] < want_ext
