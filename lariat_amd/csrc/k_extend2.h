@@ -153,26 +153,16 @@ __global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t*
 #define K4_T0()
 #define K4_T(s_)
 #endif
+// circ_mask = 63: the band is narrow (w <= LH_EXT_CIRC_MAX_W), row i only touches columns i-w .. i+w+2, so eh[] lives in a
+// circular window of 64 words per lane whatever the query length; a column's first-row value (a closed form) and its query base
+// are written when the window reaches it — exactly the value the full array would still hold there.  circ_mask = -1: eh[] as is.
+#define LH_EXT_CIRC_MAX_W 30
 __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t* q, uint32_t* ehl, int lane, int qoff, int qstep, int qlen, LaneTgt& tg, int tlen, int w,
-                                                   int end_bonus, int zdrop, int h0, u64* cells) {
+                                                   int end_bonus, int zdrop, int h0, u64* cells, int circ_mask) {
     const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-#define EHW(j_) ehl[(j_) * 64 + lane]
+#define EHW(j_) ehl[((j_) & circ_mask) * 64 + lane]
     K4_T0()
-    {   // fill the first row
-        int hprev = h0;
-        for (int j = 0; j <= qlen; ++j) {
-            int v = 0;
-            if (j == 0) v = h0;
-            else if (j == 1) v = h0 > oe_ins ? h0 - oe_ins : 0;
-            else v = hprev > e_ins ? hprev - e_ins : 0;
-            if (j >= 2 && hprev == 0) v = 0;
-            hprev = v;
-            int qv = j < qlen ? (int)q[qoff + qstep * j] : 4;   // the read's nt4 bytes, once per extension
-            EHW(j) = EH_PACK(qv > 4 ? 4 : qv, 0, v);
-        }
-    }
-    K4_T(1)
     int maxsc = a_ > 0 ? a_ : 0;   // max entry of mat (a, -b, -1)
     int max_ins = (int)((double)(qlen * maxsc + end_bonus - o_ins) / e_ins + 1.);
     max_ins = max_ins > 1 ? max_ins : 1;
@@ -180,12 +170,24 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
     int max_del = (int)((double)(qlen * maxsc + end_bonus - o_del) / e_del + 1.);
     max_del = max_del > 1 ? max_del : 1;
     w = w < max_del ? w : max_del;
+    // the first row: column j holds max(0, h0 - oe_ins - (j-1)*e_ins) (j >= 1), h0 (j = 0), and the read's nt4 byte
+    int n_mat = 0;   // columns [0, n_mat) of eh[] have been written
+#define EH_MATERIALIZE(upto_)                                                                                \
+    for (int lim_ = (upto_) < qlen ? (upto_) : qlen; n_mat <= lim_; ++n_mat) {                               \
+        int v_ = n_mat == 0 ? h0 : h0 - oe_ins - (n_mat - 1) * e_ins;                                        \
+        v_ = v_ > 0 ? v_ : 0;                                                                                \
+        int qv_ = n_mat < qlen ? (int)q[qoff + qstep * n_mat] : 4;                                           \
+        EHW(n_mat) = EH_PACK(qv_ > 4 ? 4 : qv_, 0, v_);                                                      \
+    }
+    EH_MATERIALIZE(circ_mask >= 0 ? w + 2 : qlen)
+    K4_T(1)
     int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     int beg = 0, end = qlen;
     u64 ncell = 0;
     for (int i = 0; i < tlen; ++i) {
         int f = 0, h1, m = 0, mj = -1;
         int tb = tg.base(i);
+        if (circ_mask >= 0) EH_MATERIALIZE(i + w + 2)
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
@@ -234,6 +236,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
         end = j + 2 < qlen ? j + 2 : qlen;
     }
 #undef EHW
+#undef EH_MATERIALIZE
     K4_T(2)
     if (cells) *cells += ncell;
     ExtRes r;
@@ -364,13 +367,15 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                         }
                     }
                     K4_T(3)
-                    if (!proven && qlen >= EHW_) { deferred = 1; break; }
+                    const int circ = narrow && narrow <= LH_EXT_CIRC_MAX_W && EHW_ >= 64;   // a narrow band needs 64 words whatever qlen is
+                    if (!proven && !circ && qlen >= EHW_) { deferred = 1; break; }
                     for (int i = 0; i < 2 && !proven; ++i) {   // MAX_BAND_TRY
                         int prev = a.score;
                         aw = o.w << i;
                         LaneTgt tg;
                         tg.init(ix, tc0, tstep);
-                        e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, narrow && narrow < aw ? narrow : aw, bonus, o.zdrop, h0, &cells);
+                        e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, narrow && narrow < aw ? narrow : aw, bonus, o.zdrop, h0, &cells,
+                                             circ ? 63 : -1);
                         a.score = e.score;
                         if (a.score == prev || e.max_off < (aw >> 1) + (aw >> 2)) break;
                     }
