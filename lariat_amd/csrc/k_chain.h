@@ -243,7 +243,10 @@ template <class T, class Lt> __device__ inline void dev_introsort_small(int n, T
 // program over a handful of seeds; a wave per read spent its time on launch and single-lane latency: 5.4 ms per 2 M
 // reads).  Same arithmetic and the same order of B-tree / sort / filter operations as the wave kernel above, whose
 // single-lane sections appear here inline.  Reads with more seeds are listed for the wave kernel.
-__global__ void __launch_bounds__(64) k_chain_lane(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
+#ifndef LH_CHAIN_LANE_WAVES
+#define LH_CHAIN_LANE_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
                                                     i64 pool_cap, const DSeed* __restrict__ seeds, const int32_t* __restrict__ s_rid,
                                                     const int32_t* __restrict__ l_rep, int32_t* __restrict__ s_next, DChainTmp* __restrict__ ct,
                                                     int32_t* __restrict__ ord, int32_t* __restrict__ srt, DChain* __restrict__ chains,

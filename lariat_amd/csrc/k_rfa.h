@@ -124,7 +124,9 @@ __device__ __forceinline__ int dev_mol_active(int alen, int nbest, int change) {
 }
 
 #define LH_SPLIT_MAX 64
-#define LH_RFA_SORT_LDS 1536   // filtered candidates of a barcode whose position sort is staged in LDS (18 KB)
+#ifndef LH_RFA_SORT_LDS
+#define LH_RFA_SORT_LDS 768   // filtered candidates of a barcode whose position sort is staged in LDS (9 KB: 16 single-wave blocks per CU)
+#endif
 #define LH_RFA_LDS_BYTES (LH_RFA_SORT_LDS * 12)
 #define LH_RFA_NCONT_LDS 1024  // contig slots of a barcode kept in LDS while grouping (index with more contigs: slab copy)
 #define LH_RFA_SRC_CHUNK 256   // source-molecule alignments staged per pass of fastScore
@@ -202,7 +204,10 @@ __device__ __forceinline__ u64 dev_mix64(u64 x) {
 // A barcode whose tables do not fit the wave's slab (the reader caps a work unit at 30,000 pairs, fastqreader/reader.go:205,
 // far above the common few hundred) is appended to ovf_list and processed by a second launch whose few waves own much
 // larger slabs (work_list = that list); only there an overflow is final (LH_ST_POOL_OVERFLOW).
-__global__ void __launch_bounds__(64) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
+#ifndef LH_RFA_WAVES
+#define LH_RFA_WAVES 4   // waves per SIMD the register budget is sized for (128 VGPRs + 64 spilled: the kernel waits on memory, 4 waves hide more of it than 2 waves of 190 registers)
+#endif
+__global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
                                              const u64* __restrict__ name_seed, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S, i64 cand_cap,
                                              uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status, int32_t* __restrict__ bc_next,
                                              const int32_t* __restrict__ work_list, const int32_t* __restrict__ work_count, int32_t* __restrict__ ovf_list,
