@@ -7,23 +7,25 @@
 // (row-major cells, f/h1 carried in registers), 64 reads per wave:
 //   - eh[] lives in LDS, one 32-bit word per query column: h (16 bits) | e (13 bits) | the column's query base (3 bits),
 //     word j of lane L at ehl[j*64+L] (conflict-free for any per-lane j); one LDS read + one write per cell;
-//   - the reads are bucketed by their longest possible extension (k_ext_prep computes it from the chains), so the lanes
-//     of a wave sweep similar windows, and the bucket classes select the LDS footprint (64 / 128 / 256 columns);
-//   - the per-chain work that is parallel over seeds (reference window, extension order) stays wave-per-read in k_ext_prep.
+//   - the reads are bucketed by the lengths of their first extension (the pre-pass inside k_chain_lane computes them from the
+//     chains), so the lanes of a wave sweep similar windows;
+//   - three exact shortcuts keep the DP small (see k_extend_lane): no DP for a provably ungapped extension, a provably
+//     sufficient narrow band otherwise (in a circular 64-word window of eh[], whatever the query length), and the full band
+//     only in the wave-per-read kernel; one LDS footprint of 64 words per lane, plus an instance without LDS for the reads
+//     that are expected to need no DP at all.
 #pragma once
 #include "k_extend.h"
 
 // Buckets (lh_ext_bucket in k_chain.h): 0 = reads with many chains / seeds (handed to the wave-per-read kernel, which is
-// parallel over seeds and columns); then by the length of the LONGER side of the first extension, longest first, in three LDS
-// classes of 256 / 128 / 64 columns (the LDS footprint sets how many waves a CU holds: 2 / 5 / 10); reads whose first
-// extension is provably ungapped on both sides (no DP expected) have their own bucket at the end of the 128 and of the 64
-// class, so that whole waves skip the DP.  Finer classes (96, 32) were measured slower: every class is a launch with its own
-// tail, and more reads outgrow a tighter class and are redone.  Each primary bucket has LH_EXT_SUB sub-buckets by the length
+// parallel over seeds and columns) and reads with a long extension that needs the full band; then by the length of the LONGER
+// side of the first extension, longest first, in three ranges (>= 128, 64..127, < 64 columns: once LDS classes of their own,
+// now three launches of the 64-word instance); reads whose first extension is provably ungapped on both sides (no DP
+// expected) have their own buckets (25 and 34), run by the instance without LDS.  Each primary bucket has LH_EXT_SUB sub-buckets by the length
 // of the SHORTER side, so that the lanes of a wave sweep similar windows on both sides of the seed.
 #define LH_EXT_BINS (LH_EXT_PRIMARY * LH_EXT_SUB)
 struct DExtBins {
     int32_t count[LH_EXT_BINS], cursor[LH_EXT_BINS];
-    int32_t range[16];   // [first,last) pairs into the bucket-sorted order: complex, 256, 128, 64 columns; range[8..9] = the deferred list
+    int32_t range[16];   // [first,last) pairs into the bucket-sorted order: complex, >= 128, 64..127, < 64 columns; [8..9] = the deferred list; [10..13] = the two no-DP buckets; [14..15] = their deferred list
 };
 
 // ---- pre-pass, one wave per read: per chain the reference window [rmax0,rmax1) and the seed order; per read the bucket ----
