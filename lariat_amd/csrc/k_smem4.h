@@ -14,10 +14,15 @@
 //
 //  - UNIQUE RUNS: once a match has a single occurrence (interval size 1), extending it is comparing the read with the text at
 //    that occurrence.  With a fully resident suffix array the lane looks the position up once (sa[x0]) and then advances
-//    eight bases per turn by XOR-ing 4-bit packed read and text words, instead of one base per turn through two
+//    sixteen bases per turn by XOR-ing 4-bit packed read and text words, instead of one base per turn through two
 //    occurrence records; the interval bound that changes meanwhile (x1 forward, x0 backward) is read back once from the
 //    inverse suffix array when the run ends (the other bound provably stays put while the size is 1).  Used for the
 //    forward extension of bwt_smem1a and for backward rows with one surviving interval: most of a read's steps.
+//  - SWEEP FILTER: intervals of the forward list that provably cannot yield a seed are left out of the backward sweep (two Bloom
+//    filters over the text's 19-mers, see BLOOM_ISSUE below): 41 % of the reference's bwt_extend calls disappear.
+//  - PASS-SPECIFIC INSTANCES: the kernel is a template over the passes it carries (k_smem4_t<MODE>); the host launches pass 1,
+//    pass 2 and pass 3 one after the other, each with only its own states (fewer instructions per turn, fewer registers).
+//  - pass 3 starts its walks from the bi-interval of the first 12 bases (a table built on load).
 //  - query: 4-bit packed in LDS (8 bases per word, word w of lane L at qn[w*64+L]), staged by the whole wave
 //  - prev/curr interval lists: 16-B packed entries in an HBM slab interleaved by thread; the entry the next row starts
 //    with stays in registers (and is never written to the slab: most backward rows have a single survivor) and the
