@@ -107,13 +107,37 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     return m;
 }
 
-// K5.  grid = n_reads waves.  Also records the best pre-rescue score of the read (gobwa.go:264-283).
+// K5, lane per read: a read with at most one region has nothing to sort, exclude or patch (mem_sort_dedup_patch returns at
+// once): only its best score is recorded; the others (3 % on the bench data) are listed for the wave kernel.
+__global__ void __launch_bounds__(256) k_dedup_fast(int n_reads, const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs,
+                                                     int32_t* __restrict__ best_score, int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    int need = 0;
+    if (r < n_reads) {
+        int n = n_regs[r];
+        if (n <= 1) best_score[r] = n == 1 ? regs[reg_off[r]].score : 0;
+        else need = 1;
+    }
+    u64 m = __ballot(need);
+    if (m) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(list_count, (int32_t)__popcll(m));
+        basep = wave_readlane(basep, 0);
+        if (need) list[basep + lanes_below(m, lane)] = r;
+    }
+}
+
+// K5, wave per listed read (list == null: every read).  Also records the best pre-rescue score of the read (gobwa.go:264-283).
 __global__ void __launch_bounds__(64) k_dedup(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                const i64* __restrict__ reg_off, DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool,
-                                               int32_t* __restrict__ n_regs, int32_t* __restrict__ best_score, DCounters* __restrict__ ctr) {
+                                               int32_t* __restrict__ n_regs, int32_t* __restrict__ best_score, DCounters* __restrict__ ctr,
+                                               const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
     __shared__ uint8_t q[LH_MAXLEN + 6];
-    int r = blockIdx.x, lane = LANE();
-    if (r >= n_reads) return;
+    const int lane = LANE();
+    const int n_items = list ? *list_count : n_reads;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int r = list ? list[item] : item;
+    WAVE_SYNC();   // the previous read's query is no longer in use
     i64 off = seq_off[r];
     int l_query = (int)(seq_off[r + 1] - off);
     if (l_query > LH_MAXLEN) l_query = 0;
@@ -130,5 +154,6 @@ __global__ void __launch_bounds__(64) k_dedup(DIndex ix, DOpts o, int n_reads, c
     if (lane == 0) {
         n_regs[r] = n; best_score[r] = best;
         if (ctr && cells) atomicAdd(&LH_CTR(ctr)->glob_cells, cells);
+    }
     }
 }
