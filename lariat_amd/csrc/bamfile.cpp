@@ -318,9 +318,26 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
         for (auto& t : th) t.join();
     }
     double t2 = now();
-    for (int t = 0; t < nt; ++t) {
+    for (int t = 0; t < nt; ++t)
         if (bad[(size_t)t]) return lh_set_error_(LH_E_ARG, "lh_bam_append: malformed record line");
-        for (size_t o = 0; o < w->outs.size(); ++o) w->outs[o].pending += local[(size_t)t][o];
+    {   // per-file byte strings are joined in block order; the files are independent, so one host thread per file
+        std::atomic<size_t> next_out{0};
+        auto join = [&]() {
+            for (size_t o = next_out++; o < w->outs.size(); o = next_out++) {
+                size_t add = 0;
+                for (int t = 0; t < nt; ++t) add += local[(size_t)t][o].size();
+                if (!add) continue;
+                std::string& pend = w->outs[o].pending;
+                pend.reserve(pend.size() + add);
+                for (int t = 0; t < nt; ++t) pend += local[(size_t)t][o];
+            }
+        };
+        int jt = (int)w->outs.size() < w->threads ? (int)w->outs.size() : w->threads;
+        if (jt > 16) jt = 16;
+        std::vector<std::thread> th;
+        for (int t = 1; t < jt; ++t) th.emplace_back(join);
+        join();
+        for (auto& t : th) t.join();
     }
     double t3 = now();
     if (!flush(w, false)) { w->failed = true; return lh_set_error_(LH_E_IO, "lh_bam_append: compression or write failed"); }
