@@ -232,6 +232,11 @@ int lh_get_seq(const lh_index* idx, int32_t rid, int64_t start, int64_t end, int
  * from a `table_bytes` table in HBM — the practical ceiling for the FM-index walks */
 int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, int64_t n_access, double* gbps, double* ms);
 
+/* diagnostics: the device's restatement of Go's math/rand source (the jitter stream of tagBestAlignments, lariat.go:1486,
+ * 1499,1510): n draws of rand.New(rand.NewSource(seed)) as Uint64 — out_fast from K8's state-free path (first min(n,273)
+ * draws, the rest 0), out_ring from its state ring — and as Float64 (out_f64). */
+int lh_diag_go_rand(int device, int64_t seed, int32_t n, uint64_t* out_fast, uint64_t* out_ring, double* out_f64);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * N2 — 9-line barcode-sorted FASTQ ingest: go/src/fastqreader/reader.go (ReadOneLine :91-147,
  * ReadBarcodeSet :173-260), zipread.go:62-85 (gunzip pipe), and the driver's use of a set (lariat.go:353-375 the read loop,

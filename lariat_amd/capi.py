@@ -316,6 +316,13 @@ class Library:
         self.check(self.L.lh_diag_random_read(device, int(table_bytes), int(granule_bytes), int(n_access), C.byref(g), C.byref(ms)))
         return g.value, ms.value
 
+    def diag_go_rand(self, seed, n, device=0):
+        """(fast-path u64 draws, ring-path u64 draws, ring-path Float64 draws) of the device's Go math/rand source"""
+        a, b, f = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.float64)
+        self.L.lh_diag_go_rand.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.check(self.L.lh_diag_go_rand(device, int(seed), int(n), a.ctypes.data, b.ctypes.data, f.ctypes.data))
+        return a, b, f
+
     def index_load(self, prefix, device=0):
         h = C.c_void_p()
         self.check(self.L.lh_index_load(prefix.encode(), device, C.byref(h)))
@@ -603,5 +610,5 @@ EXPORTED_SYMBOLS = [
     "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
     "lh_records_text", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
-    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read",
+    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read", "lh_diag_go_rand",
 ]

@@ -17,3 +17,19 @@ __global__ void __launch_bounds__(256) k_diag_random_read(const uint4* __restric
     }
     if (acc == 0x12345678u) sink[0] = acc;   // keeps the loads alive
 }
+
+// Go's math/rand stream as K8 produces it (k_rfa.h): lane 0 draws on the state-free path (first min(n, 273) values), lane 1
+// with the state ring; parity tests compare both with the oracle's restatement of rng.go and with Go's known Seed(1) values.
+__global__ void __launch_bounds__(64) k_diag_go_rand(u64 seed, int n, u64* __restrict__ ring, u64* __restrict__ out_fast, u64* __restrict__ out_ring,
+                                                     double* __restrict__ f_ring) {
+    const int lane = LANE();
+    if (lane == 0) {
+        DGoRng g; dev_go_seed(g, seed, nullptr);
+        for (int i = 0; i < n && i < LH_GO_TAP; ++i) out_fast[i] = dev_go_u64(g);
+    } else if (lane == 1) {
+        DGoRng g; dev_go_seed(g, seed, ring + lane);
+        for (int i = 0; i < n; ++i) out_ring[i] = dev_go_u64(g);
+        DGoRng h; dev_go_seed(h, seed, ring + lane);
+        for (int i = 0; i < n; ++i) f_ring[i] = dev_go_f64(h);
+    }
+}

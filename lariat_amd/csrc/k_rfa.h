@@ -28,21 +28,71 @@ struct DInf {   // per-candidate / per-read inference outputs (device)
     int32_t* split_mapq;
 };
 
-struct DTieRng {   // xoshiro256** seeded by splitmix64 (see oracle/lariat_oracle.h: Go's math/rand stream is not reproducible offline)
-    u64 s0, s1, s2, s3;
+// ---- Go's math/rand source (rng.go), the jitter stream of tagBestAlignments (lariat.go:1486 rand.New(rand.NewSource(seed)),
+// :1499,:1510 random.Float64()/2.0).  Additive lagged Fibonacci x[n] = x[n-607] + x[n-273] mod 2^64; Seed fills the 607-entry
+// state from a Lehmer stream (x' = 48271 x mod 2^31-1, three values per entry at shifts 40/20/0) XORed with the table rngCooked
+// (go_rng_cooked.inc: derived from its definition by tools/gen_go_rng_cooked.py, pinned by Go's Seed(1) value stream).
+// A read draws once per (alignment, mate alignment) combination — a handful — so the device never builds the state for
+// them: draw k <= 273 is vec0[334-k] + vec0[607-k] of the SEEDED state (neither slot has been overwritten yet), and a seeded
+// entry is three jumps of the Lehmer stream (powers of the multiplier: go_rng_lehmer_pow.inc).  Reads with more draws
+// materialise the state in the wave's slab (one u64 [607][64 lanes] ring) and step it as rng.go does.
+#ifdef LH_EMU
+static const u64 lh_go_cooked[607] = {
+#include "go_rng_cooked.inc"
 };
-__device__ __forceinline__ u64 dev_splitmix(u64& x) {
-    u64 z = (x += 0x9e3779b97f4a7c15ull);
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
+static const uint32_t lh_go_lpow[1848] = {
+#include "go_rng_lehmer_pow.inc"
+};
+#else
+__device__ const u64 lh_go_cooked[607] = {
+#include "go_rng_cooked.inc"
+};
+__device__ const uint32_t lh_go_lpow[1848] = {
+#include "go_rng_lehmer_pow.inc"
+};
+#endif
+#define LH_GO_LEN 607
+#define LH_GO_TAP 273
+#define LH_GO_FAST_DRAWS 256   // draws a read may make on the state-free path (<= 273; the slack covers Float64's redraws)
+#define LH_GO_RING_BYTES ((size_t)LH_GO_LEN * 64 * 8)
+struct DGoRng {
+    uint32_t x0;   // normalised seed: the Lehmer stream's x_0
+    int k;         // draws made
+    u64* ring;     // null: state-free path; else this lane's state, entry i at ring[i * 64]
+    int tap, feed;
+};
+__device__ __forceinline__ uint32_t dev_go_mulmod31(uint32_t a, uint32_t b) {   // a * b mod (2^31 - 1)
+    u64 p = (u64)a * (u64)b;
+    u64 r = (p & 0x7fffffffull) + (p >> 31);
+    r = (r & 0x7fffffffull) + (r >> 31);
+    if (r >= 0x7fffffffull) r -= 0x7fffffffull;
+    return (uint32_t)r;
 }
-__device__ __forceinline__ void dev_rng_seed(DTieRng& g, u64 seed) { g.s0 = dev_splitmix(seed); g.s1 = dev_splitmix(seed); g.s2 = dev_splitmix(seed); g.s3 = dev_splitmix(seed); }
-__device__ __forceinline__ u64 dev_rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
-__device__ __forceinline__ double dev_rng_f64(DTieRng& g) {
-    u64 r = dev_rotl(g.s1 * 5, 7) * 9, t = g.s1 << 17;
-    g.s2 ^= g.s0; g.s3 ^= g.s1; g.s1 ^= g.s2; g.s0 ^= g.s3; g.s2 ^= t; g.s3 = dev_rotl(g.s3, 45);
-    return (double)(r >> 11) * (1.0 / 9007199254740992.0);
+__device__ __forceinline__ u64 dev_go_vec0(uint32_t x0, int i) {   // rngSource.Seed's vec[i]
+    u64 a = dev_go_mulmod31(x0, lh_go_lpow[21 + 3 * i]), b = dev_go_mulmod31(x0, lh_go_lpow[22 + 3 * i]), c = dev_go_mulmod31(x0, lh_go_lpow[23 + 3 * i]);
+    return ((a << 40) ^ (b << 20) ^ c) ^ lh_go_cooked[i];
+}
+__device__ __forceinline__ void dev_go_seed(DGoRng& g, u64 seed_bits, u64* ring) {
+    i64 seed = (i64)seed_bits % 2147483647ll;   // rng.go Seed: int64 remainder (sign of the dividend), then made positive
+    if (seed < 0) seed += 2147483647ll;
+    if (seed == 0) seed = 89482311;
+    g.x0 = (uint32_t)seed; g.k = 0; g.ring = ring; g.tap = 0; g.feed = LH_GO_LEN - LH_GO_TAP;
+    if (ring) for (int i = 0; i < LH_GO_LEN; ++i) ring[(size_t)i * 64] = dev_go_vec0(g.x0, i);
+}
+__device__ __forceinline__ u64 dev_go_u64(DGoRng& g) {   // rngSource.Uint64
+    ++g.k;
+    if (!g.ring) return dev_go_vec0(g.x0, LH_GO_LEN - LH_GO_TAP - g.k) + dev_go_vec0(g.x0, LH_GO_LEN - g.k);   // k <= 273 (caller's contract)
+    if (--g.tap < 0) g.tap += LH_GO_LEN;
+    if (--g.feed < 0) g.feed += LH_GO_LEN;
+    u64 x = g.ring[(size_t)g.feed * 64] + g.ring[(size_t)g.tap * 64];
+    g.ring[(size_t)g.feed * 64] = x;
+    return x;
+}
+__device__ __forceinline__ double dev_go_f64(DGoRng& g) {   // Rand.Float64: float64(Int63()) / (1<<63), redrawn if it rounds to 1
+    for (;;) {
+        double f = (double)(i64)(dev_go_u64(g) & 0x7fffffffffffffffull) * (1.0 / 9223372036854775808.0);
+        if (f != 1.0) return f;
+    }
 }
 
 // lariat.go:1102-1133
@@ -261,18 +311,31 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         WAVE_SYNC();
         RFA_T(0)
         // ---- tagBestAlignments: one lane per pair.  Read 2 of a pair is always "touched" by read 1 (every read has >= 1
-        // filtered candidate), so only read 1's scan decides; its RNG stream is seeded from the read name. ----
+        // filtered candidate), so only read 1's scan decides; its jitter stream is Go's, seeded from the read name. ----
+        {   // a read that draws more often than the state-free path allows keeps its generator state in the (still unused) slab
+            int big = 0;
+            for (int p = p0 + lane; p < p1; p += 64) {
+                int nA = 0, nM = 0;
+                for (i64 a = R.cand_off[2 * p]; a < R.cand_off[2 * p + 1]; ++a) nA += R.in_filtered[a] != 0;
+                for (i64 m = R.cand_off[2 * p + 1]; m < R.cand_off[2 * p + 2]; ++m) nM += R.in_filtered[m] != 0;
+                big |= (i64)nA * nM > LH_GO_FAST_DRAWS;
+            }
+            if (__ballot(big) && (size_t)slab_bytes < LH_GO_RING_BYTES) RFA_OVERFLOW()
+        }
         for (int p = p0 + lane; p < p1; p += 64) {
             int ra = 2 * p, rb = 2 * p + 1;
-            DTieRng rng;
-            dev_rng_seed(rng, name_seed[p]);
+            int nA = 0, nM = 0;
+            for (i64 a = R.cand_off[ra]; a < R.cand_off[ra + 1]; ++a) nA += R.in_filtered[a] != 0;
+            for (i64 m = R.cand_off[rb]; m < R.cand_off[rb + 1]; ++m) nM += R.in_filtered[m] != 0;
+            DGoRng rng;
+            dev_go_seed(rng, name_seed[p], (i64)nA * nM > LH_GO_FAST_DRAWS ? (u64*)slab + lane : (u64*)nullptr);
             double best = -1.7976931348623157e308;
             i64 ba = -1, bm = -1;
             for (i64 a = R.cand_off[ra]; a < R.cand_off[ra + 1]; ++a) {
                 if (!R.in_filtered[a]) continue;
                 for (i64 m = R.cand_off[rb]; m < R.cand_off[rb + 1]; ++m) {
                     if (!R.in_filtered[m]) continue;
-                    double total = dev_score_aln(R, S, improper, a, m, 0.0) + (dev_rng_f64(rng) / 2.0);
+                    double total = dev_score_aln(R, S, improper, a, m, 0.0) + (dev_go_f64(rng) / 2.0);
                     if (total > best) { best = total; ba = a; bm = m; }
                 }
             }

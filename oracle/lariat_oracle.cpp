@@ -12,19 +12,46 @@
 
 namespace orc {
 
-// ---- tie-break RNG (see header) -----------------------------------------------------------
-static inline uint64_t splitmix64(uint64_t& x) {
-    uint64_t z = (x += 0x9e3779b97f4a7c15ull);
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
+// ---- Go's math/rand source (see header) ------------------------------------------------------
+static const uint64_t kGoRngCooked[607] = {
+#include "go_rng_cooked.inc"
+};
+static inline int32_t go_seedrand(int32_t x) {   // rng.go seedrand: x[n+1] = 48271 * x[n] mod (2^31 - 1)
+    int32_t hi = x / 44488, lo = x % 44488;
+    x = 48271 * lo - 3399 * hi;
+    if (x < 0) x += 2147483647;
+    return x;
 }
-TieRng::TieRng(uint64_t seed) { for (int i = 0; i < 4; ++i) s[i] = splitmix64(seed); }
-static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-double TieRng::float64() {
-    uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
-    return (double)(r >> 11) * (1.0 / 9007199254740992.0);
+GoRand::GoRand(int64_t seed) {
+    tap = 0; feed = 607 - 273;
+    seed = seed % 2147483647;
+    if (seed < 0) seed += 2147483647;
+    if (seed == 0) seed = 89482311;
+    int32_t x = (int32_t)seed;
+    for (int i = -20; i < 607; ++i) {
+        x = go_seedrand(x);
+        if (i >= 0) {
+            int64_t u = (int64_t)x << 40;
+            x = go_seedrand(x);
+            u ^= (int64_t)x << 20;
+            x = go_seedrand(x);
+            u ^= (int64_t)x;
+            vec[i] = (uint64_t)u ^ kGoRngCooked[i];
+        }
+    }
+}
+uint64_t GoRand::uint64() {
+    if (--tap < 0) tap += 607;
+    if (--feed < 0) feed += 607;
+    uint64_t x = vec[feed] + vec[tap];
+    vec[feed] = x;
+    return x;
+}
+double GoRand::float64() {
+    for (;;) {
+        double f = (double)int63() / 9223372036854775808.0;
+        if (f != 1.0) return f;
+    }
 }
 
 // ---- gobwa.go:226-337 GoBwaMemMateSW --------------------------------------------------------
@@ -517,7 +544,7 @@ void do_rfa_for_one_barcode(const LariatOpts& o, const Index& idx, const std::ve
         bool was_touched = touched[read_id];
         double bestScore = -DBL_MAX;
         int bestAlignment = -1, bestMate = -1;
-        TieRng rng(pairs[read_id >> 1].name_seed);
+        GoRand rng((int64_t)pairs[read_id >> 1].name_seed);
         for (int a : arr) {
             const std::vector<int>& mates = alignments[C[a].mate_id];
             for (int m : mates) {

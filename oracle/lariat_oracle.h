@@ -71,13 +71,17 @@ void do_rfa_for_one_barcode(const LariatOpts& o, const Index& idx, const std::ve
 // Go 1.9 sort.Sort (quickSort + shell pass + insertion sort + heapSort): lariat.go:1546, split.go:108
 template <class Less, class Swap> void go19_sort(int n, Less less, Swap swp);
 
-// tie-break stream for tagBestAlignments (lariat.go:1486,1499,1510).  Go's math/rand ALFG cannot be reproduced
-// here (its 607-entry rngCooked table is not available offline), so the stream is defined by this generator:
-// xoshiro256** seeded by splitmix64(seed); Float64 = (next >> 11) * 2^-53.  Only exactly-tied pair scores are affected.
-struct TieRng {
-    uint64_t s[4];
-    explicit TieRng(uint64_t seed);
-    double float64();
+// The jitter stream of tagBestAlignments (lariat.go:1486 rand.New(rand.NewSource(seed)), :1499,:1510 random.Float64()/2.0):
+// Go's math/rand source restated — rng.go: additive lagged Fibonacci x[n] = x[n-607] + x[n-273] mod 2^64, seeded by a
+// Lehmer stream XORed with the 607-entry table rngCooked.  The table (go_rng_cooked.inc) is derived from its published
+// definition by tools/gen_go_rng_cooked.py and pinned by Go's well-known Seed(1) value stream (tests/test_go_rng.py).
+struct GoRand {
+    uint64_t vec[607];
+    int tap, feed;
+    explicit GoRand(int64_t seed);   // rngSource.Seed
+    uint64_t uint64();               // rngSource.Uint64
+    int64_t int63() { return (int64_t)(uint64() & 0x7fffffffffffffffull); }
+    double float64();                // Rand.Float64: float64(Int63()) / (1<<63), redrawn when it rounds to 1
 };
 
 }  // namespace orc

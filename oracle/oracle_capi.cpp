@@ -59,6 +59,12 @@ extern "C" {
 
 const char* lo_last_error() { return g_err.c_str(); }
 
+// the math/rand value stream of rand.New(rand.NewSource(seed)): n draws of Int63 and of Float64 (tests/test_go_rng.py)
+void lo_go_rand_stream(int64_t seed, int32_t n, int64_t* int63_out, double* float64_out) {
+    if (int63_out) { orc::GoRand g(seed); for (int i = 0; i < n; ++i) int63_out[i] = g.int63(); }
+    if (float64_out) { orc::GoRand g(seed); for (int i = 0; i < n; ++i) float64_out[i] = g.float64(); }
+}
+
 void lo_opts_init(lh_opts* o) {
     memset(o, 0, sizeof *o);
     MemOpt m;

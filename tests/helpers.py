@@ -91,3 +91,41 @@ def assert_same_result(r, ref, inference=True, mapq_tol=1, rel=1e-9):
     if inference:
         d = np.abs(r.mapq.astype(np.int64) - ref.mapq.astype(np.int64))
         assert (d <= mapq_tol).all(), ("mapq", np.nonzero(d > mapq_tol)[0][:5])
+
+
+def exact_repeat_genome(copies=20, unit=900, spacer=400, seed=3):
+    """one contig holding `copies` EXACT copies of a unit between random spacers + a unique tail: reads from a unit have
+    `copies` equally good candidates on both mates (tagBestAlignments then draws copies^2 jitter values per pair)"""
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 4, size=unit).astype(np.uint8)
+    parts = []
+    for _ in range(copies):
+        parts += [rng.integers(0, 4, size=spacer).astype(np.uint8), u]
+    parts.append(rng.integers(0, 4, size=20000).astype(np.uint8))
+    return ["chrR"], [np.concatenate(parts)], unit, spacer
+
+
+def repeat_unit_reads(contigs, unit, spacer, n_pairs, seed=4, copy=3, len1=120, len2=120):
+    """FR pairs that lie inside copy `copy` of exact_repeat_genome's unit; one barcode"""
+    rng = np.random.default_rng(seed)
+    g = contigs[0]
+    base = copy * (unit + spacer) + spacer
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    reads, names = [], []
+    for i in range(n_pairs):
+        ins = int(rng.integers(300, 500))
+        s = base + int(rng.integers(0, unit - ins))
+        r1 = g[s:s + len1].copy()
+        r2 = comp[g[s + ins - len2:s + ins][::-1]]
+        if rng.random() < 0.5:
+            r1[int(rng.integers(len1))] ^= 1
+        reads += [r1, r2]
+        names.append("rep:%d" % i)
+    rs = synth.ReadSet()
+    lens = np.array([len(x) for x in reads], dtype=np.int64)
+    rs.seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rs.seq = np.concatenate(reads)
+    rs.bc_pair_off = np.array([0, n_pairs], dtype=np.int32)
+    rs.names = names
+    rs.name_seed = synth._name_seeds(names)
+    return rs

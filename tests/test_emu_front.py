@@ -112,3 +112,18 @@ def test_emu_k1_launch_variants_and_sweep_filter(emu, oracle, monkeypatch):
         seen[tuple(sorted(env))] = ctx.align_barcodes(b, emu.opts(run_inference=0)).counters["n_ext"]
     assert seen[("LH_NO_SWEEP_FILTER",)] == want_ext == seen[("LH_NO_SWEEP_FILTER", "LH_SMEM4_FUSED")]
     assert seen[()] == seen[("LH_SMEM4_P12",)] == seen[("LH_SMEM4_FUSED",)] < want_ext
+
+
+def test_emu_many_candidate_pairs_go_rng_ring(emu, oracle):
+    """pairs with 20 x 20 equally good (alignment, mate) combinations: tagBestAlignments draws 400 jitter values per pair from
+    Go's generator (lariat.go:1499) — past the 273 draws the device serves without materialising the generator state"""
+    names, contigs, unit, spacer = helpers.exact_repeat_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = helpers.repeat_unit_reads(contigs, unit, spacer, n_pairs=6)
+    b = helpers.batch_of(rs)
+    ref = oidx.align_barcodes(b)
+    nf = np.add.reduceat(ref.in_filtered.astype(np.int64), ref.cand_off[:-1])
+    assert (nf[0::2] * nf[1::2]).max() > 273
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, ref, inference=True)
