@@ -29,16 +29,17 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 1
+#define LH_ABI_VERSION 2
 
 /* status codes */
 #define LH_OK 0
 #define LH_E_ARG 1       /* bad argument */
 #define LH_E_IO 2        /* index files unreadable / inconsistent (reference: gobwa.go:132-135 only logs) */
 #define LH_E_HIP 3       /* HIP runtime error (message in lh_last_error) */
-#define LH_E_CAPACITY 4  /* a workspace pool overflowed: split the batch and retry */
+#define LH_E_CAPACITY 4  /* a per-BATCH workspace pool overflowed: split the batch and retry */
 #define LH_E_NODEVICE 5  /* no HIP device / extension not usable: there is NO CPU fallback */
-#define LH_E_LIMIT 6     /* input outside documented limits (read length > LH_MAX_READ_LEN ...) */
+#define LH_E_LIMIT 6     /* input outside documented limits (read length > LH_MAX_READ_LEN, a per-READ / per-candidate slot limit ...):
+                          * splitting the batch does not help; lh_last_error names the first offending read */
 
 #define LH_MAX_READ_LEN 250 /* bases per read after trimming (u8 mate-rescue path needs l*a < 250, as upstream) */
 
@@ -67,8 +68,40 @@ typedef struct lh_opts {
     double improper_pair_penalty; /* -4.0, main.go:10 */
     double genome_length;         /* 3.2e9, lariat.go:885 */
     int32_t run_inference;        /* 0: stop after candidate generation (GetChains+GetAlignments) */
-    int32_t reserved;
+    uint32_t flags;               /* LH_F_*: A/B switches of the kernel sequence; results are identical under every combination */
 } lh_opts;
+
+/* lh_opts.flags (development / measurement; the defaults are the measured best) */
+#define LH_F_NO_SWEEP_FILTER 1u  /* K1 sweeps every interval like bwt_smem1a does (n_ext then counts every bwt_extend of the reference) */
+#define LH_F_SMEM_FUSED 2u       /* K1's three passes in one launch */
+#define LH_F_SMEM_P12 4u         /* K1's passes 1+2 in one launch, pass 3 in another */
+#define LH_F_SMEM_LANE 8u        /* K1 as BWA's loop nest, one lane per read (k_smem3.h) */
+#define LH_F_EXT_WAVE 16u        /* K4 wave-per-read only */
+#define LH_F_EXT_SERIAL 32u      /* K4's classes one after the other on one stream (per-class timings) */
+
+/* how an index is made resident (lh_index_load / lh_index_from_arrays / lh_index_build_device); NULL = defaults */
+typedef struct lh_index_opts {
+    int32_t abi_version;
+    int32_t sa_intv;          /* resident suffix-array sampling interval (power of two); 0 = the densest that fits half the free HBM (<= 128 GiB) */
+    int32_t sb_shift;         /* occurrence-table super-block = 2^sb_shift symbols, 7..31; 0 = 31 */
+    int32_t no_kmer_table;    /* leave out K1's 12-mer table */
+    int32_t no_unique_runs;   /* leave out the inverse suffix array and the 4-bit text (and with them the sweep filters) */
+    int32_t no_sweep_filter;  /* leave out the Bloom filters of K1's sweep filter */
+    int32_t build_chunk_log2; /* lh_index_build_device: at most 2^this suffixes per sort chunk; 0 = 29 */
+    int32_t reserved;
+} lh_index_opts;
+void lh_index_opts_init(lh_index_opts* io);
+
+/* per-context launch geometry (NULL = defaults; 0 in a field = its default) */
+typedef struct lh_context_opts {
+    int32_t abi_version;
+    int32_t smem_grid;    /* K1 persistent waves (6144) */
+    int32_t aln_grid;     /* K7 waves (5120) */
+    int32_t rfa_grid;     /* K8 waves (4096) */
+    int32_t rfa_slab_kb;  /* K8 first-pass slab per wave in KiB (2048); tests force the second pass with a small value */
+    int32_t reserved[3];
+} lh_context_opts;
+void lh_context_opts_init(lh_context_opts* co);
 
 /* one batch of barcodes.  Reads are post-trim (reader.go trims read1) nt4 bytes: A0 C1 G2 T3 other 4
  * (SequenceConvert, gobwa.go:159).  read index r = 2*pair + mate (lariat.go:1720-1721,1758-1759). */
@@ -184,18 +217,18 @@ int lh_device_count(void);
 void lh_opts_init(lh_opts* o); /* replaces mem_opt_init + lariat flag defaults */
 
 /* replaces bwa_idx_load(path, BWA_IDX_ALL) (gobwa.go:130): reads <prefix>.bwt/.sa/.pac/.ann/.amb and uploads to `device` */
-int lh_index_load(const char* prefix, int device, lh_index** out);
+int lh_index_load(const char* prefix, int device, const lh_index_opts* io, lh_index** out);
 /* same, from in-memory images laid out exactly like the BWA files (used by the index builder / synthetic genomes) */
 int lh_index_from_arrays(int device, uint64_t primary, const uint64_t L2[5], const uint32_t* bwt, uint64_t bwt_words,
                          int32_t sa_intv, const uint64_t* sa, uint64_t n_sa, const uint8_t* pac, int64_t l_pac,
                          int32_t n_contigs, const int64_t* contig_off, const int32_t* contig_len, const char* const* contig_name,
-                         lh_index** out);
+                         const lh_index_opts* io, lh_index** out);
 /* GetReferenceContigsInfo (gobwa.go:26) */
 int lh_index_contigs(const lh_index* idx, int32_t* n, const char* const** names, const int64_t** lens, const int64_t** offsets);
 int64_t lh_index_l_pac(const lh_index* idx);
 /* The .sa file holds every 32nd suffix-array row (bwa index default); bwt_sa (reached from mem_chain via gobwa.go:244,253)
  * walks the BWT to the next sampled row.  On load the samples are re-derived ON THE DEVICE at the densest power-of-two
- * interval whose table fits a quarter of the free HBM (<= 64 GiB; override with the environment variable LH_SA_INTV), so a
+ * interval whose table fits half of the free HBM (<= 128 GiB; lh_index_opts.sa_intv forces one), so a
  * lookup costs (interval-1)/2 occurrence-block reads instead of 15.5.  The values are exact at any interval; results do not
  * change.  lh_index_resample_sa switches the resident table to another interval (denser: walk; sparser: sub-sample). */
 int lh_index_resample_sa(lh_index* idx, int32_t sa_intv);
@@ -205,8 +238,20 @@ void lh_index_free(lh_index* idx);
 /* FM-index construction: text = fwd || revcomp of the 2-bit contigs, BWA-byte-compatible output.
  * Host-side (multi-threaded suffix sorting); writes <prefix>.bwt/.sa/.pac/.ann/.amb. */
 int lh_index_build(const char* prefix, int32_t n_contigs, const char* const* names, const uint8_t* const* nt4, const int64_t* lens, int32_t threads);
+/* The same construction ON THE DEVICE, sized for a human genome in 288 GB of HBM (hg38: 6.2 G suffixes): suffixes of
+ * fwd || revcomp are gathered by 8-mer prefix into chunks, radix-sorted by their first 32 bases, ties finished by direct
+ * comparison through the packed text; BWT, occurrence table, dense suffix array and K1's side tables are built from the
+ * result without leaving HBM.  `pac` is the .pac file's 2-bit forward reference (l_pac/4+1 bytes).  The index equals the
+ * one lh_index_load makes from `bwa index` files of the same reference (lh_index_export gives those files' contents). */
+int lh_index_build_device(int device, const uint8_t* pac, int64_t l_pac, int32_t n_contigs, const int64_t* contig_off, const int32_t* contig_len,
+                          const char* const* contig_name, const lh_index_opts* io, lh_index** out);
+/* the resident index in the byte layout of <prefix>.bwt / .sa: call with bwt == NULL to get the sizes, then with buffers.
+ * sa_intv: 32 for `bwa index` compatibility (a multiple of the resident interval); sa[0] = (uint64_t)-1 as in memory. */
+int lh_index_export(const lh_index* idx, uint64_t* primary, uint64_t L2[5], uint32_t* bwt, uint64_t* bwt_words, int32_t sa_intv, uint64_t* sa, uint64_t* n_sa);
+/* writes <prefix>.bwt .sa .pac .ann .amb (what lh_index_build writes) from the resident index */
+int lh_index_save(const lh_index* idx, const char* prefix);
 
-int lh_context_create(lh_index* idx, int64_t max_pairs_per_batch, lh_context** out);
+int lh_context_create(lh_index* idx, int64_t max_pairs_per_batch, const lh_context_opts* co, lh_context** out);
 void lh_context_free(lh_context* ctx);
 
 /* THE hot path: DoRFAForOneBarcode for every barcode of the batch (lariat.go:461-547), minus DumpToBams.
@@ -231,6 +276,25 @@ int lh_get_seq(const lh_index* idx, int32_t rid, int64_t start, int64_t end, int
 /* diagnostics: rate (GB/s of requested bytes) of independent random reads of `granule_bytes` blocks (multiple of 16)
  * from a `table_bytes` table in HBM — the practical ceiling for the FM-index walks */
 int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, int64_t n_access, double* gbps, double* ms);
+
+/* diagnostics: self-check of a resident index with a dense suffix array, on every stride-th row: adjacent suffixes are in
+ * order (direct text comparison); the stored BWT symbol is the base before the suffix and the LF-mapping through the
+ * occurrence table reaches that suffix's row.  A size-independent property for indexes the oracle cannot hold. */
+int lh_diag_index_check(const lh_index* idx, uint64_t stride, uint64_t* n_checked, uint64_t* n_bad_order, uint64_t* n_bad_lf);
+
+/* Workload generators for bench.py and the tests (no genome but PhiX exists offline).  Host-only, threaded.
+ * lh_synth_genome: iid ACGT with GC fraction `gc` as a .pac image (l_pac/4+1 bytes, MSB-first 2-bit), reproducible from `seed`
+ * whatever the thread count.  lh_synth_reads: barcode-sorted FR read pairs under the linked-read model — per barcode
+ * mol_min..mol_max molecules (log-normal length, median 50 kb, clipped to [10 kb, 200 kb]), pairs_per_barcode pairs spread
+ * over them in proportion to length, insert ~ N(350,50) clipped to [max(200,len),700], substitution error ramping
+ * sub_lo -> sub_hi along each read, indels at indel_rate per base (1-3 bases), junk_frac of the reads replaced by random
+ * bases.  Output arrays as an lh_batch wants them; truth_pos (forward-strand start of read 1 / read 2's fragment end) may be NULL. */
+int lh_synth_genome(uint64_t seed, double gc, int64_t l_pac, uint8_t* pac, int32_t threads);
+int lh_synth_reads(const uint8_t* pac, int64_t l_pac, int32_t n_contigs, const int64_t* contig_off, const int32_t* contig_len, uint64_t seed,
+                   int32_t n_barcodes, int32_t pairs_per_barcode, int32_t len1, int32_t len2, double sub_lo, double sub_hi, double indel_rate,
+                   double junk_frac, int32_t mol_min, int32_t mol_max, int32_t threads,
+                   uint8_t* seq /* cap 2*n_pairs*(max(len1,len2)+3) */, int64_t* seq_off /* 2*n_pairs+1 */, int32_t* bc_pair_off /* n_barcodes+1 */,
+                   uint64_t* name_seed /* n_pairs */, int32_t* truth_rid /* n_pairs or NULL */, int64_t* truth_pos1, int64_t* truth_pos2);
 
 /* diagnostics: the device's restatement of Go's math/rand source (the jitter stream of tagBestAlignments, lariat.go:1486,
  * 1499,1510): n draws of rand.New(rand.NewSource(seed)) as Uint64 — out_fast from K8's state-free path (first min(n,273)

@@ -13,7 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LARIAT_HIP_LIB") or os.path.join(_HERE, "_build", "liblariat_hip.so")
 
 LH_OK = 0
-LH_ABI_VERSION = 1
+LH_ABI_VERSION = 2
+LH_E_ARG, LH_E_IO, LH_E_HIP, LH_E_CAPACITY, LH_E_NODEVICE, LH_E_LIMIT = 1, 2, 3, 4, 5, 6
+# lh_opts.flags
+LH_F_NO_SWEEP_FILTER, LH_F_SMEM_FUSED, LH_F_SMEM_P12, LH_F_SMEM_LANE, LH_F_EXT_WAVE, LH_F_EXT_SERIAL = 1, 2, 4, 8, 16, 32
 LH_MAX_READ_LEN = 250
 
 c_i32p = C.POINTER(C.c_int32)
@@ -39,8 +42,18 @@ class LhOpts(C.Structure):
         ("pes_low", C.c_int32), ("pes_high", C.c_int32),
         ("rescue_score_delta", C.c_int32), ("rescue_max_hits", C.c_int32), ("aln_score_delta", C.c_int32),
         ("improper_pair_penalty", C.c_double), ("genome_length", C.c_double),
-        ("run_inference", C.c_int32), ("reserved", C.c_int32),
+        ("run_inference", C.c_int32), ("flags", C.c_uint32),
     ]
+
+
+class LhIndexOpts(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("sa_intv", C.c_int32), ("sb_shift", C.c_int32), ("no_kmer_table", C.c_int32), ("no_unique_runs", C.c_int32),
+                ("no_sweep_filter", C.c_int32), ("build_chunk_log2", C.c_int32), ("reserved", C.c_int32)]
+
+
+class LhContextOpts(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("smem_grid", C.c_int32), ("aln_grid", C.c_int32), ("rfa_grid", C.c_int32), ("rfa_slab_kb", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class LhBatch(C.Structure):
@@ -232,9 +245,19 @@ def _declare(L):
     L.lh_last_error.restype = C.c_char_p
     L.lh_device_count.restype = C.c_int
     L.lh_opts_init.argtypes = [C.POINTER(LhOpts)]
-    L.lh_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.lh_index_opts_init.argtypes = [C.POINTER(LhIndexOpts)]
+    L.lh_index_opts_init.restype = None
+    L.lh_context_opts_init.argtypes = [C.POINTER(LhContextOpts)]
+    L.lh_context_opts_init.restype = None
+    L.lh_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(LhIndexOpts), C.POINTER(C.c_void_p)]
     L.lh_index_from_arrays.argtypes = [C.c_int, C.c_uint64, c_u64p, c_u32p, C.c_uint64, C.c_int32, c_u64p, C.c_uint64, c_u8p, C.c_int64,
-                                       C.c_int32, c_i64p, c_i32p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+                                       C.c_int32, c_i64p, c_i32p, C.POINTER(C.c_char_p), C.POINTER(LhIndexOpts), C.POINTER(C.c_void_p)]
+    L.lh_index_build_device.argtypes = [C.c_int, c_u8p, C.c_int64, C.c_int32, c_i64p, c_i32p, C.POINTER(C.c_char_p), C.POINTER(LhIndexOpts), C.POINTER(C.c_void_p)]
+    L.lh_index_export.argtypes = [C.c_void_p, c_u64p, c_u64p, c_u32p, c_u64p, C.c_int32, c_u64p, c_u64p]
+    L.lh_index_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.lh_synth_genome.argtypes = [C.c_uint64, C.c_double, C.c_int64, c_u8p, C.c_int32]
+    L.lh_synth_reads.argtypes = [c_u8p, C.c_int64, C.c_int32, c_i64p, c_i32p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                 C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, c_u8p, c_i64p, c_i32p, c_u64p, c_i32p, c_i64p, c_i64p]
     L.lh_index_contigs.argtypes = [C.c_void_p, c_i32p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(c_i64p), C.POINTER(c_i64p)]
     L.lh_index_l_pac.argtypes = [C.c_void_p]
     L.lh_index_l_pac.restype = C.c_int64
@@ -264,7 +287,7 @@ def _declare(L):
     L.lh_index_sa_interval.restype = C.c_int32
     L.lh_index_free.argtypes = [C.c_void_p]
     L.lh_index_build.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(c_u8p), c_i64p, C.c_int32]
-    L.lh_context_create.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.lh_context_create.argtypes = [C.c_void_p, C.c_int64, C.POINTER(LhContextOpts), C.POINTER(C.c_void_p)]
     L.lh_context_free.argtypes = [C.c_void_p]
     L.lh_align_barcodes.argtypes = [C.c_void_p, C.POINTER(LhOpts), C.POINTER(LhBatch), C.POINTER(C.POINTER(LhResult))]
     L.lh_batch_upload.argtypes = [C.c_void_p, C.POINTER(LhBatch)]
@@ -323,12 +346,71 @@ class Library:
         self.check(self.L.lh_diag_go_rand(device, int(seed), int(n), a.ctypes.data, b.ctypes.data, f.ctypes.data))
         return a, b, f
 
-    def index_load(self, prefix, device=0):
+    def index_opts(self, **kw):
+        io = LhIndexOpts()
+        self.L.lh_index_opts_init(C.byref(io))
+        for k, v in kw.items():
+            if not hasattr(io, k):
+                raise AttributeError(k)
+            setattr(io, k, v)
+        return io
+
+    def context_opts(self, **kw):
+        co = LhContextOpts()
+        self.L.lh_context_opts_init(C.byref(co))
+        for k, v in kw.items():
+            if not hasattr(co, k):
+                raise AttributeError(k)
+            setattr(co, k, v)
+        return co
+
+    def index_load(self, prefix, device=0, **index_opts):
         h = C.c_void_p()
-        self.check(self.L.lh_index_load(prefix.encode(), device, C.byref(h)))
+        io = self.index_opts(**index_opts)
+        self.check(self.L.lh_index_load(prefix.encode(), device, C.byref(io), C.byref(h)))
         return Index(self, h)
 
-    def index_from_arrays(self, arrs, device=0):
+    def index_build_device(self, pac, l_pac, contigs, device=0, **index_opts):
+        """contigs = [(name, len, off)]; pac = the .pac image (uint8, l_pac // 4 + 1 bytes)"""
+        n = len(contigs)
+        names = (C.c_char_p * n)(*[c[0].encode() for c in contigs])
+        lens = np.array([c[1] for c in contigs], dtype=np.int32)
+        offs = np.array([c[2] for c in contigs], dtype=np.int64)
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        assert len(pac) >= l_pac // 4 + 1
+        h = C.c_void_p()
+        io = self.index_opts(**index_opts)
+        self.check(self.L.lh_index_build_device(device, pac.ctypes.data_as(c_u8p), int(l_pac), n, offs.ctypes.data_as(c_i64p), lens.ctypes.data_as(c_i32p), names,
+                                                C.byref(io), C.byref(h)))
+        return Index(self, h)
+
+    def synth_genome(self, l_pac, seed=20261002, gc=0.41, threads=0):
+        """.pac image of an iid genome (host, threaded; reproducible from the seed)"""
+        pac = np.zeros(l_pac // 4 + 1, dtype=np.uint8)
+        self.check(self.L.lh_synth_genome(int(seed), float(gc), int(l_pac), pac.ctypes.data_as(c_u8p), int(threads)))
+        return pac
+
+    def synth_reads(self, pac, l_pac, contigs, seed, n_barcodes, pairs_per_barcode=100, len1=143, len2=150, sub_lo=0.001, sub_hi=0.01, indel_rate=0.0001,
+                    junk_frac=0.0, mol_min=4, mol_max=10, threads=0):
+        """barcode-sorted synthetic pairs (linked-read model) as a dict of the arrays an lh_batch wants + truth"""
+        n = len(contigs)
+        lens = np.array([c[1] for c in contigs], dtype=np.int32)
+        offs = np.array([c[2] for c in contigs], dtype=np.int64)
+        n_pairs = n_barcodes * pairs_per_barcode
+        seq = np.zeros(2 * n_pairs * (max(len1, len2) + 3), dtype=np.uint8)
+        seq_off = np.zeros(2 * n_pairs + 1, dtype=np.int64)
+        bco = np.zeros(n_barcodes + 1, dtype=np.int32)
+        ns = np.zeros(n_pairs, dtype=np.uint64)
+        trid = np.zeros(n_pairs, dtype=np.int32)
+        tp1 = np.zeros(n_pairs, dtype=np.int64)
+        tp2 = np.zeros(n_pairs, dtype=np.int64)
+        self.check(self.L.lh_synth_reads(pac.ctypes.data_as(c_u8p), int(l_pac), n, offs.ctypes.data_as(c_i64p), lens.ctypes.data_as(c_i32p), int(seed), int(n_barcodes),
+                                         int(pairs_per_barcode), int(len1), int(len2), float(sub_lo), float(sub_hi), float(indel_rate), float(junk_frac), int(mol_min),
+                                         int(mol_max), int(threads), seq.ctypes.data_as(c_u8p), seq_off.ctypes.data_as(c_i64p), bco.ctypes.data_as(c_i32p),
+                                         ns.ctypes.data_as(c_u64p), trid.ctypes.data_as(c_i32p), tp1.ctypes.data_as(c_i64p), tp2.ctypes.data_as(c_i64p)))
+        return dict(seq=seq[:seq_off[-1]], seq_off=seq_off, bc_pair_off=bco, name_seed=ns, truth_rid=trid, truth_pos1=tp1, truth_pos2=tp2, n_pairs=n_pairs)
+
+    def index_from_arrays(self, arrs, device=0, **index_opts):
         """arrs: dict(primary, L2, bwt, sa, sa_intv, pac, l_pac, contigs=[(name,len,off)])"""
         n = len(arrs["contigs"])
         names = (C.c_char_p * n)(*[c[0].encode() for c in arrs["contigs"]])
@@ -339,9 +421,10 @@ class Library:
         sa = np.ascontiguousarray(arrs["sa"], dtype=np.uint64)
         pac = np.ascontiguousarray(arrs["pac"], dtype=np.uint8)
         h = C.c_void_p()
+        io = self.index_opts(**index_opts)
         self.check(self.L.lh_index_from_arrays(device, int(arrs["primary"]), L2.ctypes.data_as(c_u64p), bwt.ctypes.data_as(c_u32p), len(bwt),
                                                int(arrs["sa_intv"]), sa.ctypes.data_as(c_u64p), len(sa), pac.ctypes.data_as(c_u8p), int(arrs["l_pac"]),
-                                               n, offs.ctypes.data_as(c_i64p), lens.ctypes.data_as(c_i32p), names, C.byref(h)))
+                                               n, offs.ctypes.data_as(c_i64p), lens.ctypes.data_as(c_i32p), names, C.byref(io), C.byref(h)))
         return Index(self, h)
 
     def ingest(self, path, trim=7, cap=0, chunk=0, max_pairs=1 << 20):
@@ -417,10 +500,33 @@ class Index:
         self.lib.check(self.lib.L.lh_get_seq(self.h, rid, start, end, int(reversed_), buf))
         return buf.raw[: end - start]
 
-    def context(self, max_pairs):
+    def context(self, max_pairs, **context_opts):
         h = C.c_void_p()
-        self.lib.check(self.lib.L.lh_context_create(self.h, int(max_pairs), C.byref(h)))
+        co = self.lib.context_opts(**context_opts)
+        self.lib.check(self.lib.L.lh_context_create(self.h, int(max_pairs), C.byref(co), C.byref(h)))
         return Context(self, h)
+
+    def export(self, sa_intv=32):
+        """the index in the layout of bwa's files: dict(primary, L2, bwt, sa, sa_intv, pac-less) for oracle / file writers"""
+        prim, nw, ns = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L2 = np.zeros(5, dtype=np.uint64)
+        L = self.lib.L
+        self.lib.check(L.lh_index_export(self.h, C.byref(prim), L2.ctypes.data_as(c_u64p), None, C.byref(nw), sa_intv, None, C.byref(ns)))
+        bwt = np.zeros(nw.value, dtype=np.uint32)
+        sa = np.zeros(ns.value, dtype=np.uint64)
+        self.lib.check(L.lh_index_export(self.h, C.byref(prim), L2.ctypes.data_as(c_u64p), bwt.ctypes.data_as(c_u32p), C.byref(nw), sa_intv, sa.ctypes.data_as(c_u64p),
+                                         C.byref(ns)))
+        return dict(primary=prim.value, L2=L2, bwt=bwt, sa=sa, sa_intv=sa_intv, l_pac=self.l_pac, contigs=self.contigs())
+
+    def check(self, stride=64):
+        """(rows checked, order violations, BWT/LF violations) — lh_diag_index_check"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.lib.L.lh_diag_index_check.argtypes = [C.c_void_p, C.c_uint64, c_u64p, c_u64p, c_u64p]
+        self.lib.check(self.lib.L.lh_diag_index_check(self.h, int(stride), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def save(self, prefix):
+        self.lib.check(self.lib.L.lh_index_save(self.h, prefix.encode()))
 
 
 class Context:
@@ -611,4 +717,5 @@ EXPORTED_SYMBOLS = [
     "lh_records_text", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read", "lh_diag_go_rand",
+    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check",
 ]

@@ -33,3 +33,42 @@ __global__ void __launch_bounds__(64) k_diag_go_rand(u64 seed, int n, u64* __res
         for (int i = 0; i < n; ++i) f_ring[i] = dev_go_f64(h);
     }
 }
+
+// Self-check of a resident index with a dense suffix array (sampled rows r = k * stride): (1) suffix sa[r] < suffix sa[r+1]
+// by direct comparison of the text; (2) the BWT symbol stored for row r+1 is the text base before its suffix, and the
+// LF-mapping through the occurrence table lands on the row of that longer suffix (isa).  out: [0] rows checked,
+// [1] order violations, [2] BWT / LF violations.  Size-independent property test for indexes too large for the oracle.
+__global__ void __launch_bounds__(256) k_diag_index_check(DIndex ix, u64 stride, unsigned long long* __restrict__ out) {
+    const u64 n = ix.seq_len;
+    unsigned long long checked = 0, bad_order = 0, bad_lf = 0;
+    for (u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * stride; r < n; r += (u64)gridDim.x * blockDim.x * stride) {
+        u64 a = r == 0 ? n : ix.sa[r], b = ix.sa[r + 1];
+        ++checked;
+        if (a != n) {
+            int verdict = 0;
+            for (u64 i = 0; i < (1u << 20) && !verdict; ++i) {
+                if (a + i >= n) verdict = 1;            // a is a proper prefix of b: smaller
+                else if (b + i >= n) verdict = -1;
+                else {
+                    int ca = dev_ref_base(ix, (i64)(a + i)), cb = dev_ref_base(ix, (i64)(b + i));
+                    if (ca != cb) verdict = ca < cb ? 1 : -1;
+                }
+            }
+            if (verdict <= 0) ++bad_order;
+        }
+        u64 k = r + 1;
+        if (k != ix.primary) {
+            u64 x = k - (k > ix.primary);
+            uint4 pl = ix.occ[((x >> 6) << 1) + 1];
+            int sh = (int)(x & 63);
+            int c = (int)((((u64)pl.y << 32 | pl.x) >> sh & 1) << 1 | (((u64)pl.w << 32 | pl.z) >> sh & 1));
+            u64 cnt[4];
+            dev_occ4(ix, k, cnt);
+            u64 lf = ix.L2[c] + cnt[c];
+            if (b == 0 || c != dev_ref_base(ix, (i64)(b - 1)) || (ix.isa && ix.isa[b - 1] != lf) || ix.sa[lf] != b - 1) ++bad_lf;
+        } else if (b != 0) ++bad_lf;
+    }
+    if (checked) atomicAdd(&out[0], checked);
+    if (bad_order) atomicAdd(&out[1], bad_order);
+    if (bad_lf) atomicAdd(&out[2], bad_lf);
+}

@@ -1,0 +1,302 @@
+// k_index_build.h — FM-index construction ON THE DEVICE (lh_index_build_device).
+//
+// What `bwa index` does on a host in an hour (the reference consumes its files: go/src/gobwa/gobwa.go:130; formats pinned by
+// the fixture go/src/test/inputs/phix/PhiX.fa.*) sized for 288 GB of HBM: the suffixes of the text fwd || revcomp are
+//   1. counted by their first LH_IB_PFX symbols (LDS-private histograms),
+//   2. gathered chunk by chunk (a chunk = a range of prefixes holding at most 2^build_chunk_log2 suffixes) together with
+//      their first 32 symbols as one 64-bit key, and radix-sorted by that key,
+//   3. finished where keys tie: each group of equal keys is sorted in place by direct comparison through the packed text
+//      (one lane per group; on a genome groups are short: repeats longer than 32 bases),
+// and the BWT in the `.bwt` file's layout (occurrence counts interleaved every 128 symbols) is derived from the full suffix
+// array by a blocked count scan.  Everything downstream (occurrence records, dense SA, ISA, filters) is lh_host.inc's.
+// The sentinel is smallest: a suffix that is a prefix of another sorts first (zero padding + length comparison).
+#pragma once
+#include "lh_dev.h"
+
+#define LH_IB_PFX 6                       // symbols of the chunking prefix
+#define LH_IB_BINS (1 << (2 * LH_IB_PFX))
+
+// 32 symbols starting at text position i (zero padded past the end: W has two spare zero words)
+__device__ __forceinline__ u64 ib_key(const u64* __restrict__ W, u64 i) {
+    u64 wi = i >> 5;
+    int sh = (int)(i & 31) << 1;
+    u64 a = W[wi];
+    return sh ? (a << sh) | (W[wi + 1] >> (64 - sh)) : a;
+}
+__device__ __forceinline__ int ib_sym(const u64* __restrict__ W, u64 p) { return (int)(W[p >> 5] >> (62 - ((int)(p & 31) << 1))) & 3; }
+
+// suffix a < suffix b, given that their first `off0` symbols are equal (as padded keys)
+__device__ __forceinline__ bool ib_suf_less(const u64* __restrict__ W, u64 n, u64 a, u64 b, u64 off0) {
+    u64 la = n - a, lb = n - b, l = la < lb ? la : lb;
+    for (u64 off = off0; off < l; off += 32) {
+        u64 wa = ib_key(W, a + off), wb = ib_key(W, b + off);
+        if (wa != wb) {
+            int lead = __clzll((long long)(wa ^ wb)) >> 1;   // first differing symbol
+            if (off + (u64)lead >= l) break;                  // the difference lies in the padding
+            return wa < wb;
+        }
+    }
+    return la < lb;   // one is a prefix of the other: the shorter one (sentinel first) is smaller
+}
+
+// the text fwd || revcomp, 32 symbols per u64, MSB first
+__global__ void __launch_bounds__(256) k_ib_text(const uint8_t* __restrict__ pac, i64 l_pac, u64 n_words, u64* __restrict__ W) {
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (u64)gridDim.x * blockDim.x) {
+        u64 v = 0;
+        for (int k = 0; k < 32; ++k) {
+            i64 p = (i64)(w << 5) + k;
+            if (p >= 2 * l_pac) break;
+            u64 b = p < l_pac ? (u64)dev_pac(pac, p) : (u64)(3 - dev_pac(pac, 2 * l_pac - 1 - p));
+            v |= b << (62 - 2 * k);
+        }
+        W[w] = v;
+    }
+}
+
+// histogram of the LH_IB_PFX-symbol prefixes of all n suffixes; one thread per text word (32 suffixes)
+__global__ void __launch_bounds__(256) k_ib_hist(const u64* __restrict__ W, u64 n, unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t h[LH_IB_BINS];
+    for (int b = threadIdx.x; b < LH_IB_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    u64 n_words = (n + 31) >> 5;
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (u64)gridDim.x * blockDim.x) {
+        u64 a = W[w], b = W[w + 1];
+        for (int k = 0; k < 32; ++k) {
+            if ((w << 5) + k >= n) break;
+            u64 key = k ? (a << (2 * k)) | (b >> (64 - 2 * k)) : a;
+            atomicAdd(&h[key >> (64 - 2 * LH_IB_PFX)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < LH_IB_BINS; b += 256) if (h[b]) atomicAdd(&hist[b], (unsigned long long)h[b]);
+}
+
+// (key, position) of every suffix whose prefix bin lies in [bin_lo, bin_hi), appended in no particular order
+__global__ void __launch_bounds__(256) k_ib_gather(const u64* __restrict__ W, u64 n, uint32_t bin_lo, uint32_t bin_hi, unsigned long long* __restrict__ cursor,
+                                                   u64* __restrict__ keys, u64* __restrict__ vals) {
+    __shared__ uint32_t s_cnt[256];
+    __shared__ unsigned long long s_base;
+    u64 n_words = (n + 31) >> 5;
+    u64 n_iter = (n_words + (u64)gridDim.x * 256 - 1) / ((u64)gridDim.x * 256);
+    for (u64 it = 0; it < n_iter; ++it) {
+        u64 w = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        u64 a = 0, b = 0;
+        uint32_t mine = 0;
+        if (w < n_words) {
+            a = W[w]; b = W[w + 1];
+            for (int k = 0; k < 32; ++k) {
+                if ((w << 5) + k >= n) break;
+                u64 key = k ? (a << (2 * k)) | (b >> (64 - 2 * k)) : a;
+                uint32_t bin = (uint32_t)(key >> (64 - 2 * LH_IB_PFX));
+                mine += bin >= bin_lo && bin < bin_hi;
+            }
+        }
+        s_cnt[threadIdx.x] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int t = 0; t < 256; ++t) { uint32_t c = s_cnt[t]; s_cnt[t] = tot; tot += c; }
+            s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        if (mine) {
+            u64 o = s_base + s_cnt[threadIdx.x];
+            u64 c = W[w + 2];
+            for (int k = 0; k < 32; ++k) {
+                if ((w << 5) + k >= n) break;
+                u64 key = k ? (a << (2 * k)) | (b >> (64 - 2 * k)) : a;
+                uint32_t bin = (uint32_t)(key >> (64 - 2 * LH_IB_PFX));
+                if (bin >= bin_lo && bin < bin_hi) { keys[o] = key; vals[o] = (w << 5) + k; ++o; }
+            }
+            (void)c;
+        }
+        __syncthreads();
+    }
+}
+
+// number of chunk slots j > 0 whose key equals its predecessor's
+__global__ void __launch_bounds__(256) k_ib_count_ties(const u64* __restrict__ keys, u64 cnt, unsigned long long* __restrict__ n_ties) {
+    unsigned long long mine = 0;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1; j < cnt; j += (u64)gridDim.x * blockDim.x) mine += keys[j] == keys[j - 1];
+    if (mine) atomicAdd(n_ties, mine);
+}
+
+// every group of equal keys, sorted in place by its head's lane: heap sort over the suffixes' text from symbol 32 on
+__global__ void __launch_bounds__(256) k_ib_sort_groups(const u64* __restrict__ W, u64 n, const u64* __restrict__ keys, u64* __restrict__ vals, u64 cnt) {
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j + 1 < cnt; j += (u64)gridDim.x * blockDim.x) {
+        u64 k = keys[j];
+        if ((j > 0 && keys[j - 1] == k) || keys[j + 1] != k) continue;   // not the head of a group of >= 2
+        u64 e = j + 2;
+        while (e < cnt && keys[e] == k) ++e;
+        u64* v = vals + j;
+        u64 m = e - j;
+        if (m == 2) {
+            if (ib_suf_less(W, n, v[1], v[0], 32)) { u64 t = v[0]; v[0] = v[1]; v[1] = t; }
+            continue;
+        }
+        // heap sort (max-heap, in place)
+        for (u64 start = m / 2; start-- > 0;) {
+            u64 root = start;
+            for (;;) {
+                u64 child = 2 * root + 1;
+                if (child >= m) break;
+                if (child + 1 < m && ib_suf_less(W, n, v[child], v[child + 1], 32)) ++child;
+                if (!ib_suf_less(W, n, v[root], v[child], 32)) break;
+                u64 t = v[root]; v[root] = v[child]; v[child] = t;
+                root = child;
+            }
+        }
+        for (u64 end = m - 1; end > 0; --end) {
+            u64 t = v[0]; v[0] = v[end]; v[end] = t;
+            u64 root = 0;
+            for (;;) {
+                u64 child = 2 * root + 1;
+                if (child >= end) break;
+                if (child + 1 < end && ib_suf_less(W, n, v[child], v[child + 1], 32)) ++child;
+                if (!ib_suf_less(W, n, v[root], v[child], 32)) break;
+                u64 t2 = v[root]; v[root] = v[child]; v[child] = t2;
+                root = child;
+            }
+        }
+    }
+}
+
+// chunk -> its rows of the full suffix array (row 0 is the sentinel's); the row of suffix 0 is `primary`
+__global__ void __launch_bounds__(256) k_ib_write_sa(const u64* __restrict__ vals, u64 cnt, u64 row0, u64* __restrict__ sa, unsigned long long* __restrict__ primary) {
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += (u64)gridDim.x * blockDim.x) {
+        u64 v = vals[j];
+        sa[row0 + j] = v;
+        if (v == 0) *primary = row0 + j;
+    }
+}
+
+// ---- BWT in the .bwt file's layout (bwt.c bwt_bwtupdate_core): per 128 symbols [4 x u64 counts before the block][8 x u32 of
+// 2-bit symbols, first symbol in the top bits]; one more count record after the last block.  The '$' row is left out.
+// symbol of stored position j: row = j + (j >= primary); preceded by T[sa[row] - 1] (row 0: the sentinel suffix, preceded by T[n-1])
+__device__ __forceinline__ uint32_t ib_bwt_sym(const u64* __restrict__ W, const u64* __restrict__ sa, u64 n, u64 primary, u64 j) {
+    u64 row = j + (j >= primary);
+    u64 s = row == 0 ? n : sa[row];
+    return (uint32_t)ib_sym(W, s - 1);
+}
+// pass 1: the symbol words of every block and the block's own counts (4 x u32)
+__global__ void __launch_bounds__(256) k_ib_bwt_blocks(const u64* __restrict__ W, const u64* __restrict__ sa, u64 n, u64 primary, u64 n_blk, uint32_t* __restrict__ bwa,
+                                                       u64 bwa_words, uint32_t* __restrict__ blk_cnt) {
+    for (u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x; b < n_blk; b += (u64)gridDim.x * blockDim.x) {
+        uint32_t c[4] = {0, 0, 0, 0};
+        for (int t = 0; t < 8; ++t) {
+            u64 j0 = (b << 7) + ((u64)t << 4);
+            if (j0 >= n) break;
+            uint32_t word = 0;
+            for (int s = 0; s < 16 && j0 + s < n; ++s) {
+                uint32_t sym = ib_bwt_sym(W, sa, n, primary, j0 + s);
+                word |= sym << ((15 - s) << 1);
+                ++c[sym];
+            }
+            u64 wo = (b << 4) + 8 + t;
+            if (wo < bwa_words) bwa[wo] = word;
+        }
+        blk_cnt[4 * b] = c[0]; blk_cnt[4 * b + 1] = c[1]; blk_cnt[4 * b + 2] = c[2]; blk_cnt[4 * b + 3] = c[3];
+    }
+}
+// pass 2: per tile of LH_IB_TILE blocks the tile's totals
+#define LH_IB_TILE 1024
+__global__ void __launch_bounds__(256) k_ib_tile_sums(const uint32_t* __restrict__ blk_cnt, u64 n_blk, u64* __restrict__ tile_sum) {
+    __shared__ u64 s[4][256];
+    u64 b0 = (u64)blockIdx.x * LH_IB_TILE;
+    u64 c[4] = {0, 0, 0, 0};
+    for (int u = 0; u < LH_IB_TILE / 256; ++u) {
+        u64 b = b0 + (u64)threadIdx.x * (LH_IB_TILE / 256) + u;
+        if (b < n_blk) for (int q = 0; q < 4; ++q) c[q] += blk_cnt[4 * b + q];
+    }
+    for (int q = 0; q < 4; ++q) s[q][threadIdx.x] = c[q];
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) for (int q = 0; q < 4; ++q) s[q][threadIdx.x] += s[q][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) for (int q = 0; q < 4; ++q) tile_sum[4 * (u64)blockIdx.x + q] = s[q][0];
+}
+// pass 3: exclusive scan of the tile totals (one workgroup; thread t owns a contiguous slice)
+__global__ void __launch_bounds__(256) k_ib_scan_tiles(u64 n_tiles, u64* __restrict__ tile_sum) {
+    __shared__ u64 s[4][256];
+    u64 per = (n_tiles + 255) / 256;
+    u64 t0 = (u64)threadIdx.x * per, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    u64 c[4] = {0, 0, 0, 0};
+    for (u64 t = t0; t < t1; ++t) for (int q = 0; q < 4; ++q) c[q] += tile_sum[4 * t + q];
+    for (int q = 0; q < 4; ++q) s[q][threadIdx.x] = c[q];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 4; ++q) { u64 acc = 0; for (int t = 0; t < 256; ++t) { u64 v = s[q][t]; s[q][t] = acc; acc += v; } }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) c[q] = s[q][threadIdx.x];
+    for (u64 t = t0; t < t1; ++t) for (int q = 0; q < 4; ++q) { u64 v = tile_sum[4 * t + q]; tile_sum[4 * t + q] = c[q]; c[q] += v; }
+}
+// pass 4: the count records (counts BEFORE each block), and the closing record after the last block
+__global__ void __launch_bounds__(256) k_ib_bwa_counts(const uint32_t* __restrict__ blk_cnt, u64 n_blk, const u64* __restrict__ tile_base, uint32_t* __restrict__ bwa,
+                                                       u64 bwa_words) {
+    __shared__ u64 s[4][256];
+    const int PER = LH_IB_TILE / 256;
+    u64 b0 = (u64)blockIdx.x * LH_IB_TILE + (u64)threadIdx.x * PER;
+    u64 c[4] = {0, 0, 0, 0};
+    for (int u = 0; u < PER; ++u) if (b0 + u < n_blk) for (int q = 0; q < 4; ++q) c[q] += blk_cnt[4 * (b0 + u) + q];
+    for (int q = 0; q < 4; ++q) s[q][threadIdx.x] = c[q];
+    __syncthreads();
+    if (threadIdx.x < 4) { int q = threadIdx.x; u64 acc = tile_base[4 * (u64)blockIdx.x + q]; for (int t = 0; t < 256; ++t) { u64 v = s[q][t]; s[q][t] = acc; acc += v; } }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) c[q] = s[q][threadIdx.x];
+    for (int u = 0; u < PER; ++u) {
+        u64 b = b0 + u;
+        if (b > n_blk) break;
+        u64 wo = b < n_blk ? b << 4 : bwa_words - 8;   // b == n_blk: the closing record
+        for (int q = 0; q < 4; ++q) { bwa[wo + 2 * q] = (uint32_t)c[q]; bwa[wo + 2 * q + 1] = (uint32_t)(c[q] >> 32); }
+        if (b < n_blk) for (int q = 0; q < 4; ++q) c[q] += blk_cnt[4 * b + q];
+    }
+}
+
+// every v-th row of a suffix array sampled every `have`-th row (v a multiple of have)
+__global__ void __launch_bounds__(256) k_ib_sa_subsample(const u64* __restrict__ sa, u64 step, u64 n_new, u64* __restrict__ out) {
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_new; j += (u64)gridDim.x * blockDim.x) out[j] = sa[j * step];
+}
+
+// the inverse of lh_host.inc's k_occ_relayout: occurrence records -> the .bwt file's layout (lh_index_export)
+__global__ void __launch_bounds__(256) k_ib_occ_to_bwa(const uint4* __restrict__ occ, const u64* __restrict__ sb, int sb_shift, u64 n, u64 n_blk, uint32_t* __restrict__ bwa,
+                                                       u64 bwa_words) {
+    for (u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x; b <= n_blk; b += (u64)gridDim.x * blockDim.x) {
+        u64 wo = b < n_blk ? b << 4 : bwa_words - 8;
+        u64 c[4];
+        if (b < n_blk) {
+            uint4 h = occ[4 * b];
+            c[0] = h.x; c[1] = h.y; c[2] = h.z; c[3] = h.w;
+            if (sb) { const u64* q = sb + (((b << 7) >> sb_shift) << 2); c[0] += q[0]; c[1] += q[1]; c[2] += q[2]; c[3] += q[3]; }
+        } else {   // totals: the last record's counts plus its symbols
+            u64 last = n - 1, r = last >> 6;
+            uint4 h = occ[2 * r], d = occ[2 * r + 1];
+            int m = (int)(last & 63) + 1;
+            u64 mask = ~0ull >> (64 - m);
+            u64 hi = ((u64)d.y << 32 | d.x) & mask, lo = ((u64)d.w << 32 | d.z) & mask;
+            u64 i3 = hi & lo, i2 = hi ^ i3, i1 = lo ^ i3;
+            int n3 = __popcll(i3), n2 = __popcll(i2), n1 = __popcll(i1);
+            c[0] = (u64)h.x + (u64)(m - n1 - n2 - n3); c[1] = (u64)h.y + n1; c[2] = (u64)h.z + n2; c[3] = (u64)h.w + n3;
+            if (sb) { const u64* q = sb + ((last >> sb_shift) << 2); c[0] += q[0]; c[1] += q[1]; c[2] += q[2]; c[3] += q[3]; }
+        }
+        for (int q = 0; q < 4; ++q) { bwa[wo + 2 * q] = (uint32_t)c[q]; bwa[wo + 2 * q + 1] = (uint32_t)(c[q] >> 32); }
+        if (b == n_blk) continue;
+        for (int half = 0; half < 2; ++half) {
+            u64 r = 2 * b + half;
+            if ((r << 6) >= n) break;
+            uint4 d = occ[2 * r + 1];
+            u64 hi = (u64)d.y << 32 | d.x, lo = (u64)d.w << 32 | d.z;
+            for (int t = 0; t < 4; ++t) {
+                u64 j0 = (r << 6) + ((u64)t << 4);
+                if (j0 >= n) break;
+                uint32_t word = 0;
+                for (int s = 0; s < 16; ++s) {
+                    int bit = t * 16 + s;
+                    uint32_t sym = (uint32_t)((hi >> bit & 1) << 1 | (lo >> bit & 1));
+                    if (j0 + s < n) word |= sym << ((15 - s) << 1);
+                }
+                bwa[wo + 8 + 4 * half + t] = word;
+            }
+        }
+    }
+}

@@ -89,6 +89,28 @@ int lo_index_load(const char* prefix, Index** out) {
     return LH_OK;
 }
 
+// an index from in-memory images in the files' layout (what lh_index_export returns): the oracle for device-built indexes
+int lo_index_from_arrays(uint64_t primary, const uint64_t L2[5], const uint32_t* bwt, uint64_t bwt_words, int32_t sa_intv, const uint64_t* sa, uint64_t n_sa,
+                         const uint8_t* pac, int64_t l_pac, int32_t n_contigs, const int64_t* contig_off, const int32_t* contig_len, const char* const* contig_name,
+                         Index** out) {
+    auto idx = std::make_unique<Index>();
+    idx->primary = primary;
+    for (int i = 0; i < 5; ++i) idx->L2[i] = L2[i];
+    idx->seq_len = L2[4]; idx->bwt_size = bwt_words;
+    idx->bwt.assign(bwt, bwt + bwt_words);
+    idx->sa_intv = sa_intv; idx->n_sa = n_sa;
+    idx->sa.assign(sa, sa + n_sa);
+    idx->l_pac = l_pac;
+    idx->pac.assign(pac, pac + (l_pac / 4 + 1));
+    for (int i = 0; i < n_contigs; ++i) {
+        Contig c;
+        c.name = contig_name[i]; c.offset = contig_off[i]; c.len = contig_len[i];
+        idx->contigs.push_back(c);
+    }
+    *out = idx.release();
+    return LH_OK;
+}
+
 // naive builder (small genomes): nt4 contigs -> index in memory
 int lo_index_build_naive(int32_t n_contigs, const char* const* names, const uint8_t* const* nt4, const int64_t* lens, Index** out) {
     std::vector<std::string> nm;

@@ -26,6 +26,8 @@ class Oracle:
         L.lo_opts_init.argtypes = [C.POINTER(capi.LhOpts)]
         L.lo_index_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.lo_index_build_naive.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(capi.c_u8p), capi.c_i64p, C.POINTER(C.c_void_p)]
+        L.lo_index_from_arrays.argtypes = [C.c_uint64, capi.c_u64p, capi.c_u32p, C.c_uint64, C.c_int32, capi.c_u64p, C.c_uint64, capi.c_u8p, C.c_int64, C.c_int32,
+                                           capi.c_i64p, capi.c_i32p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         L.lo_index_free.argtypes = [C.c_void_p]
         L.lo_index_l_pac.argtypes = [C.c_void_p]
         L.lo_index_l_pac.restype = C.c_int64
@@ -66,6 +68,22 @@ class Oracle:
         rc = self.L.lo_index_load(prefix.encode(), C.byref(h))
         if rc:
             raise RuntimeError(self.L.lo_last_error().decode())
+        return OracleIndex(self, h)
+
+    def index_from_arrays(self, arrs, pac):
+        """arrs: what capi.Index.export() returns; pac: the .pac image"""
+        n = len(arrs["contigs"])
+        names = (C.c_char_p * n)(*[c[0].encode() for c in arrs["contigs"]])
+        lens = np.array([c[1] for c in arrs["contigs"]], dtype=np.int32)
+        offs = np.array([c[2] for c in arrs["contigs"]], dtype=np.int64)
+        L2 = np.ascontiguousarray(arrs["L2"], dtype=np.uint64)
+        bwt = np.ascontiguousarray(arrs["bwt"], dtype=np.uint32)
+        sa = np.ascontiguousarray(arrs["sa"], dtype=np.uint64)
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        h = C.c_void_p()
+        self.L.lo_index_from_arrays(int(arrs["primary"]), L2.ctypes.data_as(capi.c_u64p), bwt.ctypes.data_as(capi.c_u32p), len(bwt), int(arrs["sa_intv"]),
+                                    sa.ctypes.data_as(capi.c_u64p), len(sa), pac.ctypes.data_as(capi.c_u8p), int(arrs["l_pac"]), n,
+                                    offs.ctypes.data_as(capi.c_i64p), lens.ctypes.data_as(capi.c_i32p), names, C.byref(h))
         return OracleIndex(self, h)
 
     def index_build_naive(self, names, seqs_nt4):

@@ -37,14 +37,12 @@ def test_emu_front_synthetic(emu, oracle):
     helpers.assert_same_result(res, oidx.align_barcodes(b, oracle.opts(run_inference=0)), inference=False)
 
 
-def test_emu_occ_superblocks_and_sparse_sa(emu, oracle, monkeypatch):
+def test_emu_occ_superblocks_and_sparse_sa(emu, oracle):
     """the occurrence table's u32 counts are relative to super-block bases (needed past 2^31 symbols, e.g. hg38): force
     tiny super-blocks; and keep the .sa file's sampling so that bwt_sa really walks the re-laid-out BWT"""
-    monkeypatch.setenv("LH_SB_SHIFT", "14")
-    monkeypatch.setenv("LH_SA_INTV", "32")
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
-    idx = emu.index_from_arrays(oidx.arrays())
+    idx = emu.index_from_arrays(oidx.arrays(), sb_shift=14, sa_intv=32)
     assert idx.sa_interval == 32
     rs = helpers.small_reads(names, contigs, n_barcodes=2, pairs=30, junk=0.05, seed=11)
     b = helpers.batch_of(rs)
@@ -64,15 +62,14 @@ def test_emu_full_inference(emu, oracle):
     assert (res.active_idx >= 0).all()
 
 
-def test_emu_inference_slab_overflow_pass(emu, oracle, monkeypatch):
+def test_emu_inference_slab_overflow_pass(emu, oracle):
     """barcodes whose tables outgrow a wave's slab are redone by the second launch with large slabs: force that path"""
-    monkeypatch.setenv("LH_RFA_SLAB_KB", "4")
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
     idx = emu.index_from_arrays(oidx.arrays())
     rs = helpers.small_reads(names, contigs, n_barcodes=3, pairs=30, junk=0.05, seed=21)
     b = helpers.batch_of(rs)
-    res = idx.context(rs.n_pairs).align_barcodes(b)
+    res = idx.context(rs.n_pairs, rfa_slab_kb=4).align_barcodes(b)
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
 
 
@@ -89,8 +86,8 @@ def test_emu_long_noisy_reads(emu, oracle):
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
 
 
-def test_emu_k1_launch_variants_and_sweep_filter(emu, oracle, monkeypatch):
-    """K1 as three launches (default), two (LH_SMEM4_P12) or one (LH_SMEM4_FUSED), with and without the sweep filter: the same
+def test_emu_k1_launch_variants_and_sweep_filter(emu, oracle):
+    """K1 as three launches (default), two (LH_F_SMEM_P12) or one (LH_F_SMEM_FUSED), with and without the sweep filter: the same
     intervals / seeds / chains as the oracle every time; the filter executes fewer bwt_extend calls, without it the count is
     the reference's"""
     names, contigs = helpers.small_genome()
@@ -103,15 +100,12 @@ def test_emu_k1_launch_variants_and_sweep_filter(emu, oracle, monkeypatch):
     want_ext = oidx.align_barcodes(b, oracle.opts(run_inference=0)).counters["n_ext"]
     ctx = idx.context(rs.n_pairs)
     seen = {}
-    for env in ({}, {"LH_SMEM4_P12": "1"}, {"LH_SMEM4_FUSED": "1"}, {"LH_NO_SWEEP_FILTER": "1"}, {"LH_NO_SWEEP_FILTER": "1", "LH_SMEM4_FUSED": "1"}):
-        for k in ("LH_SMEM4_P12", "LH_SMEM4_FUSED", "LH_NO_SWEEP_FILTER"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        helpers.assert_same_dump(ctx.stage_dump(b), want, helpers.DUMP_FRONT)
-        seen[tuple(sorted(env))] = ctx.align_barcodes(b, emu.opts(run_inference=0)).counters["n_ext"]
-    assert seen[("LH_NO_SWEEP_FILTER",)] == want_ext == seen[("LH_NO_SWEEP_FILTER", "LH_SMEM4_FUSED")]
-    assert seen[()] == seen[("LH_SMEM4_P12",)] == seen[("LH_SMEM4_FUSED",)] < want_ext
+    P12, FUSED, NOF = capi.LH_F_SMEM_P12, capi.LH_F_SMEM_FUSED, capi.LH_F_NO_SWEEP_FILTER
+    for flags in (0, P12, FUSED, NOF, NOF | FUSED):
+        helpers.assert_same_dump(ctx.stage_dump(b, emu.opts(flags=flags)), want, helpers.DUMP_FRONT)
+        seen[flags] = ctx.align_barcodes(b, emu.opts(run_inference=0, flags=flags)).counters["n_ext"]
+    assert seen[NOF] == want_ext == seen[NOF | FUSED]
+    assert seen[0] == seen[P12] == seen[FUSED] < want_ext
 
 
 def test_emu_many_candidate_pairs_go_rng_ring(emu, oracle):

@@ -59,21 +59,11 @@ def test_candidates_synthetic(lib, oracle, seed, junk):
     # n_ext: K1's sweep filter leaves intervals out of the backward sweeps that cannot give a seed (k_smem4.h): fewer bwt_extend
     # than the reference; without the filter (honoured per call) the count is the reference's
     assert 0 < res.counters["n_ext"] < ores.counters["n_ext"]
-    os.environ["LH_NO_SWEEP_FILTER"] = "1"
-    try:
-        res_nf = ctx.align_barcodes(b, lib.opts(run_inference=0))
-    finally:
-        del os.environ["LH_NO_SWEEP_FILTER"]
+    res_nf = ctx.align_barcodes(b, lib.opts(run_inference=0, flags=capi.LH_F_NO_SWEEP_FILTER))
     helpers.assert_same_result(res_nf, ores, inference=False)
     assert res_nf.counters["n_ext"] == ores.counters["n_ext"]
     # the three passes in ONE kernel (k_smem4_t<0>, what bench.py's reference-count pass launches): same results, same count
-    os.environ["LH_NO_SWEEP_FILTER"] = "1"
-    os.environ["LH_SMEM4_FUSED"] = "1"
-    try:
-        res_fu = ctx.align_barcodes(b, lib.opts(run_inference=0))
-    finally:
-        del os.environ["LH_NO_SWEEP_FILTER"]
-        del os.environ["LH_SMEM4_FUSED"]
+    res_fu = ctx.align_barcodes(b, lib.opts(run_inference=0, flags=capi.LH_F_NO_SWEEP_FILTER | capi.LH_F_SMEM_FUSED))
     helpers.assert_same_result(res_fu, ores, inference=False)
     assert res_fu.counters["n_ext"] == ores.counters["n_ext"]
     # ext_cells counts the DP cells the device evaluated: extensions that are provably ungapped (k_extend2.h) skip their DP

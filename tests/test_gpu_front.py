@@ -36,14 +36,12 @@ def test_front_synthetic(lib, oracle):
 
 
 @pytest.mark.gpu
-def test_occ_superblocks_and_sparse_sa(lib, oracle, monkeypatch):
+def test_occ_superblocks_and_sparse_sa(lib, oracle):
     """u32 occurrence counts relative to super-block bases (forced small here; real use: > 2^31 symbols) and bwt_sa walking
     the re-laid-out BWT at the .sa file's own sampling interval"""
-    monkeypatch.setenv("LH_SB_SHIFT", "14")
-    monkeypatch.setenv("LH_SA_INTV", "32")
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
-    idx = lib.index_from_arrays(oidx.arrays())
+    idx = lib.index_from_arrays(oidx.arrays(), sb_shift=14, sa_intv=32)
     assert idx.sa_interval == 32
     rs = helpers.small_reads(names, contigs, n_barcodes=8, pairs=60, junk=0.05, seed=11)
     b = helpers.batch_of(rs)

@@ -95,15 +95,14 @@ def test_round_trip_properties_large(lib):
     assert ok.mean() > 0.99
 
 
-def test_slab_overflow_second_pass(lib, oracle, monkeypatch):
+def test_slab_overflow_second_pass(lib, oracle):
     """barcodes whose tables outgrow a wave's slab are redone by the second k_rfa launch with large slabs"""
-    monkeypatch.setenv("LH_RFA_SLAB_KB", "8")
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
     idx = lib.index_from_arrays(oidx.arrays())
     rs = helpers.small_reads(names, contigs, n_barcodes=6, pairs=80, junk=0.03, seed=23)
     b = helpers.batch_of(rs)
-    res = idx.context(rs.n_pairs).align_barcodes(b)
+    res = idx.context(rs.n_pairs, rfa_slab_kb=8).align_barcodes(b)
     helpers.assert_same_result(res, oidx.align_barcodes(b, threads=8), inference=True)
 
 

@@ -1,0 +1,118 @@
+"""lh_index_build_device (FM-index construction in HBM, k_index_build.h): the index it leaves resident, exported back to the
+layout of `bwa index`'s files, must be byte-identical to the reference's PhiX fixture (go/src/test/inputs/phix/PhiX.fa.*) and to
+the oracle's builder on genomes with repeats; CPU runs use the kernel sources under the emulator, `-m gpu` the product."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from lariat_amd import capi
+
+EMU = os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "hipemu")])
+    return capi.Library(EMU)
+
+
+def pac_of(contigs):
+    g = np.concatenate(contigs).astype(np.uint8)
+    l_pac = len(g)
+    pad = np.zeros((l_pac // 4 + 1) * 4, dtype=np.uint8)
+    pad[:l_pac] = g
+    q = pad.reshape(-1, 4)
+    pac = (q[:, 0] << 6 | q[:, 1] << 4 | q[:, 2] << 2 | q[:, 3]).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(c) for c in contigs])])
+    return pac, l_pac, offs
+
+
+def check_against(lib, oidx, names, contigs, **index_opts):
+    pac, l_pac, offs = pac_of(contigs)
+    ctg = [(names[i], len(contigs[i]), int(offs[i])) for i in range(len(names))]
+    idx = lib.index_build_device(pac, l_pac, ctg, **index_opts)
+    want = oidx.arrays()
+    got = idx.export(sa_intv=32)
+    assert got["primary"] == want["primary"]
+    assert list(got["L2"]) == list(want["L2"])
+    assert np.array_equal(got["bwt"], want["bwt"])
+    assert np.array_equal(got["sa"], want["sa"])
+    return idx
+
+
+def phix(oracle):
+    names, seqs = helpers.read_fasta(helpers.PHIX)
+    contigs = [capi.sequence_convert(s) for s in seqs]
+    return names, contigs, oracle.index_load(helpers.PHIX)
+
+
+def test_emu_device_build_reproduces_phix_fixture(emu, oracle, tmp_path):
+    names, contigs, oidx = phix(oracle)
+    for opts in ({}, {"build_chunk_log2": 9}, {"build_chunk_log2": 6, "sa_intv": 4}):   # one chunk; many chunks; sparse resident SA
+        idx = check_against(emu, oidx, names, contigs, **opts)
+    # the files lh_index_save writes are the fixture's, byte for byte
+    idx = check_against(emu, oidx, names, contigs)
+    prefix = str(tmp_path / "PhiX.fa")
+    idx.save(prefix)
+    for ext in (".bwt", ".sa", ".pac", ".ann", ".amb"):
+        assert open(prefix + ext, "rb").read() == open(helpers.PHIX + ext, "rb").read(), ext
+
+
+def test_emu_device_build_with_repeats_and_aligns(emu, oracle):
+    """exact repeats (ties past the 32-base sort key, groups of 20+), several contigs, and the index is then USED"""
+    names, contigs, unit, spacer = helpers.exact_repeat_genome(copies=12, unit=620, spacer=150)
+    contigs = contigs + [np.zeros(700, dtype=np.uint8), contigs[0][500:3000][::-1].copy()]   # poly-A; a reversed copy
+    names = names + ["polyA", "rev"]
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = check_against(emu, oidx, names, contigs, build_chunk_log2=11)
+    rs = helpers.repeat_unit_reads(contigs, unit, spacer, n_pairs=4, len1=100, len2=100)
+    b = helpers.batch_of(rs)
+    helpers.assert_same_result(idx.context(rs.n_pairs).align_barcodes(b), oidx.align_barcodes(b), inference=True)
+
+
+def test_emu_export_of_a_loaded_index_is_the_file(emu):
+    idx = emu.index_load(helpers.PHIX, sb_shift=9)
+    got = idx.export(sa_intv=32)
+    raw = np.fromfile(helpers.PHIX + ".bwt", dtype=np.uint8)
+    assert np.array_equal(got["bwt"], raw[40:].view(np.uint32))
+    sa = np.fromfile(helpers.PHIX + ".sa", dtype=np.uint8)[56:].view(np.uint64)
+    assert np.array_equal(got["sa"][1:], sa)
+
+
+@pytest.mark.gpu
+def test_gpu_device_build_phix_and_repeats(oracle):
+    lib = capi.load_library()
+    names, contigs, oidx = phix(oracle)
+    for opts in ({}, {"build_chunk_log2": 8}):
+        check_against(lib, oidx, names, contigs, **opts)
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = check_against(lib, oidx, names, contigs, build_chunk_log2=16)
+    rs = helpers.small_reads(names, contigs, n_barcodes=8, pairs=50, junk=0.03, seed=9)
+    b = helpers.batch_of(rs)
+    helpers.assert_same_result(idx.context(rs.n_pairs).align_barcodes(b), oidx.align_barcodes(b, threads=8), inference=True)
+
+
+def test_emu_index_self_check_and_synth(emu, oracle):
+    """lh_synth_genome / lh_synth_reads feed the device builder; lh_diag_index_check passes on a sound index"""
+    l_pac = 40000
+    pac = emu.synth_genome(l_pac, seed=5)
+    assert np.array_equal(pac, emu.synth_genome(l_pac, seed=5, threads=3))
+    ctg = [("c0", 25000, 0), ("c1", 15000, 25000)]
+    idx = emu.index_build_device(pac, l_pac, ctg, build_chunk_log2=12)
+    checked, bad_order, bad_lf = idx.check(stride=7)
+    assert checked > 10000 and bad_order == 0 and bad_lf == 0
+    r = emu.synth_reads(pac, l_pac, ctg, seed=9, n_barcodes=3, pairs_per_barcode=20, indel_rate=0.002, junk_frac=0.05)
+    r2 = emu.synth_reads(pac, l_pac, ctg, seed=9, n_barcodes=3, pairs_per_barcode=20, indel_rate=0.002, junk_frac=0.05, threads=2)
+    assert np.array_equal(r["seq"], r2["seq"]) and np.array_equal(r["seq_off"], r2["seq_off"])
+    b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
+    res = idx.context(r["n_pairs"]).align_barcodes(b)
+    oidx = oracle.index_from_arrays(idx.export(), pac)
+    helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
+    # most reads land where they were drawn from
+    act = res.active_idx[0::2]
+    ok = (res.rid[act] == r["truth_rid"]) & (np.abs(res.pos[act] - r["truth_pos1"]) < 20)
+    assert ok.mean() > 0.8
