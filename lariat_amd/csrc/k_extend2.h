@@ -246,6 +246,120 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
     return r;
 }
 
+// ksw_extend2 with the FULL band in a circular 64-word window of eh[]: what a row really touches is the live interval
+// [beg, end] that ksw_extend2 itself maintains (it shrinks both ends past zero cells after every row), not the band.  A seed
+// that does not belong to an alignment — at human-genome scale every third read carries one: a 19..22-base chance match that
+// mem_chain_flt keeps as the first shadowed chain — dies within a few rows and a few dozen columns, however long the query
+// side is.  Exactness: (1) row 0 nominally sweeps min(qlen, w+1) columns, but once the first-row values have run out
+// (column value 0, so M = 0 and e = 0), and the insertion score f carried along the row and the cell itself are 0, every
+// further cell of the row is identically 0 and is left out; mj only moves on a cell >= the row maximum, which is > 0 or the
+// row ends the extension; the `end == qlen` bookkeeping uses the nominal end.  (2) After row 0 every column outside the
+// stored window holds h = e = 0 in the full array (beyond the first row's non-zero prefix; or shrunk past, which only
+// happens over zero cells; a column is never written again once beg has passed it), so a column entering the window at the
+// advancing end is materialised as zero + its query base.  (3) Column c and c - 64 share a slot: the live interval must stay
+// narrower than 64 columns, else *overflow is set and the caller defers the read to the wave-per-read kernel.
+__device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uint8_t* q, uint32_t* ehl, int lane, int qoff, int qstep, int qlen, LaneTgt& tg, int tlen,
+                                                       int w, int end_bonus, int zdrop, int h0, u64* cells, int* overflow) {
+    const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+#define EHW(j_) ehl[((j_) & 63) * 64 + lane]
+    int maxsc = a_ > 0 ? a_ : 0;
+    int max_ins = (int)((double)(qlen * maxsc + end_bonus - o_ins) / e_ins + 1.);
+    max_ins = max_ins > 1 ? max_ins : 1;
+    w = w < max_ins ? w : max_ins;
+    int max_del = (int)((double)(qlen * maxsc + end_bonus - o_del) / e_del + 1.);
+    max_del = max_del > 1 ? max_del : 1;
+    w = w < max_del ? w : max_del;
+    int n_mat = 0;   // columns [0, n_mat) have a slot holding their value; columns >= n_mat are zero (after row 0) and not stored yet
+#define EH_MAT(upto_, row0_)                                                                                  \
+    for (; n_mat <= (upto_); ++n_mat) {                                                                       \
+        int v_ = 0;                                                                                           \
+        if (row0_) { v_ = n_mat == 0 ? h0 : h0 - oe_ins - (n_mat - 1) * e_ins; v_ = v_ > 0 ? v_ : 0; }        \
+        int qv_ = n_mat < qlen ? (int)q[qoff + qstep * n_mat] : 4;                                            \
+        EHW(n_mat) = EH_PACK(qv_ > 4 ? 4 : qv_, 0, v_);                                                       \
+    }
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    int beg = 0, end = qlen;
+    u64 ncell = 0;
+    int over = 0;
+    for (int i = 0; i < tlen; ++i) {
+        int f = 0, h1, m = 0, mj = -1;
+        int tb = tg.base(i);
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+        else h1 = 0;
+        int j, cut = 0;
+        if (i == 0) { EH_MAT(1 < qlen ? 1 : qlen, 1) }
+        else {
+            if (end - beg > 63) { over = 1; break; }
+            EH_MAT(end, 0)
+        }
+        uint32_t p = EHW(beg);
+        for (j = beg; j < end; ++j) {
+            if (i == 0 && n_mat <= j + 1) {   // row 0 materialises its columns as it goes (j + 1 <= qlen)
+                if (j + 1 > 63) { over = 1; break; }
+                EH_MAT(j + 1, 1)
+            }
+            uint32_t pnext = EHW(j + 1);
+            int M = EH_H(p), e = EH_E(p), qv = EH_Q(p);
+            int sc = qv > 3 ? -1 : (tb == qv ? a_ : -b_);
+            const int m_in = M;
+            M = M ? M + sc : 0;
+            int h = M > e ? M : e;
+            h = h > f ? h : f;
+            mj = m > h ? mj : j;
+            m = m > h ? m : h;
+            int t = M - oe_del; t = t > 0 ? t : 0;
+            e -= e_del; e = e > t ? e : t;
+            EHW(j) = EH_PACK(qv, e, h1);
+            h1 = h;
+            t = M - oe_ins; t = t > 0 ? t : 0;
+            f -= e_ins; f = f > t ? f : t;
+            p = pnext;
+            ++ncell;
+            if (i == 0 && m_in == 0 && e == 0 && f == 0 && h == 0 && j >= 1) { cut = 1; ++j; break; }   // the rest of row 0 is identically zero
+        }
+        if (over) break;
+        if (cut) {
+            // cells [j, end) and eh[end] are zero; stored slots among them (at most column j, just materialised with a zero first-row value) already are
+            h1 = 0;
+        } else { uint32_t pe = EHW(end); EHW(end) = EH_PACK(EH_Q(pe), 0, h1); }
+        if (end == qlen) {
+            max_ie = gscore > h1 ? max_ie : i;
+            gscore = gscore > h1 ? gscore : h1;
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            int d = mj - i; d = d < 0 ? -d : d;
+            max_off = max_off > d ? max_off : d;
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) {
+                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+            } else {
+                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+            }
+        }
+        for (j = beg; j < end && (j >= n_mat || (EHW(j) & 0x1fffffffu) == 0); ++j) {}
+        beg = j;
+        j = end < n_mat ? end : n_mat - 1;   // columns >= n_mat are zero
+        for (; j >= beg && (EHW(j) & 0x1fffffffu) == 0; --j) {}
+        end = j + 2 < qlen ? j + 2 : qlen;
+    }
+#undef EHW
+#undef EH_MAT
+    if (cells) *cells += ncell;
+    *overflow = over;
+#ifdef LH_EMU
+    if (getenv("LH_DYN_TRACE")) fprintf(stderr, "dyn qlen=%d h0=%d w=%d cells=%llu over=%d score=%d\n", qlen, h0, w, (unsigned long long)ncell, over, max);
+#endif
+    ExtRes r;
+    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    return r;
+}
+
 // Reads order[range[0] .. range[1]).  EHW_ = LDS words per lane: a read that turns out to need an extension of EHW_ or more
 // columns (its bucket only bounds the FIRST extension) is left without output and appended to the deferred list, which the
 // wave-per-read kernel processes afterwards from scratch.
@@ -370,17 +484,24 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                     }
                     K4_T(3)
                     const int circ = narrow && narrow <= LH_EXT_CIRC_MAX_W && EHW_ >= 64;   // a narrow band needs 64 words whatever qlen is
-                    if (!proven && !circ && qlen >= EHW_) { deferred = 1; break; }
+                    const int dyn = !proven && !circ && qlen >= EHW_;   // full band, query side longer than the LDS window: live-interval window
+                    if (dyn && EHW_ < 64) { deferred = 1; break; }
                     for (int i = 0; i < 2 && !proven; ++i) {   // MAX_BAND_TRY
                         int prev = a.score;
                         aw = o.w << i;
                         LaneTgt tg;
                         tg.init(ix, tc0, tstep);
-                        e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, narrow && narrow < aw ? narrow : aw, bonus, o.zdrop, h0, &cells,
-                                             circ ? 63 : -1);
+                        if (dyn) {
+                            int over = 0;
+                            e = lane_ksw_extend2_dyn(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells, &over);
+                            if (over) { deferred = 1; break; }
+                        } else
+                            e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, narrow && narrow < aw ? narrow : aw, bonus, o.zdrop, h0, &cells,
+                                                 circ ? 63 : -1);
                         a.score = e.score;
                         if (a.score == prev || e.max_off < (aw >> 1) + (aw >> 2)) break;
                     }
+                    if (deferred) break;
                     if (side == 0) {
                         aw0 = aw;
                         if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip5) { a.qb = s.qbeg - e.qle; a.rb = s.rbeg - e.tle; a.truesc = a.score; }   // local extension

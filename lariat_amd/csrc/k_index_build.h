@@ -101,14 +101,12 @@ __global__ void __launch_bounds__(256) k_ib_gather(const u64* __restrict__ W, u6
         __syncthreads();
         if (mine) {
             u64 o = s_base + s_cnt[threadIdx.x];
-            u64 c = W[w + 2];
             for (int k = 0; k < 32; ++k) {
                 if ((w << 5) + k >= n) break;
                 u64 key = k ? (a << (2 * k)) | (b >> (64 - 2 * k)) : a;
                 uint32_t bin = (uint32_t)(key >> (64 - 2 * LH_IB_PFX));
                 if (bin >= bin_lo && bin < bin_hi) { keys[o] = key; vals[o] = (w << 5) + k; ++o; }
             }
-            (void)c;
         }
         __syncthreads();
     }
@@ -159,6 +157,21 @@ __global__ void __launch_bounds__(256) k_ib_sort_groups(const u64* __restrict__ 
             }
         }
     }
+}
+
+// bit (row0 + j) of rep <- suffixes j and j + 1 of the chunk share their first 19 bases, both complete (lh_dev.h LH_BLOOM_K);
+// chunks of different prefixes never do.  The sweep filter's "occurs at least twice" set is built from these bits.
+__global__ void __launch_bounds__(256) k_ib_rep_bits(const u64* __restrict__ keys, const u64* __restrict__ vals, u64 cnt, u64 row0, u64 n, u64* __restrict__ rep,
+                                                     unsigned long long* __restrict__ n_rep) {
+    unsigned long long mine = 0;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j + 1 < cnt; j += (u64)gridDim.x * blockDim.x) {
+        if ((keys[j] >> (64 - 2 * LH_BLOOM_K)) != (keys[j + 1] >> (64 - 2 * LH_BLOOM_K))) continue;
+        if (vals[j] + LH_BLOOM_K > n || vals[j + 1] + LH_BLOOM_K > n) continue;
+        u64 row = row0 + j;
+        atomicOr((unsigned long long*)&rep[row >> 6], 1ull << (row & 63));
+        ++mine;
+    }
+    if (mine) atomicAdd(n_rep, mine);
 }
 
 // chunk -> its rows of the full suffix array (row 0 is the sentinel's); the row of suffix 0 is `primary`

@@ -129,3 +129,41 @@ def repeat_unit_reads(contigs, unit, spacer, n_pairs, seed=4, copy=3, len1=120, 
     rs.names = names
     rs.name_seed = synth._name_seeds(names)
     return rs
+
+
+def chance_match_genome_and_reads(n_pairs=24, seed=8, plant=21, rlen=150):
+    """a random contig in which the MIDDLE `plant` bases of every read 1 (and of some reads 2) also occur at an unrelated place:
+    re-seeding (bwt_smem1 from the middle of a long SMEM with min_intv 2) then yields a second, one-seed chain per read that
+    mem_chain_flt keeps as the first shadowed chain and mem_chain2aln extends with the full band over long query sides — at
+    human-genome scale chance matches do that to every third read"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=260000).astype(np.uint8)
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    loci = []
+    for i in range(n_pairs):
+        p = 5000 + i * 4000 + int(rng.integers(0, 1000))
+        ins = int(rng.integers(320, 480))
+        loci.append((p, ins))
+        mid = p + rlen // 2 - plant // 2
+        g[150000 + i * 300: 150000 + i * 300 + plant] = g[mid: mid + plant]
+        if i % 3 == 0:   # read 2's middle as well (reverse strand)
+            mid2 = p + ins - rlen // 2 - plant // 2
+            g[200000 + i * 300: 200000 + i * 300 + plant] = g[mid2: mid2 + plant]
+    reads, names = [], []
+    for i, (p, ins) in enumerate(loci):
+        r1 = g[p:p + rlen].copy()
+        r2 = comp[g[p + ins - rlen:p + ins][::-1]]
+        if i % 2:
+            r1[int(rng.integers(5, 40))] ^= 2      # a mismatch off the middle: the planted match still covers the re-seeding point
+        if i % 4 == 0:
+            r2[int(rng.integers(100, 140))] ^= 1
+        reads += [r1, r2]
+        names.append("chance:%d" % i)
+    rs = synth.ReadSet()
+    lens = np.array([len(x) for x in reads], dtype=np.int64)
+    rs.seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rs.seq = np.concatenate(reads)
+    rs.bc_pair_off = np.array([0, n_pairs // 2, n_pairs], dtype=np.int32)
+    rs.names = names
+    rs.name_seed = synth._name_seeds(names)
+    return ["chrC"], [g], rs

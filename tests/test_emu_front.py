@@ -121,3 +121,18 @@ def test_emu_many_candidate_pairs_go_rng_ring(emu, oracle):
     assert (nf[0::2] * nf[1::2]).max() > 273
     res = idx.context(rs.n_pairs).align_barcodes(b)
     helpers.assert_same_result(res, ref, inference=True)
+
+
+def test_emu_chance_match_second_chains(emu, oracle):
+    """one-seed chains from chance matches (the hg38-scale case): extended with the full band over query sides of 64 columns and
+    more — k_extend_lane's live-interval window — with every region, CIGAR and pick equal to the oracle's"""
+    names, contigs, rs = helpers.chance_match_genome_and_reads()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    b = helpers.batch_of(rs)
+    od = oidx.stage_dump(b)
+    n_chains = np.diff(od.chain_off)
+    assert (n_chains >= 2).sum() >= rs.n_pairs   # the construction works: most reads 1 carry a second chain
+    ctx = idx.context(rs.n_pairs)
+    helpers.assert_same_dump(ctx.stage_dump(b), od, helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b), inference=True)
