@@ -172,6 +172,9 @@ typedef struct lh_result {
     const double* split_score;
     /* --- telemetry: device-side counters of the algorithmic work (roofline accounting) --- */
     uint64_t n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells;
+    /* bwt_extend calls K1 really executed on the occurrence table in passes 1, 2, 3 of mem_collect_intv (n_ext counts the reference's
+     * calls it performed OR accounted for: unique runs, the 12-mer jump; with the sweep filter on, intervals it left out are in neither) */
+    uint64_t n_ext_exec_p1, n_ext_exec_p2, n_ext_exec_p3;
     void* arena_; /* private */
 } lh_result;
 
@@ -260,6 +263,11 @@ int lh_align_barcodes(lh_context* ctx, const lh_opts* opts, const lh_batch* batc
 /* split form used by bench.py: inputs resident in HBM when the timed region starts */
 int lh_batch_upload(lh_context* ctx, const lh_batch* batch);
 int lh_align_resident(lh_context* ctx, const lh_opts* opts);            /* enqueue all kernels + sync */
+/* further input batches kept resident next to lh_batch_upload's (which is slot 0): a driver that streams many batches through
+ * one context uploads ahead (slot k+1 while slot k is aligned) and switches with lh_batch_select; bench.py has every batch of
+ * its timed region in HBM this way.  A slot's batch must fit the context's capacity like any other. */
+int lh_batch_upload_slot(lh_context* ctx, int32_t slot, const lh_batch* batch);
+int lh_batch_select(lh_context* ctx, int32_t slot);
 int lh_result_download(lh_context* ctx, lh_result** out);
 void lh_result_free(lh_result* r);
 
@@ -362,6 +370,11 @@ int lh_bam_open(const char* dir, int32_t n_contigs, const char* const* contig_na
 /* appends the records of one batch (lh_records_text order) to bc_sorted_bam.bam and to their position bucket */
 int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_ingest_batch* in);
 int lh_bam_close(lh_bam_writer* w); /* flushes, writes the BGZF end-of-file blocks, frees w */
+/* The host-side step of the multi-GPU path: every rank aligns a contiguous barcode range and writes its own file set
+ * (lh_bam_open with first_chunk only on rank 0); the job's files are the rank-ordered concatenation, file by file — for
+ * bc_sorted_bam.bam that is the single-process file (input order), for a position bucket the same multiset of records.
+ * BGZF blocks are copied as they are; later shards lose their header, every end-of-file block but the last is dropped. */
+int lh_bam_concat(int32_t n_shards, const char* const* shard_dirs, const char* out_dir);
 
 #ifdef __cplusplus
 }

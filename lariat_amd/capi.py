@@ -82,7 +82,7 @@ _RESULT_READ_FIELDS = [
     ("as_score", c_f64p, np.float64), ("split_idx", c_i64p, np.int64), ("split_mapq", c_i32p, np.int32),
     ("split_second_best", c_f64p, np.float64), ("split_score", c_f64p, np.float64),
 ]
-_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells"]
+_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3"]
 
 
 class LhResult(C.Structure):
@@ -292,6 +292,8 @@ def _declare(L):
     L.lh_align_barcodes.argtypes = [C.c_void_p, C.POINTER(LhOpts), C.POINTER(LhBatch), C.POINTER(C.POINTER(LhResult))]
     L.lh_batch_upload.argtypes = [C.c_void_p, C.POINTER(LhBatch)]
     L.lh_align_resident.argtypes = [C.c_void_p, C.POINTER(LhOpts)]
+    L.lh_batch_upload_slot.argtypes = [C.c_void_p, C.c_int32, C.POINTER(LhBatch)]
+    L.lh_batch_select.argtypes = [C.c_void_p, C.c_int32]
     L.lh_result_download.argtypes = [C.c_void_p, C.POINTER(C.POINTER(LhResult))]
     L.lh_result_free.argtypes = [C.POINTER(LhResult)]
     L.lh_last_timings.argtypes = [C.c_void_p, c_i32p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float))]
@@ -444,6 +446,12 @@ class Library:
         self.L.lh_records_free(txt)
         return out
 
+    def bam_concat(self, shard_dirs, out_dir):
+        n = len(shard_dirs)
+        dirs = (C.c_char_p * n)(*[d.encode() for d in shard_dirs])
+        self.L.lh_bam_concat.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.c_char_p]
+        self.check(self.L.lh_bam_concat(n, dirs, out_dir.encode()))
+
     def name_seed(self, name):
         if isinstance(name, str):
             name = name.encode()
@@ -547,6 +555,12 @@ class Context:
     def upload(self, batch):
         self._batch = batch
         self.lib.check(self.lib.L.lh_batch_upload(self.h, C.byref(batch.c)))
+
+    def upload_slot(self, slot, batch):
+        self.lib.check(self.lib.L.lh_batch_upload_slot(self.h, int(slot), C.byref(batch.c)))
+
+    def select(self, slot):
+        self.lib.check(self.lib.L.lh_batch_select(self.h, int(slot)))
 
     def align_resident(self, opts):
         self.lib.check(self.lib.L.lh_align_resident(self.h, C.byref(opts)))
@@ -717,5 +731,5 @@ EXPORTED_SYMBOLS = [
     "lh_records_text", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read", "lh_diag_go_rand",
-    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check",
+    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat",
 ]

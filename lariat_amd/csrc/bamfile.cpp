@@ -357,3 +357,146 @@ extern "C" int lh_bam_close(lh_bam_writer* w) {
     delete w;
     return ok ? LH_OK : lh_set_error_(LH_E_IO, "lh_bam_close: write failed");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// lh_bam_concat — the one host-side step of the multi-GPU path (BASELINE.json north_star: barcodes partition across the GPUs by
+// barcode range, "only a host-side concat of per-GPU BAM shards"; reference: one process writes the file set of
+// bamwriter.go:139-191).  Every rank writes its own file set with lh_bam_open/_append/_close; because the input is
+// barcode-sorted and the ranks own contiguous barcode ranges, concatenating bc_sorted_bam.bam in rank order IS the
+// single-process file, and a position bucket of the whole job is the concatenation of the ranks' buckets (records inside a
+// bucket are unordered until the downstream sort, as upstream).  BGZF makes this a block copy: shard 0 is copied whole,
+// later shards lose their header (the block the header ends in is re-compressed from the first record on), every
+// end-of-file block but the last is dropped.
+namespace {
+struct BgzfBlock { size_t off, size, isize; };
+
+bool bgzf_scan(const std::string& file, std::vector<BgzfBlock>& blocks) {
+    size_t p = 0;
+    while (p < file.size()) {
+        if (file.size() - p < 18) return false;
+        const uint8_t* h = (const uint8_t*)file.data() + p;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+        size_t xlen = h[10] | (size_t)h[11] << 8;
+        if (file.size() - p < 12 + xlen) return false;
+        size_t bsize = 0;
+        for (size_t q = 12; q + 4 <= 12 + xlen;) {
+            size_t slen = h[q + 2] | (size_t)h[q + 3] << 8;
+            if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) bsize = (h[q + 4] | (size_t)h[q + 5] << 8) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || file.size() - p < bsize) return false;
+        const uint8_t* t = h + bsize - 4;
+        blocks.push_back(BgzfBlock{p, bsize, (size_t)t[0] | (size_t)t[1] << 8 | (size_t)t[2] << 16 | (size_t)t[3] << 24});
+        p += bsize;
+    }
+    return true;
+}
+
+bool bgzf_inflate(const std::string& file, const BgzfBlock& b, std::string& out) {
+    const uint8_t* h = (const uint8_t*)file.data() + b.off;
+    size_t xlen = h[10] | (size_t)h[11] << 8;
+    out.resize(b.isize);
+    if (!b.isize) return true;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = (Bytef*)(h + 12 + xlen); zs.avail_in = (uInt)(b.size - 12 - xlen - 8);
+    zs.next_out = (Bytef*)&out[0]; zs.avail_out = (uInt)b.isize;
+    int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+bool slurp_file(const std::string& path, std::string& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t n;
+    out.clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    bool ok = !ferror(f);
+    fclose(f);
+    return ok;
+}
+
+// length of the BAM header (magic, text, reference table) at the start of an uncompressed stream; 0 if `s` does not hold all of it yet
+size_t bam_header_len(const std::string& s, uint32_t* n_ref_out) {
+    if (s.size() < 12 || memcmp(s.data(), "BAM\1", 4)) return 0;
+    auto u32 = [&](size_t o) { const uint8_t* q = (const uint8_t*)s.data() + o; return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; };
+    size_t p = 8 + u32(4);
+    if (s.size() < p + 4) return 0;
+    uint32_t n_ref = u32(p);
+    p += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (s.size() < p + 4) return 0;
+        p += 4 + u32(p) + 4;
+        if (s.size() < p) return 0;
+    }
+    if (n_ref_out) *n_ref_out = n_ref;
+    return p;
+}
+}   // namespace
+
+#include <dirent.h>
+
+extern "C" int lh_bam_concat(int32_t n_shards, const char* const* shard_dirs, const char* out_dir) {
+    if (n_shards <= 0 || !shard_dirs || !out_dir) return lh_set_error_(LH_E_ARG, "lh_bam_concat: bad argument");
+    std::vector<std::string> files;
+    {
+        DIR* d = opendir(shard_dirs[0]);
+        if (!d) return lh_set_error_(LH_E_IO, (std::string("lh_bam_concat: cannot list ") + shard_dirs[0]).c_str());
+        while (dirent* e = readdir(d)) {
+            std::string n = e->d_name;
+            if (n.size() > 4 && n.compare(n.size() - 4, 4, ".bam") == 0) files.push_back(n);
+        }
+        closedir(d);
+    }
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (const std::string& name : files) {
+        FILE* out = fopen((std::string(out_dir) + "/" + name).c_str(), "wb");
+        if (!out) return lh_set_error_(LH_E_IO, ("lh_bam_concat: cannot create " + std::string(out_dir) + "/" + name).c_str());
+        uint32_t n_ref0 = 0;
+        bool ok = true;
+        std::string err;
+        for (int s = 0; s < n_shards && ok; ++s) {
+            std::string file, path = std::string(shard_dirs[s]) + "/" + name;
+            std::vector<BgzfBlock> blocks;
+            if (!slurp_file(path, file) || !bgzf_scan(file, blocks)) { ok = false; err = "cannot read BGZF file " + path; break; }
+            while (!blocks.empty() && blocks.back().isize == 0) blocks.pop_back();   // end-of-file marker(s)
+            // the header: inflate blocks until it is complete
+            std::string head, blk;
+            size_t k = 0, hlen = 0;
+            uint32_t n_ref = 0;
+            while (k < blocks.size() && !(hlen = bam_header_len(head, &n_ref))) {
+                if (!bgzf_inflate(file, blocks[k], blk)) { ok = false; err = "corrupt BGZF block in " + path; break; }
+                head += blk;
+                ++k;
+            }
+            if (!ok) break;
+            if (!hlen && !(hlen = bam_header_len(head, &n_ref))) { ok = false; err = "no BAM header in " + path; break; }
+            if (s == 0) n_ref0 = n_ref;
+            else if (n_ref != n_ref0) { ok = false; err = "shards disagree on the reference table: " + path; break; }
+            if (s == 0) {   // whole, as written
+                size_t end = blocks.empty() ? 0 : blocks.back().off + blocks.back().size;
+                if (end && fwrite(file.data(), 1, end, out) != end) { ok = false; err = "write failed"; }
+            } else {
+                if (head.size() > hlen) {   // records that share the header's last block: their own block now
+                    Deflater d(Z_DEFAULT_COMPRESSION);
+                    for (size_t o = hlen; o < head.size() && ok; o += BGZF_DATA) {
+                        std::string z;
+                        size_t n = head.size() - o < BGZF_DATA ? head.size() - o : BGZF_DATA;
+                        if (!bgzf_block(d, head.data() + o, n, z) || fwrite(z.data(), 1, z.size(), out) != z.size()) { ok = false; err = "compression or write failed"; }
+                    }
+                }
+                if (ok && k < blocks.size()) {
+                    size_t b0 = blocks[k].off, b1 = blocks.back().off + blocks.back().size;
+                    if (fwrite(file.data() + b0, 1, b1 - b0, out) != b1 - b0) { ok = false; err = "write failed"; }
+                }
+            }
+        }
+        if (ok && fwrite(eof_block, 1, 28, out) != 28) { ok = false; err = "write failed"; }
+        if (fclose(out)) { ok = false; err = "write failed"; }
+        if (!ok) return lh_set_error_(LH_E_IO, ("lh_bam_concat: " + err).c_str());
+    }
+    return LH_OK;
+}

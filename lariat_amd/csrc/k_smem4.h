@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     const bool filt = DO12 && ix.bloom1 != nullptr && o.min_seed_len >= LH_BLOOM_K;
     u64 wkey = 0, bword = 0, bmask = 0;
     int filt_from = 0;
-    unsigned n_ext_total = 0;
+    unsigned n_ext_total = 0, n_exec_total = 0;   // bwt_extend calls of the reference accounted for / really executed on the occurrence table
 #define QB(i_) ((int)((qn[((i_) >> 3) * 64 + lane] >> (((i_) & 7) * 4)) & 0xF))
     // eight read bases from index s_ on (s_ may be negative or run past the read: those read as 4 = never equal to a text base)
 #define Q8(s_, out_)                                                                                         \
@@ -404,6 +404,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             a.x0 = c0; a.x1 = c1; a.x2 = c2; a.info = 0;
             ok = dev_extend_c(ix, a, ec, st == S4_REQ_BWD);
             n_ext_total++;
+            n_exec_total++;
         }
         // ---- E. bookkeeping of the loop the lane is in, and its next request ----
         if (DO12 && st == S4_REQ_FWD) {
@@ -487,5 +488,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     if (ctr) {
         unsigned tot = (unsigned)wave_sum_i32((int)n_ext_total);
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->n_ext, (u64)tot);
+        unsigned ex = (unsigned)wave_sum_i32((int)n_exec_total);
+        if (lane == 0 && ex) atomicAdd(&LH_CTR(ctr)->n_ext_exec[MODE == 3 || MODE == 1 || MODE == 0 ? 0 : MODE == 4 ? 1 : 2], (u64)ex);
     }
 }

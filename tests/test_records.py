@@ -145,3 +145,45 @@ def test_bam_short_contig_packing(hostlib, tmp_path):
     w.close()
     assert sorted(os.listdir(d)) == ["000000-a_0000000000_pos_bucketed.bam", "000002-c_0000000000_pos_bucketed.bam", "000003-d_0000000000_pos_bucketed.bam",
                                      "000003-d_0000000100_pos_bucketed.bam", "000003-d_0000000200_pos_bucketed.bam", "ZZZ_unmapped_pos_bucketed.bam", "bc_sorted_bam.bam"]
+
+
+def test_bam_shard_concat_equals_single_process(hostlib, oracle, tmp_path):
+    """the multi-GPU output path: two ranks align contiguous barcode ranges and write their own file sets; lh_bam_concat of the
+    shards in rank order gives bc_sorted_bam.bam record-for-record as one process writes it, and every position bucket holds
+    the same records (bamwriter.go:139-191 file set)"""
+    import bam_reader
+    from lariat_amd import shard
+    names, contigs = helpers.small_genome()
+    lens = [len(c) for c in contigs]
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = synth.make_reads(contigs, names, n_barcodes=6, pairs_per_barcode=40, seed=71, sub_hi=0.02, junk_frac=0.05)
+    path = write_fastq(tmp_path, rs)
+    batches = list(hostlib.ingest(path, trim=7, max_pairs=40))   # one barcode per batch
+    assert len(batches) == 6
+    results = [oidx.align_barcodes(b, threads=4) for b in batches]
+
+    def write(dirname, which, first):
+        d = tmp_path / dirname
+        d.mkdir()
+        w = hostlib.bam_writer(str(d), names, lens, read_groups="s:lib:1:fc:1", position_chunk_size=150000, first_chunk=first, command_line="x", threads=2)
+        for k in which:
+            w.append(results[k], batches[k])
+        w.close()
+        return str(d)
+
+    single = write("single", range(6), True)
+    sizes = np.concatenate([[0], np.cumsum([b.n_pairs for b in batches])])
+    ranges = shard.barcode_ranges(sizes, 2)
+    shards = [write("rank%d" % r, range(b0, b1), r == 0) for r, (b0, b1) in enumerate(ranges)]
+    out = tmp_path / "joined"
+    out.mkdir()
+    hostlib.bam_concat(shards, str(out))
+    assert sorted(os.listdir(out)) == sorted(os.listdir(single))
+    for f in sorted(os.listdir(single)):
+        t1, r1, l1 = bam_reader.read_bam(os.path.join(single, f))
+        t2, r2, l2 = bam_reader.read_bam(str(out / f))
+        assert t1 == t2 and r1 == r2
+        if f == "bc_sorted_bam.bam":
+            assert l1 == l2 and len(l1) > 400
+        else:
+            assert sorted(l1) == sorted(l2)
