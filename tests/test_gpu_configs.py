@@ -1,0 +1,146 @@
+"""BASELINE.json's configs on the GPU, against the oracle:
+
+  configs[0]  4.6 Mb "E. coli-like" genome, 10 k pairs / 100 barcodes written as 9-line FASTQ, through lh_ingest_* -> lh_align_barcodes
+  configs[1]  64 Mb "chr20-like" genome, 1 M pairs / 10 k barcodes: every field of every candidate
+  work units of the reference's own size: barcodes of 5,000 and 30,000 pairs (fastqreader/reader.go:205 caps a set at 30,000)
+  configs[2]  hg38-scale genome (3.1 Gb, index built in HBM): index self-check, oracle parity on a sample of barcodes, and
+              size-independent properties on a whole 1 M-pair batch (idempotence; barcode-range split == whole batch)
+
+Integer / index fields bit-exact, MAPQ within +-1, float scores within 1e-9 relative (helpers.assert_same_result).
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import helpers
+from lariat_amd import capi, synth, workload
+
+pytestmark = pytest.mark.gpu
+THREADS = min(os.cpu_count() or 8, 128)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = capi.load_library()
+    assert L.device_count() >= 1
+    return L
+
+
+def synthetic(lib, oracle, total_bases, **index_opts):
+    ctg = workload.hg38_like_contigs(total_bases)
+    l_pac = sum(c[1] for c in ctg)
+    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED)
+    idx = lib.index_build_device(pac, l_pac, ctg, **index_opts)
+    return ctg, l_pac, pac, idx
+
+
+def unpack(pac, ctg):
+    out = []
+    for _, ln, off in ctg:
+        i = np.arange(off, off + ln)
+        out.append(((pac[i >> 2] >> ((~i & 3) << 1)) & 3).astype(np.uint8))
+    return out
+
+
+def test_config0_ecoli_scale_fastq_to_alignments(lib, oracle, tmp_path):
+    """configs[0]: the plumbing case — 9-line barcode-sorted FASTQ in, every alignment field out, equal to the oracle's"""
+    ctg = [("ecoli_like", 4600000, 0)]
+    l_pac = 4600000
+    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED)
+    idx = lib.index_build_device(pac, l_pac, ctg)
+    oidx = oracle.index_from_arrays(idx.export(), pac)
+    contigs = unpack(pac, ctg)
+    rs = synth.make_reads(contigs, ["ecoli_like"], n_barcodes=100, pairs_per_barcode=100, seed=workload.READS_SEED)
+    path = str(tmp_path / "reads.fastq")
+    open(path, "w").write(synth.to_fastq9(rs, trim_prefix=7))
+    n_pairs = n_sets = 0
+    for b in lib.ingest(path, trim=7, max_pairs=2500):
+        res = idx.context(b.n_pairs).align_barcodes(b)
+        helpers.assert_same_result(res, oidx.align_barcodes(b, threads=THREADS), inference=True)
+        n_pairs += b.n_pairs
+        n_sets += b.n_sets
+    assert n_pairs == 10000 and n_sets == 100
+
+
+def test_config1_chr20_scale_every_field(lib, oracle):
+    """configs[1]: 64 Mb, 1 M pairs in 10 k barcodes — the whole batch against the oracle"""
+    ctg = [("chr20", 64000000, 0)]
+    l_pac = 64000000
+    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED)
+    idx = lib.index_build_device(pac, l_pac, ctg)
+    oidx = oracle.index_from_arrays(idx.export(), pac)
+    r = lib.synth_reads(pac, l_pac, ctg, seed=workload.READS_SEED + 1, n_barcodes=10000, pairs_per_barcode=100, junk_frac=0.002)
+    b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
+    res = idx.context(r["n_pairs"]).align_barcodes(b)
+    ref = oidx.align_barcodes(b, threads=THREADS)
+    assert ref.n_cand > 2 * r["n_pairs"]
+    helpers.assert_same_result(res, ref, inference=True)
+
+
+def test_reference_sized_work_units(lib, oracle):
+    """barcodes of 5,000 and 30,000 pairs (the reader's cap, reader.go:205) between ordinary ones: K8 runs them through its
+    large-slab second pass; every field equals the oracle's"""
+    ctg = [("c0", 1200000, 0), ("c1", 800000, 1200000)]
+    l_pac = 2000000
+    pac = lib.synth_genome(l_pac, seed=77)
+    idx = lib.index_build_device(pac, l_pac, ctg)
+    oidx = oracle.index_from_arrays(idx.export(), pac)
+    sizes = [100, 5000, 60, 30000, 7]
+    parts = [lib.synth_reads(pac, l_pac, ctg, seed=50 + k, n_barcodes=1, pairs_per_barcode=n, mol_min=8, mol_max=10, junk_frac=0.01) for k, n in enumerate(sizes)]
+    seq = np.concatenate([p["seq"] for p in parts])
+    offs, base = [np.zeros(1, dtype=np.int64)], 0
+    for p in parts:
+        offs.append(p["seq_off"][1:] + base)
+        base += int(p["seq_off"][-1])
+    seq_off = np.concatenate(offs)
+    bco = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    seeds = np.concatenate([p["name_seed"] for p in parts])
+    b = capi.Batch.from_arrays(seq, seq_off, bco, seeds)
+    ctx = idx.context(int(bco[-1]))
+    t0 = time.time()
+    res = ctx.align_barcodes(b)
+    dt = time.time() - t0
+    ref = oidx.align_barcodes(b, threads=THREADS)
+    helpers.assert_same_result(res, ref, inference=True)
+    print("reference-sized work units: %d pairs aligned in %.2f s (k_rfa %.1f ms)" % (int(bco[-1]), dt, dict(ctx.timings()).get("k_rfa", -1)))
+    assert dt < 20.0
+
+
+def test_config2_hg38_scale(lib, oracle):
+    """configs[2]'s reference: 3.1 Gb in 24 contigs — 6.2 G suffixes, past 2^31 symbols (occurrence super-blocks), dense SA + ISA"""
+    ctg, l_pac, pac, idx = synthetic(lib, oracle, 3100000000)
+    assert 2 * l_pac > 1 << 32 and idx.sa_interval == 1
+    rows, bad_order, bad_lf = idx.check(stride=997)
+    assert rows > 6000000 and bad_order == 0 and bad_lf == 0
+    r = lib.synth_reads(pac, l_pac, ctg, seed=workload.READS_SEED + 2, n_barcodes=10000, pairs_per_barcode=100)
+    b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
+    ctx = idx.context(r["n_pairs"])
+    res = ctx.align_barcodes(b)
+    # (1) a sample of barcodes against the oracle, on the SAME index (exported to the layout of bwa's files)
+    oidx = oracle.index_from_arrays(idx.export(), pac)
+    nb = 400
+    p1 = int(r["bc_pair_off"][nb])
+    sub = capi.Batch.from_arrays(r["seq"][: r["seq_off"][2 * p1]], r["seq_off"][: 2 * p1 + 1], r["bc_pair_off"][: nb + 1], r["name_seed"][:p1])
+    ref = oidx.align_barcodes(sub, threads=THREADS)
+    got = idx.context(p1).align_barcodes(sub)
+    helpers.assert_same_result(got, ref, inference=True)
+    # (2) size-independent properties on the whole batch
+    assert (res.active_idx >= 0).all() and (np.add.reduceat(res.active.astype(np.int64), res.cand_off[:-1]) == 1).all()   # one active candidate per read
+    act = res.active_idx[0::2]
+    placed = (res.rid[act] == r["truth_rid"]) & (np.abs(res.pos[act] - r["truth_pos1"]) < 20)
+    assert placed.mean() > 0.995
+    again = ctx.align_barcodes(b)                                                                                          # idempotence
+    helpers.assert_same_result(again, res, inference=True, mapq_tol=0, rel=0)
+    half = 5000                                                                                                            # barcodes are independent:
+    ph = int(r["bc_pair_off"][half])                                                                                       # a barcode-range shard == that range of the whole
+    lo = capi.Batch.from_arrays(r["seq"][: r["seq_off"][2 * ph]], r["seq_off"][: 2 * ph + 1], r["bc_pair_off"][: half + 1], r["name_seed"][:ph])
+    rl = ctx.align_barcodes(lo)
+    nc = int(res.cand_off[2 * ph])
+    assert rl.n_cand == nc
+    for f in helpers.INT_FIELDS + ["active", "is_proper", "duplicate", "molecule_id", "mapq"]:
+        a, w = getattr(rl, f), getattr(res, f)
+        n = {"cand_off": 2 * ph + 1, "cigar_off": nc + 1, "mm_off": nc + 1, "cigar": int(res.cigar_off[nc]), "mm_ref_loc": int(res.mm_off[nc]),
+             "mm_read_loc": int(res.mm_off[nc])}.get(f, nc)
+        assert np.array_equal(a[:n], w[:n]), f
