@@ -164,7 +164,7 @@ struct Record {   // views into the read buffer (valid until the next refill) or
 
 struct lh_ingest {
     FILE* f = nullptr;
-    bool piped = false;
+    bool piped = false, pipe_failed = false;
     int trim = 0, cap = 30000, chunk = 200;
     std::vector<char> buf;
     size_t pos = 0, lim = 0;
@@ -201,7 +201,15 @@ struct lh_ingest {
             pos -= mark; lim = keep; mark = 0; moved = true;
             size_t n = fread(buf.data() + lim, 1, buf.size() - lim, f);
             lim += n;
-            if (n == 0) { eof = true; if (ferror(f)) return -1; }
+            if (n == 0) {
+                eof = true;
+                if (ferror(f)) return -1;
+                if (piped) {   // a corrupt or truncated .gz makes gunzip exit non-zero: not a clean end of input
+                    int st = pclose(f);
+                    f = nullptr;
+                    if (st != 0) { pipe_failed = true; return -1; }
+                }
+            }
         }
     }
 };
@@ -253,8 +261,10 @@ int read_one(lh_ingest* in, Record& r) {
         r.rgid = nf < 2 ? View() : last;
         const View* g = got + 1;
         size_t to_trim = g[0].n < (size_t)in->trim ? g[0].n : (size_t)in->trim;
-        // the quality line is sliced with the same count; a shorter quality line makes the reference panic: clamp instead
-        size_t tq = g[1].n < to_trim ? g[1].n : to_trim;
+        // the quality line is sliced with the same count (reader.go:135-139); a shorter quality line makes the reference panic
+        // (slice bounds): a read error here, so that trim_bases and trim_quals always share their offsets
+        if (g[1].n < to_trim) return 2;
+        size_t tq = to_trim;
         r.r1 = View{g[0].p + to_trim, g[0].n - to_trim};
         r.q1 = View{g[1].p + tq, g[1].n - tq};
         r.tb = View{g[0].p, to_trim};
@@ -403,6 +413,7 @@ extern "C" int lh_ingest_next(lh_ingest* in, int64_t max_pairs, lh_ingest_batch*
         int rc = read_set(in, *T);
         if (rc) {
             if (T != A) arena_put(T);
+            if (in->pipe_failed) { arena_put(A); return lh_set_error_(LH_E_IO, "gunzip failed: the compressed FASTQ is corrupt or truncated"); }
             if (rc == 2 && A->do_rfa.empty()) { arena_put(A); return lh_set_error_(LH_E_IO, "read error in the FASTQ stream"); }
             at_eof = true;
             break;

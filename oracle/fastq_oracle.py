@@ -61,7 +61,9 @@ class Reader:
             if err:
                 return err
         t = min(len(got[0]), self.trim)
-        tq = min(len(got[1]), t)
+        if len(got[1]) < t:
+            return "panic"   # reader.go:135-139 slices the quality line with the same count: slice bounds out of range
+        tq = t
         rec.r1, rec.q1, rec.tb, rec.tq = got[0][t:], got[1][tq:], got[0][:t], got[1][:tq]
         rec.r2, rec.q2 = got[2], got[3]
         parts = got[4].split(b",")

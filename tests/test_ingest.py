@@ -134,3 +134,80 @@ def test_default_constants_at_scale(hostlib, tmp_path):
     assert sizes[0] == 30000 and not want[0][1]   # cut at the cap, flagged incomplete, no RFA
     assert sizes[1] == 201 and not want[1][1]     # "abnormal break" of the continuation
     assert 200 in sizes
+
+
+# ---- the reference's own ingest goldens: go/src/test/fastq_reader_test.go on inputs/1.fq (a gz file despite its name) ----
+FQ1 = os.path.join(helpers.ROOT, "tests", "golden", "1.fq")
+# fastq_reader_test.go:19-27 — the third record, read with trim 2
+REC3 = dict(
+    r1="CCGCCCTAGCCAGGAGAGAAGCACTTCTTACCTGGGTTTCTTAGAGGCTTTGGCTGGCAATATTGTCAGCACCAGAGAGGACTTCTCGATGGCTGA",
+    q1="BFFFFFFFFFFIIIIIFFIIIIIIIIFIIIIIFIFIFFIIFIIIIIIIIIIIIIIIFFFFFFFFFFFFFFFFFFFBFFFFFFFFFFFFFFFFFFFF",
+    r2="GTGGTAGTCTCCTGTTCAGCCATCGAGAAGTCCTCTCTGGTGCTGACAATATTGCCAGCCAAAGCCTCTAAGAAACCCAGGTAAGAAGTGCTTCTCTC",
+    q2="BBBFFFFFFFFFFIIFIIFIIIIIIIIIIIIIIIIFIIIFFFIIIIIIIIIIIIIIIIIIIIFIIIIIIIIIIFFFFFFFFBBFFFFFBBFFFFFFFF",
+    bc="AAACAGAGAAAGAT", bcq="BBBFFFFFFFFFFI", si="CCGAACGC", siq="BBBFFFFF", name="HWI-D00684:80:HFCKCADXX:2:2113:9410:56703")
+# fastq_reader_test.go:34-40 — ReadBarcodeSet twice
+SET1_FIRST_NAME = "HWI-D00684:80:HFCKCADXX:2:2113:17628:14813"
+SET1_SECOND_R1 = "CTGCTGCTCTCTCCATGTTTTTCCTGCACTCCTTGCAGGGACCTGAATAGCATGAACTGACTTTTCCTTGACGTAGTTGCTTCGTAGGATACTTCT"
+SET2_FIRST_NAME = "HWI-D00684:80:HFCKCADXX:2:2112:14227:100270"
+SET2_SECOND_R1 = "CGGGCAGCAGCCATGGGATGCAGGACCTGCAGTCCACACATGTCACATGAATCTCCATGGAGAGGCACACAGTTCTCCCCATCTCAGCACTCTCTC"
+
+
+def _acgt(a):
+    return "".join("ACGTN"[v] for v in a)
+
+
+def test_reference_goldens_oracle():
+    """oracle/fastq_oracle.py against the strings the reference's own tests assert"""
+    sets = fastq_oracle.read_all(FQ1, 2, 30000, 200)
+    recs = [r for s in sets for r in s[0]]
+    r = recs[2]
+    assert (r.r1.decode(), r.q1.decode(), r.r2.decode(), r.q2.decode()) == (REC3["r1"], REC3["q1"], REC3["r2"], REC3["q2"])
+    assert (r.bc.decode(), r.bcq.decode(), r.si.decode(), r.siq.decode(), r.name.decode()) == (REC3["bc"], REC3["bcq"], REC3["si"], REC3["siq"], REC3["name"])
+    assert sets[0][0][0].name.decode() == SET1_FIRST_NAME and sets[0][0][1].r1.decode() == SET1_SECOND_R1
+    assert sets[1][0][0].name.decode() == SET2_FIRST_NAME and sets[1][0][1].r1.decode() == SET2_SECOND_R1
+    # structure of the fixture (SURVEY.md section 4): 666 complete records + a truncated tail, 89 barcode sets, none of them whitelisted
+    assert len(recs) == 666 and len(sets) == 89
+    assert [len(s[0]) for s in sets[:6]] == [9, 11, 4, 16, 9, 8] and max(len(s[0]) for s in sets) == 25
+    assert not any(s[2] for s in sets)   # barcodes without '-': worthRunningRFA is false for every set
+
+
+def test_reference_goldens_product(hostlib):
+    """lh_ingest_* (the product's reader) against the same strings, then against the oracle record by record"""
+    rd = hostlib.ingest(FQ1, trim=2, max_pairs=1 << 20)
+    batches = list(rd)
+    assert len(batches) == 1
+    b = batches[0]
+    assert b.n_pairs == 666 and b.n_sets == 89
+    cols = {c: b.column(c) for c in ("name", "qual1", "qual2", "bc", "bcqual", "si", "siqual", "trim_bases", "trim_quals")}
+    assert _acgt(b.read(4)) == REC3["r1"] and _acgt(b.read(5)) == REC3["r2"]
+    assert cols["qual1"][2].decode() == REC3["q1"] and cols["qual2"][2].decode() == REC3["q2"]
+    assert (cols["bc"][2].decode(), cols["bcqual"][2].decode(), cols["si"][2].decode(), cols["siqual"][2].decode(), cols["name"][2].decode()) == \
+        (REC3["bc"], REC3["bcq"], REC3["si"], REC3["siq"], REC3["name"])
+    assert len(cols["trim_bases"][2]) == 2 and len(cols["trim_quals"][2]) == 2
+    assert cols["name"][0].decode() == SET1_FIRST_NAME and _acgt(b.read(2)) == SET1_SECOND_R1
+    p2 = int(b.bc_pair_off[1])
+    assert p2 == 9 and cols["name"][p2].decode() == SET2_FIRST_NAME and _acgt(b.read(2 * (p2 + 1))) == SET2_SECOND_R1
+    assert not b.bc_do_rfa.any()
+    check_against_oracle(hostlib, FQ1, 2)
+    check_against_oracle(hostlib, FQ1, 7, max_pairs=40)
+
+
+def test_truncated_gz_is_an_error_not_a_short_run(hostlib, tmp_path):
+    """gunzip exits non-zero on a truncated member: the reader must not report a clean end of input (a silently short BAM)"""
+    raw = open(FQ1, "rb").read()
+    p = tmp_path / "cut.fastq.gz"
+    p.write_bytes(raw[: len(raw) * 2 // 3])
+    with pytest.raises(capi.LhError) as e:
+        for _ in hostlib.ingest(str(p), trim=2, max_pairs=50):
+            pass
+    assert e.value.code == capi.LH_E_IO
+
+
+def test_quality_line_shorter_than_trim_is_a_read_error(hostlib, tmp_path):
+    """reader.go:135-139 slices read 1's quality with the trim count and panics when it is shorter; here: a read error, on both sides"""
+    rec = ["@n1 1:N:0:", "ACGTACGTACGT", "III", "ACGTACGTAC", "IIIIIIIIII", "AAACAGAGAAAGAT-1", "IIIIIIIIIIIIIIII", "ACGTACGT", "IIIIIIII"]
+    p = tmp_path / "bad.fastq"
+    p.write_text("\n".join(rec) + "\n")
+    assert fastq_oracle.read_all(str(p), 7, 30000, 200) == []
+    with pytest.raises(capi.LhError):
+        list(hostlib.ingest(str(p), trim=7))

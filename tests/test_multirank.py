@@ -1,7 +1,10 @@
-"""N>1 control path on CPU: two gloo ranks shard a barcode-sorted batch by barcode range, align their shards
-independently (with the oracle standing in for the device, which this container lacks), and the concatenation in range
-order equals the single-process result.  No data-path collective is used — only gather-for-checking and a MAX reduce."""
+"""The N>1 path: two torch.distributed ranks (gloo here; bench.py uses RCCL on a multi-GPU node) take contiguous barcode ranges
+of ONE barcode-sorted input (lariat_amd.shard), align them through the PRODUCT's C-ABI — liblariat_hip.so on a device when one
+is present (two ranks may share it), otherwise the same host pipeline and kernel sources built against the CPU emulator —
+exchange nothing on the data path, and the rank-ordered concatenation of what they return equals the single-process result
+(checked against the oracle on rank 0).  Only the check itself gathers; the product path uses a barrier and a MAX reduce."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -12,47 +15,76 @@ import torch.multiprocessing as mp
 
 import helpers
 
+EMU = os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu.so")
+FIELDS = ["rid", "pos", "aend", "reversed", "score", "nm", "active", "is_proper", "mapq", "molecule_id", "duplicate"]
 
-def _worker(rank, world, port, out):
+
+def _library(prefer_gpu):
+    from lariat_amd import capi
+    if prefer_gpu:
+        lib = capi.load_library()
+        if lib.device_count() >= 1:
+            return lib, "hip"
+    return capi.Library(EMU), "emu"
+
+
+def _worker(rank, world, port, out, prefer_gpu):
     sys.path.insert(0, helpers.ROOT)
     sys.path.insert(0, os.path.join(helpers.ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import oracle_py
-    from lariat_amd import capi, shard
-    o = oracle_py.load()
-    names, contigs = helpers.small_genome()
-    idx = o.index_build_naive(names, contigs)
-    rs = helpers.small_reads(names, contigs, n_barcodes=7, pairs=20, seed=3)
-    b0, b1 = shard.barcode_ranges(rs.bc_pair_off, world)[rank]
-    sub = rs.slice_barcodes(b0, b1)
-    res = idx.align_barcodes(helpers.batch_of(sub))
-    act = res.active_idx
-    mine = dict(range=(b0, b1), pos=res.pos[act].tolist(), mapq=res.mapq[act].tolist(), rid=res.rid[act].tolist())
+    from lariat_amd import shard
+    lib, kind = _library(prefer_gpu)
+    # every rank builds the same index in its own memory (replicated, as on a node) and sees the same sorted input
+    l_pac = 600000
+    ctg = [("cA", 360000, 0), ("cB", 240000, 360000)]
+    pac = lib.synth_genome(l_pac, seed=11, threads=2)
+    idx = lib.index_build_device(pac, l_pac, ctg)
+    r = lib.synth_reads(pac, l_pac, ctg, seed=3, n_barcodes=9, pairs_per_barcode=24, junk_frac=0.03, threads=2)
+    (b0, b1), results = shard.align_rank_shard(lib, idx, r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"], rank, world, max_pairs_per_batch=60)
+    mine = {"range": (b0, b1), "n_batches": len(results), "kind": kind}
+    for f in FIELDS:
+        mine[f] = np.concatenate([getattr(x, f) for x in results]).tolist() if results else []
     gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
+    dist.all_gather_object(gathered, mine)   # for the check only
     tmax = shard.reduce_max(dist, 1.0 + rank)
     if rank == 0:
-        full = idx.align_barcodes(helpers.batch_of(rs))
-        fa = full.active_idx
-        cat = {k: sum((g[k] for g in gathered), []) for k in ("pos", "mapq", "rid")}
-        ok = (cat["pos"] == full.pos[fa].tolist() and cat["mapq"] == full.mapq[fa].tolist() and cat["rid"] == full.rid[fa].tolist())
-        ranges = [g["range"] for g in gathered]
-        with open(out, "w") as f:
-            f.write("%d %s %s\n" % (int(ok), tmax, ranges))
+        import oracle_py
+        from lariat_amd import capi
+        o = oracle_py.load()
+        oidx = o.index_from_arrays(idx.export(), pac)
+        full = oidx.align_barcodes(capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]), threads=4)
+        ok = all(sum((g[f] for g in gathered), []) == getattr(full, f).tolist() for f in FIELDS if f != "mapq")
+        dm = np.abs(np.array(sum((g["mapq"] for g in gathered), [])) - full.mapq)
+        ok = ok and bool((dm <= 1).all())
+        with open(out, "w") as fh:
+            fh.write("%d|%s|%s|%s|%s\n" % (int(ok), tmax, [g["range"] for g in gathered], [g["n_batches"] for g in gathered], gathered[0]["kind"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_barcode_sharding(tmp_path):
+def _run(tmp_path, prefer_gpu):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "hipemu")])
     out = str(tmp_path / "r.txt")
     port = 29500 + (os.getpid() % 1000)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    ok, tmax, ranges = open(out).read().split(" ", 2)
+    mp.spawn(_worker, args=(2, port, out, prefer_gpu), nprocs=2, join=True)
+    ok, tmax, ranges, nb, kind = open(out).read().strip().split("|")
     assert ok == "1"
     assert float(tmax) == 2.0
-    assert "(0, " in ranges
+    assert ranges.startswith("[(0, ") and ranges.endswith(", 9)]")
+    assert all(int(x) >= 2 for x in nb.strip("[]").split(","))   # each rank streamed its range as several batches
+    return kind
+
+
+def test_two_rank_barcode_sharding_through_the_product(tmp_path):
+    assert _run(tmp_path, prefer_gpu=False) == "emu"
+
+
+@pytest.mark.gpu
+def test_two_rank_barcode_sharding_on_the_device(tmp_path):
+    """the same, the two ranks sharing the one GPU of the test box"""
+    assert _run(tmp_path, prefer_gpu=True) == "hip"
 
 
 def test_barcode_ranges_balanced():
