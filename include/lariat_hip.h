@@ -88,7 +88,7 @@ typedef struct lh_index_opts {
     int32_t no_unique_runs;   /* leave out the inverse suffix array and the 4-bit text (and with them the sweep filters) */
     int32_t no_sweep_filter;  /* leave out the Bloom filters of K1's sweep filter */
     int32_t build_chunk_log2; /* lh_index_build_device: at most 2^this suffixes per sort chunk; 0 = 29 */
-    int32_t reserved;
+    int32_t ktree_levels;     /* K1's table of the bi-intervals of all strings of up to this many bases (<= 14; needs the dense SA); 0 = by the text's size, -1 = none */
 } lh_index_opts;
 void lh_index_opts_init(lh_index_opts* io);
 
@@ -175,6 +175,8 @@ typedef struct lh_result {
     /* bwt_extend calls K1 really executed on the occurrence table in passes 1, 2, 3 of mem_collect_intv (n_ext counts the reference's
      * calls it performed OR accounted for: unique runs, the 12-mer jump; with the sweep filter on, intervals it left out are in neither) */
     uint64_t n_ext_exec_p1, n_ext_exec_p2, n_ext_exec_p3;
+    /* bwt_extend results K1 read from its k-mer tree table instead (one 16-B entry each), per pass */
+    uint64_t n_ktree_p1, n_ktree_p2, n_ktree_p3;
     void* arena_; /* private */
 } lh_result;
 

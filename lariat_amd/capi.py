@@ -48,7 +48,7 @@ class LhOpts(C.Structure):
 
 class LhIndexOpts(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("sa_intv", C.c_int32), ("sb_shift", C.c_int32), ("no_kmer_table", C.c_int32), ("no_unique_runs", C.c_int32),
-                ("no_sweep_filter", C.c_int32), ("build_chunk_log2", C.c_int32), ("reserved", C.c_int32)]
+                ("no_sweep_filter", C.c_int32), ("build_chunk_log2", C.c_int32), ("ktree_levels", C.c_int32)]
 
 
 class LhContextOpts(C.Structure):
@@ -82,7 +82,7 @@ _RESULT_READ_FIELDS = [
     ("as_score", c_f64p, np.float64), ("split_idx", c_i64p, np.int64), ("split_mapq", c_i32p, np.int32),
     ("split_second_best", c_f64p, np.float64), ("split_score", c_f64p, np.float64),
 ]
-_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3"]
+_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3", "n_ktree_p1", "n_ktree_p2", "n_ktree_p3"]
 
 
 class LhResult(C.Structure):

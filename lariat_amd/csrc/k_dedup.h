@@ -108,15 +108,61 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
 }
 
 // K5, lane per read: a read with at most one region has nothing to sort, exclude or patch (mem_sort_dedup_patch returns at
-// once): only its best score is recorded; the others (3 % on the bench data) are listed for the wave kernel.
-__global__ void __launch_bounds__(256) k_dedup_fast(int n_reads, const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs,
+// once): only its best score is recorded.  A read with TWO regions — at human-genome scale every third read: its alignment
+// and the extension of a chance-match chain somewhere else — is finished here too, mem_sort_dedup_patch unrolled for n = 2,
+// unless the two regions get as far as mem_patch_reg's re-alignment (a DP: the wave kernel's).  The rest is listed.
+__device__ __forceinline__ int dev_patch_needs_dp(const DIndex& ix, const DOpts& o, const DReg& a, const DReg& b) {   // mem_patch_reg up to its DP
+    if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
+    if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+    int w = (int)((a.re - b.rb) - (a.qe - b.qb));
+    w = w > 0 ? w : -w;
+    double r = (double)(a.re - b.rb) / (double)(b.re - a.rb) - (double)(a.qe - b.qb) / (double)(b.qe - a.qb);
+    r = r > 0. ? r : -r;
+    if (a.re < b.rb || a.qe < b.qb) {
+        if (w > o.w << 1 || r >= LH_PATCH_MAX_R_BW) return 0;
+    } else if (w > o.w << 2 || r >= LH_PATCH_MAX_R_BW * 2) return 0;
+    return 1;
+}
+__global__ void __launch_bounds__(256) k_dedup_fast(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs,
                                                      int32_t* __restrict__ best_score, int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     int need = 0;
     if (r < n_reads) {
         int n = n_regs[r];
         if (n <= 1) best_score[r] = n == 1 ? regs[reg_off[r]].score : 0;
-        else need = 1;
+        else if (n == 2) {
+            DReg* av = regs + reg_off[r];
+            DReg x0 = av[0], x1 = av[1];
+            x0.n_comp = 1; x1.n_comp = 1;
+            // sorted by re (klib's introsort on two elements: swapped only when strictly out of order)
+            DReg qq = x1.re < x0.re ? x1 : x0, p = x1.re < x0.re ? x0 : x1;
+            if (p.rid == qq.rid && p.rb < qq.re + o.max_chain_gap) {
+                i64 orr = qq.re - p.rb;
+                i64 oq = qq.qb < p.qb ? qq.qe - p.qb : p.qe - qq.qb;
+                i64 mr = qq.re - qq.rb < p.re - p.rb ? qq.re - qq.rb : p.re - p.rb;
+                i64 mq = qq.qe - qq.qb < p.qe - p.qb ? qq.qe - qq.qb : p.qe - p.qb;
+                if ((float)orr > o.mask_level_redun * (float)mr && (float)oq > o.mask_level_redun * (float)mq) {
+                    if (p.score < qq.score) p.qe = p.qb;
+                    else qq.qe = qq.qb;
+                } else if (qq.rb < p.rb && dev_patch_needs_dp(ix, o, qq, p)) need = 1;
+            }
+            if (!need) {
+                // exclude, sort by (score desc, rb, qb), drop an identical hit
+                int kp = p.qe > p.qb, kq = qq.qe > qq.qb;
+                DReg a0, a1;
+                int m = 0;
+                if (kq && kp) {   // order after the first sort: qq, p
+                    bool p_first = p.score > qq.score || (p.score == qq.score && (p.rb < qq.rb || (p.rb == qq.rb && p.qb < qq.qb)));
+                    a0 = p_first ? p : qq; a1 = p_first ? qq : p;
+                    m = (a1.score == a0.score && a1.rb == a0.rb && a1.qb == a0.qb) ? 1 : 2;
+                } else if (kq) { a0 = qq; m = 1; }
+                else if (kp) { a0 = p; m = 1; }
+                if (m >= 1) av[0] = a0;
+                if (m == 2) av[1] = a1;
+                n_regs[r] = m;
+                best_score[r] = m == 0 ? 0 : (m == 2 && a1.score > a0.score ? a1.score : a0.score);
+            }
+        } else need = 1;
     }
     u64 m = __ballot(need);
     if (m) {

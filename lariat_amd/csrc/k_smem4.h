@@ -68,6 +68,8 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_BRUN_END2 23
 #define S4_P3_JUMP 24    // pass 3: the walk's first 12 bases come from the 12-mer table
 #define S4_P3_JUMP2 25
+#define S4_TRI_LCP 26    // the sweep of a forward list whose longest entry is unique, decided from the LCP array (see BWD_ROW_BODY)
+#define S4_TRI_LCP2 27
 #define LH_KMER 12
 
 #ifndef LH_SLOW_BATCH
@@ -108,7 +110,26 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     const bool filt = DO12 && ix.bloom1 != nullptr && o.min_seed_len >= LH_BLOOM_K;
     u64 wkey = 0, bword = 0, bmask = 0;
     int filt_from = 0;
-    unsigned n_ext_total = 0, n_exec_total = 0;   // bwt_extend calls of the reference accounted for / really executed on the occurrence table
+    unsigned n_ext_total = 0, n_exec_total = 0, n_ktree_total = 0;   // bwt_extend calls of the reference accounted for / really executed on the occurrence table / read from the k-mer tree
+    // k-mer tree table (DIndex::ktree): a bwt_extend whose result is a match of at most ktl bases is ONE 16-B table read (the result
+    // is a function of the matched string alone).  fcode = the bases of the current forward / pass-3 walk from x on (base t at
+    // bits 2t), kept while the walk is that short; rcode = the 16 read bases from the current backward row's position i on.
+    const PEnt* const kt = (const PEnt*)ix.ktree;
+    const int ktl = kt ? ix.ktree_levels : 0;
+    uint32_t fcode = 0, rcode = 0;
+    // LCP shortcut of the backward sweep (pass 1): emin = end of the first entry pushed to the forward list (the shortest string),
+    // tri = the unique run in progress stands for a list of several entries, tri_failed = it was tried for this SMEM and did not apply
+    int emin = 0, tri = 0, tri_failed = 0;
+    // sixteen read bases from s_ on, 2 bits each (base t at bits 2t; non-bases squeeze to arbitrary digits: callers mask)
+#define CODE16(s_, out_)                                                                                     \
+    {                                                                                                        \
+        uint32_t a_, b_;                                                                                     \
+        Q8(s_, a_) Q8((s_) + 8, b_)                                                                          \
+        a_ &= 0x33333333u; b_ &= 0x33333333u;                                                                \
+        a_ = (a_ | a_ >> 2) & 0x0f0f0f0fu; a_ = (a_ | a_ >> 4) & 0x00ff00ffu; a_ = (a_ | a_ >> 8) & 0xffffu; \
+        b_ = (b_ | b_ >> 2) & 0x0f0f0f0fu; b_ = (b_ | b_ >> 4) & 0x00ff00ffu; b_ = (b_ | b_ >> 8) & 0xffffu; \
+        out_ = a_ | b_ << 16;                                                                                \
+    }
 #define QB(i_) ((int)((qn[((i_) >> 3) * 64 + lane] >> (((i_) & 7) * 4)) & 0xF))
     // eight read bases from index s_ on (s_ may be negative or run past the read: those read as 4 = never equal to a text base)
 #define Q8(s_, out_)                                                                                         \
@@ -158,7 +179,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     {                                                                                                        \
         int s_ = QB(x);                                                                                      \
         c0 = ix.L2[s_] + 1; c2 = ix.L2[s_ + 1] - ix.L2[s_]; c1 = ix.L2[3 - s_] + 1; cinfo = x + 1;          \
-        ncurr = 0; i = x + 1; curA = 1;                                                                      \
+        ncurr = 0; i = x + 1; curA = 1; fcode = (uint32_t)s_; tri = 0; tri_failed = 0;                       \
         if (filt) {   /* the LH_BLOOM_K bases that end at x (positions before the read count as non-bases) */ \
             uint32_t w0_, w1_, w2_;                                                                          \
             Q8(x - 18, w0_) Q8(x - 10, w1_) Q8(x - 2, w2_)                                                   \
@@ -193,10 +214,19 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         ncurr = 0; last_size = 0; j = 0;                                                                     \
         c0 = PE_X0(ce); c1 = PE_X1(ce); c2 = PE_X2(ce); cinfo = PE_INFO(ce);                                 \
         if (c_ > 3) st = S4_BWD_EMIT0;   /* nothing extends: only the first (longest) entry can be a new MEM */ \
-        else if (runs && nprev == 1 && c2 == 1 && min_intv == 1) st = S4_BRUN_INIT;   /* one unique match left */ \
+        else if (runs && nprev == 1 && c2 == 1 && min_intv == 1) { tri = 0; st = S4_BRUN_INIT; }   /* one unique match left */ \
+        /* Several entries, the longest of them unique (the usual forward list: [x, e) for growing e until one occurrence is  \
+           left).  Rows down to u, the position where the unique match ends on the left, cannot emit anything: every entry     \
+           still matches at that occurrence.  If the SHORTEST entry's string [u, emin) is unique as well — both neighbours of   \
+           its suffix-array row share fewer than emin - u bases with it (LCP array) — every entry has shrunk to that one        \
+           occurrence by row u: equal sizes of nested occurrence sets are equal sets, bwt_smem1a keeps one interval per size,  \
+           so the list has collapsed into its longest entry, whose failure at u - 1 is the only thing the sweep reports.       \
+           That is the unique run below; otherwise the sweep is done row by row as written (tri_failed).  Like the sweep filter, this leaves bwt_extend calls of the reference out (no n_ext for them): off when the filter is off. */ \
+        else if (runs && filt && ix.lcp && rev && nprev > 1 && c2 == 1 && min_intv == 1 && !tri_failed) { tri = 1; st = S4_BRUN_INIT; } \
         else {                                                                                               \
             ec = c_; st = S4_REQ_BWD;                                                                        \
             if (nprev > 1) pn = PREV[(uint32_t)(rev ? nprev - 2 : 1) * T];                                   \
+            if (ktl) CODE16(i, rcode)                                                                        \
         }                                                                                                    \
     }
     // after prev entry j: the next entry of the row (prefetched), or the next row, or the end of this bwt_smem1a
@@ -296,20 +326,41 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 ncurr++;
                 st = S4_BWD_INIT;
             }
-            else if (DO3 && st == S4_P3_JUMP) { pn = ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
-            else if (DO3 && st == S4_P3_JUMP2) {   // as if the 11 bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
+            else if (DO3 && st == S4_P3_JUMP) { pn = kt ? kt[ld64] : ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
+            else if (DO3 && st == S4_P3_JUMP2) {   // as if the bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
+                const int jl = kt ? ktl : LH_KMER;
                 c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn);
-                n_ext_total += LH_KMER - 1;
-                i = x + LH_KMER;
+                n_ext_total += jl - 1;
+                i = x + jl;
                 P3_ADVANCE()
             }
             else if (DO1 && st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
             else if (DO1 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }
             else if (DO1 && st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
+            else if (DO1 && st == S4_TRI_LCP) {   // ld64 = the row of the suffix that starts where the unique match ends on the left
+                const uint8_t* lp = ix.lcp + ld64;
+                int l0 = lp[0], l1 = lp[1];
+                ec = l0 > l1 ? l0 : l1;   // (ec is free outside the extension states)
+                st = S4_TRI_LCP2;
+            }
+            else if (DO1 && st == S4_TRI_LCP2) {
+                if (ec < emin - (i + 1)) {   // the shortest entry is unique from u = i + 1 on: the list is its longest entry
+                    c0 = ld64;
+                    if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
+                    st = S4_SMEM_DONE;
+                } else {   // not provable: the sweep as written, from its first row
+                    tri_failed = 1; tri = 0;
+                    i = x - 1;
+                    BWD_ROW_BODY()
+                }
+            }
             else if (DO1) {   // S4_BRUN_END2: the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
-                c0 = ld64;
-                if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
-                st = S4_SMEM_DONE;
+                if (tri) st = S4_TRI_LCP;
+                else {
+                    c0 = ld64;
+                    if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
+                    st = S4_SMEM_DONE;
+                }
             }
         }
         while (slow_turn && __any(st >= 8 && st < S4_FRUN_INIT)) {
@@ -356,6 +407,21 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1;
                     i = x + 1;
                     int jumped = 0;
+                    fcode = (uint32_t)b;
+                    if (ktl > 1 && x + ktl <= len && o.min_seed_len >= ktl) {   // the walk's first ktl bases from the tree's deepest level
+                        uint32_t w0, w1;
+                        Q8(x, w0)
+                        Q8(x + 8, w1)
+                        if (ktl < 8) { w0 &= (1u << (4 * ktl)) - 1u; w1 = 0; }
+                        else if (ktl < 16) w1 &= (1u << (4 * (ktl - 8))) - 1u;
+                        if (!((w0 | w1) & 0x44444444u)) {
+                            CODE16(x, fcode)
+                            fcode &= (1u << (2 * ktl)) - 1u;
+                            ld64 = (((1ull << (2 * ktl)) - 4) / 3) + fcode;
+                            st = S4_P3_JUMP;
+                            jumped = 1;
+                        }
+                    } else
                     if (ix.kmer12 && x + LH_KMER <= len && o.min_seed_len >= LH_KMER) {
                         uint32_t w0, w1;
                         Q8(x, w0)
@@ -399,19 +465,38 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         { int k_ = st == S4_REQ_FWD ? (phase == 1 ? 16 : 18) : st == S4_REQ_BWD ? (phase == 1 ? 17 : 18) : st == S4_REQ_P3 ? 19 : -1;
           for (int kk_ = 16; kk_ < 20; ++kk_) { int n_ = (int)__popcll(__ballot(k_ == kk_)); if (lane == 0 && n_) atomicAdd(&lh_dbg[kk_ + 4], n_); } }
 #endif
+#ifdef LH_KTREE_STATS   // development aid: how many executed extensions produce a match of at most 14 bases (lh_dbg[8..13])
+        {
+            int any_ = st >= S4_REQ_FWD && st <= S4_REQ_P3;
+            int L_ = st == S4_REQ_BWD ? cinfo - i : i + 1 - x;
+            int b_ = MODE == 3 ? 8 : MODE == 4 ? 10 : 12;
+            int ns_ = (int)__popcll(__ballot(any_ && L_ <= 14)), na_ = (int)__popcll(__ballot(any_));
+            if (lane == 0) { atomicAdd(&lh_dbg[b_], ns_); atomicAdd(&lh_dbg[b_ + 1], na_); }
+        }
+#endif
         if (st >= S4_REQ_FWD && st <= S4_REQ_P3) {
-            DIntv a;
-            a.x0 = c0; a.x1 = c1; a.x2 = c2; a.info = 0;
-            ok = dev_extend_c(ix, a, ec, st == S4_REQ_BWD);
+            const int lnew = st == S4_REQ_BWD ? cinfo - i : i + 1 - x;   // bases of the match this bwt_extend yields: [i, cinfo) or [x, i]
+            if (lnew <= ktl) {
+                uint32_t code;
+                if (st == S4_REQ_BWD) code = rcode & ((1u << (2 * lnew)) - 1u);
+                else { fcode |= (uint32_t)(3 - ec) << (2 * (lnew - 1)); code = fcode; }   // forward steps complement the base (ec = 3 - base)
+                PEnt e = kt[(((1ull << (2 * lnew)) - 4) / 3) + code];
+                ok.x0 = PE_X0(e); ok.x1 = PE_X1(e); ok.x2 = PE_X2(e);
+                n_ktree_total++;
+            } else {
+                DIntv a;
+                a.x0 = c0; a.x1 = c1; a.x2 = c2; a.info = 0;
+                ok = dev_extend_c(ix, a, ec, st == S4_REQ_BWD);
+                n_exec_total++;
+            }
             n_ext_total++;
-            n_exec_total++;
         }
         // ---- E. bookkeeping of the loop the lane is in, and its next request ----
         if (DO12 && st == S4_REQ_FWD) {
             if (ok.x2 != c2) {
                 ce = pe_pack(c0, c1, c2, cinfo);
                 if (ok.x2 < (u64)min_intv) { st = S4_BWD_INIT; ncurr++; }   // the interval is too small to be extended further: ce is the list's last entry
-                else if (FWD_PUSH_OK()) { CURR[(uint32_t)ncurr * T] = ce; ncurr++; }
+                else if (FWD_PUSH_OK()) { if (!ncurr) emin = cinfo; CURR[(uint32_t)ncurr * T] = ce; ncurr++; }
             }
             if (st == S4_REQ_FWD) {
                 c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i;
@@ -472,6 +557,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     }
 #undef QB
 #undef Q8
+#undef CODE16
 #undef T16_LOAD
 #undef T16_A
 #undef T16_B
@@ -490,5 +576,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->n_ext, (u64)tot);
         unsigned ex = (unsigned)wave_sum_i32((int)n_exec_total);
         if (lane == 0 && ex) atomicAdd(&LH_CTR(ctr)->n_ext_exec[MODE == 3 || MODE == 1 || MODE == 0 ? 0 : MODE == 4 ? 1 : 2], (u64)ex);
+        unsigned kx = (unsigned)wave_sum_i32((int)n_ktree_total);
+        if (lane == 0 && kx) atomicAdd(&LH_CTR(ctr)->n_ktree[MODE == 3 || MODE == 1 || MODE == 0 ? 0 : MODE == 4 ? 1 : 2], (u64)kx);
     }
 }

@@ -94,8 +94,17 @@ struct DIndex {
     // to follow a UNIQUE match through the text instead of through the FM-index (k_smem4.h).
     const u64* isa;
     const uint32_t* tn;
+    // lcp[r] = bases shared by the suffixes of rows r - 1 and r, capped at 255 (rows 0, 1 and n + 1: 0); next to isa / tn, else null.
+    // K1 (pass 1) reads from it whether every entry of a forward list is unique at the point where its longest one ends (k_smem4.h).
+    const uint8_t* lcp;
     // the bi-interval of every 12-mer (packed like K1's list entries, 16 B each): bwt_seed_strategy1's walks start there
     const void* kmer12;
+    // the bi-interval of EVERY string of 1 .. ktree_levels bases (only next to isa / tn; packed like kmer12's entries): level L
+    // (strings of L bases) starts at entry (4^L - 4) / 3, a string's index inside its level is its code with base t at bits
+    // 2t..2t+1.  K1 reads the result of a bwt_extend that yields a short match here — one 16-B read, cacheable for the
+    // shortest — instead of computing it from two occurrence records that lie far apart (k_smem4.h).  Null: not built.
+    const void* ktree;
+    int32_t ktree_levels;
     // sweep filters (k_smem4.h), only next to isa / tn: blocked Bloom filters (one 64-bit word, 4 bits per key) over the
     // LH_BLOOM_K-mers of the text fwd||rev: bloom1 = every k-mer that occurs, bloom2 = every k-mer that occurs at least twice
     const u64* bloom1;
@@ -130,7 +139,7 @@ struct DReg {   // mem_alnreg_t
 // telemetry counters: LH_CTR_SLOTS copies on separate 128-B lines, indexed by blockIdx, summed by the host
 // (same-address atomics serialize at ~12 ns each: one shared copy cost k_extend ~70 ms per 2M waves)
 #define LH_CTR_SLOTS 64
-struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells, n_ext_exec[3], pad[4]; };   // n_ext_exec: bwt_extend calls K1 really executed on the occurrence table, per pass
+struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells, n_ext_exec[3], n_ktree[3], pad[1]; };   // n_ext_exec: bwt_extend calls K1 really executed on the occurrence table, per pass; n_ktree: those it read from the k-mer tree table
 #define LH_CTR(ctr) ((ctr) + (blockIdx.x & (LH_CTR_SLOTS - 1)))
 
 // ------------------------------------------------------------------ lane helpers

@@ -136,3 +136,25 @@ def test_emu_chance_match_second_chains(emu, oracle):
     ctx = idx.context(rs.n_pairs)
     helpers.assert_same_dump(ctx.stage_dump(b), od, helpers.DUMP_FRONT + helpers.DUMP_REGS)
     helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b), inference=True)
+
+
+def test_emu_kmer_tree_levels(emu, oracle):
+    """K1 reads the result of a bwt_extend that yields a short match from the k-mer tree table: the same intervals, seeds, chains and
+    alignments with the table at several depths (incl. ambiguous bases and reads shorter than a level) and without it"""
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = helpers.small_reads(names, contigs, n_barcodes=2, pairs=25, junk=0.05, seed=43)
+    rs.seq[np.arange(5, len(rs.seq), 97)] = 4
+    b = helpers.batch_of(rs)
+    want = oidx.stage_dump(b)
+    ref = oidx.align_barcodes(b)
+    used = {}
+    for levels in (-1, 2, 7, 11):
+        idx = emu.index_from_arrays(oidx.arrays(), ktree_levels=levels)
+        ctx = idx.context(rs.n_pairs)
+        helpers.assert_same_dump(ctx.stage_dump(b), want, helpers.DUMP_FRONT)
+        res = ctx.align_barcodes(b)
+        helpers.assert_same_result(res, ref, inference=True)
+        assert res.counters["n_ext"] < ref.counters["n_ext"]
+        used[levels] = sum(res.counters["n_ktree_p%d" % k] for k in (1, 2, 3))
+    assert used[-1] == 0 < used[2] < used[7] < used[11]
