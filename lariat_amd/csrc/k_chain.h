@@ -471,9 +471,14 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
                 }
                 // a second chain (at human-genome scale every third read has one: a chance match kept as the first shadowed chain)
                 // needs a DP even when the first chain does not: the read goes to an LDS class, where that DP is a few dozen cells
-                if (cheap) { int nz_ = 0; for (int ci = 0; ci < m; ++ci) nz_ += chains[base + ci].n > 0; if (nz_ >= 2) cheap = 0; }
+                int nz_ = 0;
+                for (int ci = 0; ci < m; ++ci) nz_ += chains[base + ci].n > 0;
+                const int cheap_top = cheap;
+                if (nz_ >= 2) cheap = 0;
                 int prim = lh_ext_bucket(heavy ? LH_EXT_COMPLEX_SEEDS + 1 : nseeds, longest, cheap);
-                int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
+                // sub-bucket: reads of one wave should do the same kind of work at the same time (the lanes run their chains one
+                // after the other): a second chain or not, a DP for the first chain or not, then the length of the shorter side
+                int sub = cheap ? (shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1) : (nz_ >= 2 ? 4 : 0) + (cheap_top ? 2 : 0) + (shorter >= 32 ? 1 : 0);
                 ext_key[r] = prim * LH_EXT_SUB + sub;
                 nch_done = m;
             }

@@ -491,6 +491,9 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                         aw = o.w << i;
                         LaneTgt tg;
                         tg.init(ix, tc0, tstep);
+#if defined(LH_K4_HACK)   // timing experiments only: results are wrong
+                        if (dyn || LH_K4_HACK >= 2) { e.score = h0; e.qle = e.tle = e.gtle = 0; e.gscore = -1; e.max_off = 0; a.score = e.score; break; }
+#endif
                         if (dyn) {
                             int over = 0;
                             e = lane_ksw_extend2_dyn(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells, &over);

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--chunk-log2", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--flags", type=int, default=0, help="lh_opts.flags (e.g. 32 = K4 classes one after the other)")
     a = ap.parse_args()
     info = {"genome_mb": a.genome_mb, "nproc": os.cpu_count()}
     for line in open("/proc/meminfo"):
@@ -49,7 +50,7 @@ def main():
     b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
     ctx = idx.context(r["n_pairs"])
     ctx.upload(b)
-    opts = lib.opts()
+    opts = lib.opts(flags=a.flags)
     kern = {}
     for s in range(a.steps + 1):
         t = time.perf_counter()
