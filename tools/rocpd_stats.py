@@ -13,4 +13,7 @@ print("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage,VGPRs,AccumVG
 for r in rows:
     if r[2] / 1e6 < floor:
         continue
-    print('"%s",%d,%d,%.0f,%d,%d,%.2f,%s,%s,%s,%s,%s' % (r[0].replace('"', "'"), r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10]))
+    name = r[0].replace('"', "'")
+    if len(name) > 160:   # rocPRIM's template names run to kilobytes
+        name = name[:157] + "..."
+    print('"%s",%d,%d,%.0f,%d,%d,%.2f,%s,%s,%s,%s,%s' % (name, r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10]))
