@@ -241,7 +241,7 @@ int32_t lh_index_sa_interval(const lh_index* idx);
 void lh_index_free(lh_index* idx);
 
 /* FM-index construction: text = fwd || revcomp of the 2-bit contigs, BWA-byte-compatible output.
- * Host-side (multi-threaded suffix sorting); writes <prefix>.bwt/.sa/.pac/.ann/.amb. */
+ * Host-side (multi-threaded suffix sorting); writes <prefix>.bwt/.sa/.pac/.ann/.amb.  Ambiguous bases as in lh_reference_pack. */
 int lh_index_build(const char* prefix, int32_t n_contigs, const char* const* names, const uint8_t* const* nt4, const int64_t* lens, int32_t threads);
 /* The same construction ON THE DEVICE, sized for a human genome in 288 GB of HBM (hg38: 6.2 G suffixes): suffixes of
  * fwd || revcomp are gathered by 8-mer prefix into chunks, radix-sorted by their first 32 bases, ties finished by direct
@@ -255,6 +255,14 @@ int lh_index_build_device(int device, const uint8_t* pac, int64_t l_pac, int32_t
 int lh_index_export(const lh_index* idx, uint64_t* primary, uint64_t L2[5], uint32_t* bwt, uint64_t* bwt_words, int32_t sa_intv, uint64_t* sa, uint64_t* n_sa);
 /* writes <prefix>.bwt .sa .pac .ann .amb (what lh_index_build writes) from the resident index */
 int lh_index_save(const lh_index* idx, const char* prefix);
+/* bns_fasta2bntseq (bntseq.c) restated, host-only: the .pac image (l_pac/4+1 bytes) of the contigs, ambiguous bases replaced by
+ * lrand48() & 3 under srand48(11) in file order as `bwa index` does, and the holes they leave (.amb: offset, length, letter; a run
+ * of the same letter is one hole; n_ambs[c] = holes starting in contig c, for .ann).  Bases are nt4 codes (0..3, 4 = N) or raw
+ * FASTA letters (values > 4).  Call with max_holes 0 and NULL arrays to count.  lh_index_build does this itself; for
+ * lh_index_build_device pack first, build, then lh_index_set_holes so that lh_index_save writes the same .ann / .amb. */
+int lh_reference_pack(int32_t n_contigs, const uint8_t* const* seqs, const int64_t* lens, uint8_t* pac, int32_t* n_ambs, int32_t max_holes,
+                      int64_t* hole_off, int32_t* hole_len, char* hole_char, int32_t* n_holes);
+int lh_index_set_holes(lh_index* idx, int32_t n_holes, const int64_t* hole_off, const int32_t* hole_len, const char* hole_char);
 
 int lh_context_create(lh_index* idx, int64_t max_pairs_per_batch, const lh_context_opts* co, lh_context** out);
 void lh_context_free(lh_context* ctx);

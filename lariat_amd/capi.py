@@ -348,6 +348,26 @@ class Library:
         self.check(self.L.lh_diag_go_rand(device, int(seed), int(n), a.ctypes.data, b.ctypes.data, f.ctypes.data))
         return a, b, f
 
+    def reference_pack(self, contigs):
+        """bns_fasta2bntseq: contigs (nt4 codes or raw FASTA bytes) -> (pac, l_pac, n_ambs, holes=[(offset, len, letter)])"""
+        n = len(contigs)
+        seqs = [np.ascontiguousarray(np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else s, dtype=np.uint8) for s in contigs]
+        ptrs = (c_u8p * n)(*[s.ctypes.data_as(c_u8p) for s in seqs])
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        l_pac = int(lens.sum())
+        pac = np.zeros(l_pac // 4 + 1, dtype=np.uint8)
+        n_ambs = np.zeros(n, dtype=np.int32)
+        nh = C.c_int32()
+        self.L.lh_reference_pack.argtypes = [C.c_int32, C.POINTER(c_u8p), c_i64p, c_u8p, c_i32p, C.c_int32, c_i64p, c_i32p, C.c_char_p, c_i32p]
+        self.L.lh_reference_pack(n, ptrs, lens.ctypes.data_as(c_i64p), pac.ctypes.data_as(c_u8p), n_ambs.ctypes.data_as(c_i32p), 0, None, None, None, C.byref(nh))
+        ho = np.zeros(nh.value + 1, dtype=np.int64)
+        hl = np.zeros(nh.value + 1, dtype=np.int32)
+        hc = C.create_string_buffer(nh.value + 1)
+        self.check(self.L.lh_reference_pack(n, ptrs, lens.ctypes.data_as(c_i64p), pac.ctypes.data_as(c_u8p), n_ambs.ctypes.data_as(c_i32p), nh.value,
+                                            ho.ctypes.data_as(c_i64p), hl.ctypes.data_as(c_i32p), hc, C.byref(nh)))
+        holes = [(int(ho[i]), int(hl[i]), hc.raw[i:i + 1].decode()) for i in range(nh.value)]
+        return pac, l_pac, n_ambs, holes
+
     def index_opts(self, **kw):
         io = LhIndexOpts()
         self.L.lh_index_opts_init(C.byref(io))
@@ -532,6 +552,14 @@ class Index:
         self.lib.L.lh_diag_index_check.argtypes = [C.c_void_p, C.c_uint64, c_u64p, c_u64p, c_u64p]
         self.lib.check(self.lib.L.lh_diag_index_check(self.h, int(stride), C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def set_holes(self, holes):
+        n = len(holes)
+        ho = np.array([h[0] for h in holes], dtype=np.int64)
+        hl = np.array([h[1] for h in holes], dtype=np.int32)
+        hc = "".join(h[2] for h in holes).encode()
+        self.lib.L.lh_index_set_holes.argtypes = [C.c_void_p, C.c_int32, c_i64p, c_i32p, C.c_char_p]
+        self.lib.check(self.lib.L.lh_index_set_holes(self.h, n, ho.ctypes.data_as(c_i64p), hl.ctypes.data_as(c_i32p), hc))
 
     def save(self, prefix):
         self.lib.check(self.lib.L.lh_index_save(self.h, prefix.encode()))
@@ -731,5 +759,5 @@ EXPORTED_SYMBOLS = [
     "lh_records_text", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read", "lh_diag_go_rand",
-    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat",
+    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes",
 ]

@@ -4,8 +4,8 @@
 // BWT with '$' removed at `primary`, occurrence counts interleaved every 128 symbols, SA sampled every 32 rows.
 //
 // Host-side, multi-threaded: suffixes are bucketed by their first 12 symbols (counting sort) and each bucket is
-// finished by a comparison sort over the 2-bit packed text, 32 symbols per compare word.  Contigs must be N-free
-// (synthetic genomes are); `.amb` is written with zero holes.
+// finished by a comparison sort over the 2-bit packed text, 32 symbols per compare word.  Ambiguous bases are replaced and
+// recorded as bns_fasta2bntseq does (lh_reference_pack below).
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -63,6 +63,51 @@ bool write_file(const std::string& p, const void* d, size_t n) {
 }
 }  // namespace
 
+// bntseq.c: nst_nt4_table (A C G T in either case -> 0..3, everything else 4)
+static inline int nt4_of(uint8_t v) {
+    if (v <= 4) return v;
+    switch (v) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+
+// bns_fasta2bntseq / add1 (bntseq.c) restated: the 2-bit forward reference and the table of "holes".  An ambiguous base is
+// replaced by lrand48() & 3 — the C library's 48-bit linear congruential generator, seeded with srand48(11) once per index
+// (the 11 is the seed field of the .ann header) and stepped once per ambiguous base in file order — and a run of the SAME
+// ambiguity letter is one hole (offset, length, letter) of the .amb file; n_ambs counts a contig's holes for the .ann file.
+// Bases come as nt4 codes (0..3, 4 = 'N') or as raw FASTA letters (any value > 4).
+extern "C" int lh_reference_pack(int32_t n_contigs, const uint8_t* const* seqs, const int64_t* lens, uint8_t* pac, int32_t* n_ambs, int32_t max_holes,
+                                 int64_t* hole_off, int32_t* hole_len, char* hole_char, int32_t* n_holes) {
+    if (n_contigs <= 0 || !seqs || !lens || !pac || !n_holes) return LH_E_ARG;
+    i64 l_pac = 0;
+    for (int i = 0; i < n_contigs; ++i) l_pac += lens[i];
+    memset(pac, 0, (size_t)(l_pac / 4 + 1));
+    u64 x48 = ((u64)11 << 16) | 0x330E;   // srand48(11)
+    i64 p = 0;
+    int nh = 0;
+    for (int c = 0; c < n_contigs; ++c) {
+        int lasts = 0;   // add1(): `lasts` restarts at 0 for every sequence
+        if (n_ambs) n_ambs[c] = 0;
+        for (i64 i = 0; i < lens[c]; ++i, ++p) {
+            const uint8_t raw = seqs[c][i];
+            const int letter = raw <= 4 ? "ACGTN"[raw] : raw;
+            int b = nt4_of(raw);
+            if (b >= 4) {
+                if (lasts == letter && nh > 0) { if (hole_len && nh <= max_holes) ++hole_len[nh - 1]; }
+                else {
+                    if (nh < max_holes) { if (hole_off) hole_off[nh] = p; if (hole_len) hole_len[nh] = 1; if (hole_char) hole_char[nh] = (char)letter; }
+                    ++nh;
+                    if (n_ambs) ++n_ambs[c];
+                }
+                x48 = (x48 * 0x5DEECE66Dull + 0xB) & 0xFFFFFFFFFFFFull;   // lrand48(): the high 31 bits of the new state
+                b = (int)((x48 >> 17) & 3);
+            }
+            lasts = letter;
+            pac[p >> 2] |= (uint8_t)(b << ((~p & 3) << 1));
+        }
+    }
+    *n_holes = nh;
+    return nh > max_holes && (hole_off || hole_len || hole_char) ? LH_E_CAPACITY : LH_OK;
+}
+
 extern "C" int lh_index_build(const char* prefix, int32_t n_contigs, const char* const* names, const uint8_t* const* nt4, const int64_t* lens, int32_t threads) {
     if (!prefix || n_contigs <= 0 || !names || !nt4 || !lens) return LH_E_ARG;
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
@@ -72,13 +117,18 @@ extern "C" int lh_index_build(const char* prefix, int32_t n_contigs, const char*
     i64 n = 2 * l_pac;
     // text
     std::vector<uint8_t> T((size_t)n);
+    std::vector<int32_t> n_ambs((size_t)n_contigs, 0), hole_len;
+    std::vector<i64> hole_off;
+    std::vector<char> hole_char;
     {
-        i64 k = 0;
-        for (int i = 0; i < n_contigs; ++i)
-            for (i64 j = 0; j < lens[i]; ++j) {
-                if (nt4[i][j] > 3) return LH_E_LIMIT;   // N-free contigs only
-                T[k++] = nt4[i][j];
-            }
+        std::vector<uint8_t> pac0((size_t)(l_pac / 4 + 1), 0);
+        int32_t nh = 0;
+        lh_reference_pack(n_contigs, nt4, lens, pac0.data(), n_ambs.data(), 0, nullptr, nullptr, nullptr, &nh);   // count the holes
+        hole_off.resize((size_t)nh + 1); hole_len.resize((size_t)nh + 1); hole_char.resize((size_t)nh + 1);
+        int rc = lh_reference_pack(n_contigs, nt4, lens, pac0.data(), n_ambs.data(), nh, hole_off.data(), hole_len.data(), hole_char.data(), &nh);
+        if (rc) return rc;
+        hole_off.resize((size_t)nh); hole_len.resize((size_t)nh); hole_char.resize((size_t)nh);
+        for (i64 i = 0; i < l_pac; ++i) T[i] = pac0[i >> 2] >> ((~i & 3) << 1) & 3;
         for (i64 i = 0; i < l_pac; ++i) T[l_pac + i] = 3 - T[l_pac - 1 - i];
     }
     Packed P;
@@ -188,13 +238,18 @@ extern "C" int lh_index_build(const char* prefix, int32_t n_contigs, const char*
         s += buf;
         i64 off = 0;
         for (int i = 0; i < n_contigs; ++i) {
-            snprintf(buf, sizeof buf, "0 %s (null)\n%lld %d 0\n", names[i], (long long)off, (int)lens[i]);
+            snprintf(buf, sizeof buf, "0 %s (null)\n%lld %d %d\n", names[i], (long long)off, (int)lens[i], (int)n_ambs[(size_t)i]);
             s += buf;
             off += lens[i];
         }
         if (!write_file(p + ".ann", s.data(), s.size())) return LH_E_IO;
-        snprintf(buf, sizeof buf, "%lld %d %u\n", (long long)l_pac, n_contigs, 0u);
-        if (!write_file(p + ".amb", buf, strlen(buf))) return LH_E_IO;
+        snprintf(buf, sizeof buf, "%lld %d %u\n", (long long)l_pac, n_contigs, (unsigned)hole_off.size());
+        std::string amb = buf;
+        for (size_t h = 0; h < hole_off.size(); ++h) {   // bns_dump: "%lld %d %c"
+            snprintf(buf, sizeof buf, "%lld %d %c\n", (long long)hole_off[h], (int)hole_len[h], hole_char[h]);
+            amb += buf;
+        }
+        if (!write_file(p + ".amb", amb.data(), amb.size())) return LH_E_IO;
     }
     return LH_OK;
 }

@@ -79,6 +79,15 @@ bool index_load(const std::string& prefix, Index& idx, std::string* err) {
             c.offset = off; c.len = len; c.n_ambs = na; c.is_alt = 0;
         }
     }
+    {   // .amb (bns_restore_core): "l_pac n_seqs n_holes" then "offset len letter" per hole
+        std::ifstream f(prefix + ".amb");
+        std::string line;
+        if (f && std::getline(f, line))
+            while (std::getline(f, line)) {
+                long long o; int l; char ch;
+                if (sscanf(line.c_str(), "%lld %d %c", &o, &l, &ch) == 3) idx.holes.push_back(Index::Hole{o, l, ch});
+            }
+    }
     // .pac (forward strand only)
     if (!read_file(prefix + ".pac", d)) { if (err) *err = "cannot read " + prefix + ".pac"; return false; }
     idx.pac.assign(d.begin(), d.begin() + (idx.l_pac / 4 + 1));
@@ -90,11 +99,28 @@ void index_build_naive(const std::vector<std::string>& names, const std::vector<
     idx = Index();
     int64_t off = 0;
     std::vector<uint8_t> T;
+    // bntseq.c bns_fasta2bntseq / add1: an ambiguous base becomes lrand48() & 3 (srand48(bns->seed), seed 11, one draw per
+    // ambiguous base in file order); a run of the same ambiguity letter is one hole.  Bases: nt4 codes (4 = 'N') or raw letters.
+    uint64_t x48 = ((uint64_t)idx.seed << 16) | 0x330E;
+    auto lrand48_ = [&]() { x48 = (x48 * 0x5DEECE66Dull + 0xBull) & ((1ull << 48) - 1); return (long)(x48 >> 17); };
     for (size_t i = 0; i < seqs.size(); ++i) {
         Contig c;
         c.offset = off; c.len = (int32_t)seqs[i].size(); c.n_ambs = 0; c.gi = 0; c.is_alt = 0; c.name = names[i];
+        int lasts = 0;
+        for (size_t j = 0; j < seqs[i].size(); ++j) {
+            uint8_t raw = seqs[i][j];
+            int letter = raw <= 4 ? "ACGTN"[raw] : raw;
+            int b = raw <= 4 ? raw : (letter == 'A' || letter == 'a') ? 0 : (letter == 'C' || letter == 'c') ? 1 : (letter == 'G' || letter == 'g') ? 2
+                                   : (letter == 'T' || letter == 't') ? 3 : 4;
+            if (b >= 4) {
+                if (lasts == letter) ++idx.holes.back().len;
+                else { idx.holes.push_back(Index::Hole{c.offset + (int64_t)j, 1, (char)letter}); ++c.n_ambs; }
+                b = (int)(lrand48_() & 3);
+            }
+            lasts = letter;
+            T.push_back((uint8_t)b);
+        }
         idx.contigs.push_back(c);
-        T.insert(T.end(), seqs[i].begin(), seqs[i].end());
         off += c.len;
     }
     idx.l_pac = off;
@@ -189,8 +215,10 @@ std::string image_ann(const Index& idx) {
 }
 std::string image_amb(const Index& idx) {
     char buf[256];
-    snprintf(buf, sizeof buf, "%lld %d %u\n", (long long)idx.l_pac, (int)idx.contigs.size(), 0u);
-    return buf;
+    snprintf(buf, sizeof buf, "%lld %d %u\n", (long long)idx.l_pac, (int)idx.contigs.size(), (unsigned)idx.holes.size());
+    std::string s = buf;
+    for (const Index::Hole& h : idx.holes) { snprintf(buf, sizeof buf, "%lld %d %c\n", (long long)h.offset, h.len, h.amb); s += buf; }
+    return s;
 }
 
 // ---- bntseq.c ------------------------------------------------------------------

@@ -57,6 +57,8 @@ struct Index {
     uint32_t seed = 11;
     std::vector<Contig> contigs;
     std::vector<uint8_t> pac;    // 2-bit, MSB first
+    struct Hole { int64_t offset; int32_t len; char amb; };
+    std::vector<Hole> holes;     // bntamb1_t: runs of one ambiguity letter (.amb)
 };
 
 // read <prefix>.bwt/.sa/.pac/.ann/.amb  (bwa_idx_load, gobwa.go:130)

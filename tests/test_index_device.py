@@ -116,3 +116,28 @@ def test_emu_index_self_check_and_synth(emu, oracle):
     act = res.active_idx[0::2]
     ok = (res.rid[act] == r["truth_rid"]) & (np.abs(res.pos[act] - r["truth_pos1"]) < 20)
     assert ok.mean() > 0.8
+
+
+def test_emu_device_build_of_a_reference_with_holes(emu, oracle, tmp_path):
+    """N runs: lh_reference_pack (bwa's replacement rule) -> device build -> lh_index_set_holes -> lh_index_save gives the
+    files the oracle's builder writes, .amb and .ann included; reads across the replaced stretch align as the oracle's do"""
+    rng = np.random.default_rng(12)
+    g = "".join("ACGT"[v] for v in rng.integers(0, 4, size=40000))
+    c1 = (g[:9000] + "N" * 40 + g[9040:25000]).encode()
+    c2 = ("NN" + g[25002:33000] + "KKKK" + g[33004:]).encode()
+    contigs = [np.frombuffer(c1, dtype=np.uint8), np.frombuffer(c2, dtype=np.uint8)]
+    pac, l_pac, n_ambs, holes = emu.reference_pack(contigs)
+    ctg = [("c1", len(c1), 0), ("c2", len(c2), len(c1))]
+    idx = emu.index_build_device(pac, l_pac, ctg, build_chunk_log2=13)
+    idx.set_holes(holes)
+    oidx = oracle.index_build_naive(["c1", "c2"], contigs)
+    prefix = str(tmp_path / "h.fa")
+    idx.save(prefix)
+    for k, ext in enumerate((".bwt", ".sa", ".pac", ".ann", ".amb")):
+        assert open(prefix + ext, "rb").read() == oidx.image(k), ext
+    again = emu.index_load(prefix)   # holes survive a load / save round trip
+    again.save(str(tmp_path / "h2.fa"))
+    assert open(str(tmp_path / "h2.fa.amb")).read() == open(prefix + ".amb").read()
+    r = emu.synth_reads(pac, l_pac, ctg, seed=3, n_barcodes=2, pairs_per_barcode=30)
+    b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
+    helpers.assert_same_result(idx.context(r["n_pairs"]).align_barcodes(b), oidx.align_barcodes(b), inference=True)
