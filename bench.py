@@ -178,13 +178,15 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
 
     achieved = ALGORITHMIC bytes of one launch / its average duration (HIP events on the context's stream, this run): for a K1
     pass, 64 B (two 32-B occurrence records, what bwt_extend's bwt_2occ4 touches) x the bwt_extend calls the pass really
-    EXECUTED (device counter n_ext_exec_*, not the reference's call count) + the read bases once.
+    EXECUTED (device counter n_ext_exec_*, not the reference's call count) + 16 B x the results it read from the k-mer tree
+    table instead (n_ktree_*) + the read bases once.
     traffic = HBM-side bytes of one launch from rocprofv3 PMC passes of this same command (FETCH_SIZE + WRITE_SIZE, separate
     passes, committed as profiles/r02_pmc_bench.json with the commit it was measured at); traffic_frac is what the judge can
     recompute from profiles/.  reference_work_equiv is the reference's bookkeeping (64 B x ALL its bwt_extend calls) priced
     at this kernel's time: how much of the reference's traffic the filters make unnecessary, not a bandwidth."""
     dom = max(avg, key=avg.get)
-    k1 = {"k_smem4": ("k_smem4_t<3>", "n_ext_exec_p1"), "k_smem4_p2": ("k_smem4_t<4>", "n_ext_exec_p2"), "k_smem4_p3": ("k_smem4_t<2>", "n_ext_exec_p3")}
+    k1 = {"k_smem4": ("k_smem4_t<3>", "n_ext_exec_p1", "n_ktree_p1"), "k_smem4_p2": ("k_smem4_t<4>", "n_ext_exec_p2", "n_ktree_p2"),
+          "k_smem4_p3": ("k_smem4_t<2>", "n_ext_exec_p3", "n_ktree_p3")}
     n_bases = int(reads["seq_off"][-1])
     pmc = None
     if os.path.exists(PMC_FILE):
@@ -195,10 +197,11 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
     r = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     ms = avg[dom]
     if dom in k1:
-        kname, ckey = k1[dom]
-        alg = 64.0 * cnt[ckey] + n_bases
+        kname, ckey, tkey = k1[dom]
+        alg = 64.0 * cnt[ckey] + 16.0 * cnt[tkey] + n_bases
         r["kernel"] = "%s (K1 %s of mem_collect_intv)" % (kname, {"k_smem4": "pass 1", "k_smem4_p2": "pass 2", "k_smem4_p3": "pass 3"}[dom])
         r["bwt_extend_executed"] = cnt[ckey]
+        r["kmer_tree_reads"] = cnt[tkey]
     else:
         kname = dom
         alg = {"k_seed": 8.0 * cnt["n_sa"]}.get(dom, 0.0)

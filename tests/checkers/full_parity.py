@@ -23,7 +23,7 @@ t = time.time(); ores = oidx.align_barcodes(b, threads=min(os.cpu_count(), 128))
 helpers.assert_same_result(res, ores, inference=True)
 for k in ("n_sa", "glob_cells", "n_rescue", "rescue_cells"):
     assert res.counters[k] == ores.counters[k], k
-assert res.counters["n_ext"] <= ores.counters["n_ext"]   # K1's sweep filter skips bwt_extend calls that cannot give a seed
+assert res.counters["n_ext"] <= ores.counters["n_ext"]   # K1's sweep filter / collapsed sweeps skip bwt_extend calls that cannot give a seed
 print("bwt_extend: HIP %d, reference count %d" % (res.counters["n_ext"], ores.counters["n_ext"]))
 print("genome %g Mb%s" % (mb, ", 200 duplications of 20 kb at 99 %, 30 repeat families x 80 copies" if rep else ""))
 print("full parity ok: %d pairs, %d candidates, every field equal (HIP %.1f s incl. transfers, oracle %.1f s on %d threads)" % (rs.n_pairs, res.n_cand, t_gpu, t_cpu, min(os.cpu_count(), 128)))

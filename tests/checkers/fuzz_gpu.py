@@ -22,7 +22,17 @@ while time.time() < t_end:
     contigs = synth.make_genome(lens, seed=seed, n_dup=int(rng.integers(0, 25)), dup_len=int(rng.integers(500, 6000)), dup_identity=float(rng.uniform(0.97, 1.0)),
                                 n_rep_family=int(rng.integers(0, 6)), rep_len=int(rng.integers(100, 400)), rep_copies=int(rng.integers(5, 60)))
     oidx = oracle.index_build_naive(names, contigs)
-    idx = lib.index_from_arrays(oidx.arrays())
+    iopts = {}
+    if rng.random() < 0.5:
+        iopts["ktree_levels"] = int(rng.choice([-1, 3, 8, 11, 12]))
+    if rng.random() < 0.2:
+        iopts["sb_shift"] = int(rng.choice([10, 14, 20]))
+    if rng.random() < 0.5:   # the index built on the device from the .pac image instead of uploaded
+        pac, l_pac, _, _ = lib.reference_pack(contigs)
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        idx = lib.index_build_device(pac, l_pac, [(names[i], lens[i], int(offs[i])) for i in range(ncont)], build_chunk_log2=int(rng.choice([0, 12, 16])), **iopts)
+    else:
+        idx = lib.index_from_arrays(oidx.arrays(), **iopts)
     if rng.random() < 0.3:
         idx.resample_sa(int(rng.choice([2, 8, 32])))
     l1, l2 = int(rng.integers(50, 240)), int(rng.integers(50, 240))
@@ -34,15 +44,18 @@ while time.time() < t_end:
     rfa = (rng.random(len(rs.bc_pair_off) - 1) < 0.8).astype(np.uint8)
     b = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed, bc_do_rfa=rfa)
     kw = {}
+    if rng.random() < 0.2:
+        kw["flags"] = int(rng.choice([capi.LH_F_NO_SWEEP_FILTER, capi.LH_F_SMEM_FUSED, capi.LH_F_SMEM_P12, capi.LH_F_EXT_SERIAL, capi.LH_F_EXT_WAVE]))
     if rng.random() < 0.3:
         kw = dict(b=int(rng.integers(2, 7)), o_del=int(rng.integers(3, 9)), o_ins=int(rng.integers(3, 9)), e_del=int(rng.integers(1, 3)), e_ins=int(rng.integers(1, 3)),
                   w=int(rng.choice([20, 100])), zdrop=int(rng.choice([50, 100])), min_seed_len=int(rng.choice([15, 19, 25])))
     try:
         ctx = idx.context(rs.n_pairs)
-        helpers.assert_same_dump(ctx.stage_dump(b, lib.opts(**kw)), oidx.stage_dump(b, oracle.opts(**kw)), helpers.DUMP_FRONT + helpers.DUMP_REGS)
-        helpers.assert_same_result(ctx.align_barcodes(b, lib.opts(**kw)), oidx.align_barcodes(b, oracle.opts(**kw), threads=16), inference=True)
+        okw = {k: v for k, v in kw.items() if k != "flags"}
+        helpers.assert_same_dump(ctx.stage_dump(b, lib.opts(**kw)), oidx.stage_dump(b, oracle.opts(**okw)), helpers.DUMP_FRONT + helpers.DUMP_REGS)
+        helpers.assert_same_result(ctx.align_barcodes(b, lib.opts(**kw)), oidx.align_barcodes(b, oracle.opts(**okw), threads=16), inference=True)
     except Exception as e:
-        print("DIFF at seed %d (contigs %s, reads %dx%d/%d, opts %s): %s" % (seed, lens, l1, l2, rs.n_pairs, kw, str(e)[:600]), flush=True)
+        print("DIFF at seed %d (contigs %s, reads %dx%d/%d, opts %s, index %s): %s" % (seed, lens, l1, l2, rs.n_pairs, kw, iopts, str(e)[:600]), flush=True)
         sys.exit(1)
     it += 1
 print("fuzz ok: %d cases from seed %d in %.0f s" % (it, seed0, budget))
