@@ -232,6 +232,35 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
     return r
 
 
+def two_contexts(idx, batches, n_pairs, opts, rounds=3):
+    """informational: two contexts fed from two host threads, each aligning its own batches (the production shape INTEGRATION.md
+    recommends): kernels of one batch fill the tails of the other's.  The headline `value` stays the single-context rate, whose
+    per-kernel times are the ones profiled."""
+    import threading
+    ctxs = []
+    for k in range(2):
+        c = idx.context(n_pairs)
+        c.upload(batches[k % len(batches)])
+        ctxs.append(c)
+    for c in ctxs:
+        c.align_resident(opts)
+    t0 = time.perf_counter()
+
+    def work(c):
+        for _ in range(rounds):
+            c.align_resident(opts)
+
+    th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for c in ctxs:
+        c.close()
+    return round(2 * rounds * n_pairs / dt, 1)
+
+
 def extras(lib, idx, ctx, batch, n_pairs, opts, step_s):
     """informational: what the C-ABI costs host to host (upload + align + download of the full result SoA)"""
     t0 = time.time()
@@ -242,8 +271,13 @@ def extras(lib, idx, ctx, batch, n_pairs, opts, step_s):
     t0 = time.time()
     ctx.download_raw()
     t_down = time.time() - t0
-    return {"pcie": {"upload_h2d_s": round(t_up, 4), "download_d2h_s": round(t_down, 4),
-                     "pcie_inclusive_pairs_per_s": round(n_pairs / (step_s + t_up + t_down), 1)}}
+    out = {"pcie": {"upload_h2d_s": round(t_up, 4), "download_d2h_s": round(t_down, 4),
+                    "pcie_inclusive_pairs_per_s": round(n_pairs / (step_s + t_up + t_down), 1)}}
+    try:
+        out["two_context_resident_pairs_per_s"] = two_contexts(idx, [batch], n_pairs, opts)
+    except Exception as e:   # informational only
+        out["two_context_resident_pairs_per_s"] = "failed: %s" % e
+    return out
 
 
 def cpu_baseline(a, idx, pac, reads):

@@ -2,8 +2,8 @@
 // Layout of the outputs follows go/src/inference/bamwriter.go: CreateBAM (:46-130 header: references, read groups, program
 // line, @CO comments on first chunks), CreateBAMs (:139-191 file names and the packing of short contigs), AppendBams
 // (:281-284: every record goes to bc_sorted_bam.bam and to one position bucket, ZZZ_unmapped for IsUnmapped records).
-// The record fields come from lh_records_text (records.cpp), so the text and the binary form cannot drift apart; the
-// encoding itself is the SAM/BAM specification's (little-endian record, 4-bit bases, reg2bin, BGZF blocks of <= 0xff00
+// The record fields come from records.cpp's LhRec — the same structure lh_records_text renders as text — so the text and the
+// binary form cannot drift apart; the encoding itself is the SAM/BAM specification's (little-endian record, 4-bit bases, reg2bin, BGZF blocks of <= 0xff00
 // bytes with the BC extra field, empty end-of-file block).
 #include <zlib.h>
 #include <atomic>
@@ -20,7 +20,7 @@
 #include "../../include/lariat_hip.h"
 
 extern "C" int lh_set_error_(int code, const char* msg);
-int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, std::vector<std::string>& part);
+#include "records_internal.h"
 
 namespace {
 
@@ -115,79 +115,47 @@ std::string header_bytes(const lh_bam_writer* w, const char* read_groups, bool c
     return h;
 }
 
-// one text line of lh_records_text -> one BAM record appended to `rec`; returns the position bucket (outs index)
-int encode(const lh_bam_writer* w, const char* line, size_t n, std::string& rec) {
-    std::vector<std::pair<const char*, size_t>> f;
-    const char* p = line;
-    const char* e = line + n;
-    while (p <= e) {
-        const char* t = (const char*)memchr(p, '\t', (size_t)(e - p));
-        if (!t) t = e;
-        f.emplace_back(p, (size_t)(t - p));
-        p = t + 1;
-    }
-    if (f.size() < 11) return -1;
-    auto str = [&](int i) { return std::string(f[i].first, f[i].second); };
-    auto ref_id = [&](int i) -> int32_t {
-        if (f[i].second == 1 && f[i].first[0] == '*') return -1;
-        auto it = w->rid_of.find(str(i));
-        return it == w->rid_of.end() ? -1 : it->second;
-    };
-    const int flag = atoi(str(1).c_str());
-    const int32_t rid = ref_id(2), mrid = ref_id(6);
-    const int64_t pos = atoll(str(3).c_str()), mpos = atoll(str(7).c_str()), tlen = atoll(str(8).c_str());
-    const int mapq = atoi(str(4).c_str());
-    std::vector<uint32_t> cig;
+// one record (records.cpp) -> its BAM encoding appended to `rec`; returns the position bucket (outs index)
+int encode(const lh_bam_writer* w, const LhRec& R, std::string& rec) {
     int64_t reflen = 0;
-    if (!(f[5].second == 1 && f[5].first[0] == '*')) {
-        uint32_t len = 0;
-        for (size_t i = 0; i < f[5].second; ++i) {
-            char ch = f[5].first[i];
-            if (ch >= '0' && ch <= '9') len = len * 10 + (uint32_t)(ch - '0');
-            else {
-                int op = ch == 'M' ? 0 : ch == 'I' ? 1 : ch == 'D' ? 2 : ch == 'N' ? 3 : ch == 'S' ? 4 : ch == 'H' ? 5 : 6;
-                cig.push_back(len << 4 | (uint32_t)op);
-                if (op == 0 || op == 2 || op == 3) reflen += len;
-                len = 0;
-            }
-        }
+    for (size_t i = 0; i < R.cig_len.size(); ++i)
+        if (R.cig_op[i] == 'M' || R.cig_op[i] == 'D' || R.cig_op[i] == 'N') reflen += R.cig_len[i];
+    const size_t at = rec.size();
+    put32(rec, 0);   // block_size, patched below
+    put32(rec, (uint32_t)R.rid);
+    put32(rec, (uint32_t)(int32_t)R.pos);
+    const uint32_t lname = (uint32_t)R.name_len + 1;
+    const int bin = R.pos < 0 ? 4680 : reg2bin(R.pos, R.pos + (reflen > 0 ? reflen : 1));
+    put32(rec, (uint32_t)bin << 16 | (uint32_t)(R.mapq & 0xff) << 8 | (lname & 0xff));
+    put32(rec, (uint32_t)R.flags << 16 | (uint32_t)(R.cig_len.size() & 0xffff));
+    put32(rec, (uint32_t)R.seq.size());
+    put32(rec, (uint32_t)R.mrid);
+    put32(rec, (uint32_t)(int32_t)R.mpos);
+    put32(rec, (uint32_t)(int32_t)R.tlen);
+    rec.append(R.name, R.name_len); rec += '\0';
+    for (size_t i = 0; i < R.cig_len.size(); ++i) {
+        const char ch = R.cig_op[i];
+        const uint32_t op = ch == 'M' ? 0 : ch == 'I' ? 1 : ch == 'D' ? 2 : ch == 'N' ? 3 : ch == 'S' ? 4 : ch == 'H' ? 5 : 6;
+        put32(rec, R.cig_len[i] << 4 | op);
     }
-    std::string seq = (f[9].second == 1 && f[9].first[0] == '*') ? std::string() : str(9);
-    std::string qual = (f[10].second == 1 && f[10].first[0] == '*') ? std::string() : str(10);
-    std::string body;
-    put32(body, (uint32_t)rid);
-    put32(body, (uint32_t)(int32_t)pos);
-    const uint32_t lname = (uint32_t)f[0].second + 1;
-    const int bin = pos < 0 ? 4680 : reg2bin(pos, pos + (reflen > 0 ? reflen : 1));
-    put32(body, (uint32_t)bin << 16 | (uint32_t)(mapq & 0xff) << 8 | (lname & 0xff));
-    put32(body, (uint32_t)flag << 16 | (uint32_t)(cig.size() & 0xffff));
-    put32(body, (uint32_t)seq.size());
-    put32(body, (uint32_t)mrid);
-    put32(body, (uint32_t)(int32_t)mpos);
-    put32(body, (uint32_t)(int32_t)tlen);
-    body.append(f[0].first, f[0].second); body += '\0';
-    for (uint32_t c : cig) put32(body, c);
-    static const char* code = "=ACMGRSVTWYHKDBN";
-    for (size_t i = 0; i < seq.size(); i += 2) {
-        auto nyb = [&](char ch) { const char* q = strchr(code, ch); return q ? (int)(q - code) : 15; };
-        int hi = nyb(seq[i]), lo = i + 1 < seq.size() ? nyb(seq[i + 1]) : 0;
-        body += (char)(hi << 4 | lo);
+    auto nyb = [](char ch) { switch (ch) { case '=': return 0; case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5;
+                                           case 'S': return 6; case 'V': return 7; case 'T': return 8; case 'W': return 9; case 'Y': return 10; case 'H': return 11;
+                                           case 'K': return 12; case 'D': return 13; case 'B': return 14; default: return 15; } };
+    for (size_t i = 0; i < R.seq.size(); i += 2) rec += (char)(nyb(R.seq[i]) << 4 | (i + 1 < R.seq.size() ? nyb(R.seq[i + 1]) : 0));
+    if (R.qual.size() == R.seq.size()) for (char ch : R.qual) rec += (char)(ch - 33);   // fixQual
+    else rec.append(R.seq.size(), (char)0xff);
+    for (size_t k = 0; k < R.n_tags; ++k) {
+        const LhRecTag& g = R.tags[k];
+        rec += g.tag[0]; rec += g.tag[1];
+        if (g.type == 'i') { rec += 'i'; put32(rec, (uint32_t)g.i); }
+        else { rec += 'Z'; rec += g.z; rec += '\0'; }
     }
-    if (qual.size() == seq.size()) for (char ch : qual) body += (char)(ch - 33);   // fixQual
-    else body.append(seq.size(), (char)0xff);
-    for (size_t i = 11; i < f.size(); ++i) {   // TAG:TYPE:VALUE
-        if (f[i].second < 5) continue;
-        const char* t = f[i].first;
-        body += t[0]; body += t[1];
-        if (t[3] == 'i') { body += 'i'; put32(body, (uint32_t)(int32_t)atoll(std::string(t + 5, f[i].second - 5).c_str())); }
-        else { body += 'Z'; body.append(t + 5, f[i].second - 5); body += '\0'; }
-    }
-    put32(rec, (uint32_t)body.size());
-    rec += body;
+    const uint32_t body = (uint32_t)(rec.size() - at - 4);
+    rec[at] = (char)body; rec[at + 1] = (char)(body >> 8); rec[at + 2] = (char)(body >> 16); rec[at + 3] = (char)(body >> 24);
     // position bucket (AppendBams): IsUnmapped records carry pos -1 after AppendBam's edit
-    if (pos < 0 || rid < 0) return (int)w->outs.size() - 1;
-    size_t ch = (size_t)(pos / w->chunk);
-    const std::vector<int>& b = w->bucket[(size_t)rid];
+    if (R.pos < 0 || R.rid < 0) return (int)w->outs.size() - 1;
+    size_t ch = (size_t)(R.pos / w->chunk);
+    const std::vector<int>& b = w->bucket[(size_t)R.rid];
     return b[ch < b.size() ? ch : b.size() - 1];
 }
 
@@ -288,38 +256,21 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
     double t0 = now();
     std::vector<const char*> names;
     for (auto& s : w->names) names.push_back(s.c_str());
-    std::vector<std::string> part;
-    int rc = lh_records_parts_(res, in, (int32_t)names.size(), names.data(), part);
+    // every range of pairs is rendered and encoded by its own host thread, straight from the result's arrays into BAM records
+    // (no text form in between); per-file byte strings are joined in order
+    std::vector<std::vector<std::string>> local;
+    int nt = 0;
+    int rc = lh_records_visit_(res, in, (int32_t)names.size(), names.data(), &nt,
+                               [&](int t) { if ((size_t)t >= local.size()) local.resize((size_t)t + 1); local[(size_t)t].assign(w->outs.size(), std::string()); },
+                               [&](int t, const LhRec& R) {
+                                   std::string& bc = local[(size_t)t][0];          // BarcodeSortedBam
+                                   const size_t at = bc.size();
+                                   const int b = encode(w, R, bc);
+                                   local[(size_t)t][(size_t)b].append(bc, at, std::string::npos);   // its position bucket
+                               });
     if (rc) return rc;
     double t1 = now();
-    // every block of lines (one per range of pairs) is encoded by its own host thread; per-file byte strings are joined in order
-    const int nt = (int)part.size();
-    std::vector<std::vector<std::string>> local((size_t)nt, std::vector<std::string>(w->outs.size()));
-    std::vector<int> bad((size_t)nt, 0);
-    auto work = [&](int t) {
-        std::string rec;
-        const char* p = part[(size_t)t].data();
-        const char* e = p + part[(size_t)t].size();
-        while (p < e) {
-            const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
-            if (!nl) nl = e;
-            rec.clear();
-            int b = encode(w, p, (size_t)(nl - p), rec);
-            if (b < 0) { bad[(size_t)t] = 1; return; }
-            local[(size_t)t][0] += rec;          // BarcodeSortedBam
-            local[(size_t)t][(size_t)b] += rec;  // its position bucket
-            p = nl + 1;
-        }
-    };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& t : th) t.join();
-    }
     double t2 = now();
-    for (int t = 0; t < nt; ++t)
-        if (bad[(size_t)t]) return lh_set_error_(LH_E_ARG, "lh_bam_append: malformed record line");
     {   // per-file byte strings are joined in block order; the files are independent, so one host thread per file
         std::atomic<size_t> next_out{0};
         auto join = [&]() {
@@ -341,7 +292,7 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
     }
     double t3 = now();
     if (!flush(w, false)) { w->failed = true; return lh_set_error_(LH_E_IO, "lh_bam_append: compression or write failed"); }
-    if (timing) fprintf(stderr, "[lh_bam_append] text %.3f s, encode %.3f s, join %.3f s, compress+write %.3f s (%d threads)\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, nt);
+    if (timing) fprintf(stderr, "[lh_bam_append] records %.3f s, join %.3f s, compress+write %.3f s (%d threads)\n", t1 - t0, t3 - t2, now() - t3, nt);
     return LH_OK;
 }
 

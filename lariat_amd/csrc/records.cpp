@@ -12,6 +12,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/lariat_hip.h"
+#include "records_internal.h"
 
 extern "C" int lh_set_error_(int code, const char* msg);
 
@@ -51,8 +52,8 @@ void put_int(std::string& s, long long v) {   // decimal, without the cost of sn
     while (n) s += b[--n];
 }
 
-// AppendBam(aln, primary, debugTags = false, attach_bx)
-void append_bam(Ctx& c, std::string& o, int64_t read, int64_t aln, int64_t primary, bool attach_bx) {
+// AppendBam(aln, primary, debugTags = false, attach_bx): fills R
+void append_bam(Ctx& c, LhRec& R, int64_t read, int64_t aln, int64_t primary, bool attach_bx) {
     const lh_result* r = c.r;
     const lh_ingest_batch* in = c.in;
     const int64_t pair = read >> 1;
@@ -116,22 +117,19 @@ void append_bam(Ctx& c, std::string& o, int64_t read, int64_t aln, int64_t prima
         seq = seq.substr(start, end - start);
         qual = qual.substr(qs, qe > qs ? qe - qs : 0);
     }
-    o += col(in->name, in->name_off, pair); o += '\t';
-    put_int(o, flags); o += '\t';
-    o += ref ? ref : "*"; o += '\t';
-    put_int(o, c.pos[aln]); o += '\t';
-    put_int(o, mq); o += '\t';
-    if (cg.empty()) o += '*';
-    for (size_t i = 0; i < cg.size(); ++i) { put_int(o, cg[i] >> 4); o += opch[i]; }
-    o += '\t';
-    o += mate_ref ? mate_ref : "*"; o += '\t';
-    put_int(o, mate_pos); o += '\t';
-    put_int(o, tlen); o += '\t';
-    o += seq.empty() ? "*" : seq; o += '\t';
-    o += qual.empty() ? "*" : qual;
+    R.name = in->name + in->name_off[pair]; R.name_len = (size_t)(in->name_off[pair + 1] - in->name_off[pair]);
+    R.flags = flags; R.mapq = mq;
+    R.rid = ref ? r->rid[aln] : -1;
+    R.pos = c.pos[aln];
+    R.cig_len.clear(); R.cig_op.clear();
+    for (size_t i = 0; i < cg.size(); ++i) { R.cig_len.push_back(cg[i] >> 4); R.cig_op.push_back(opch[i]); }
+    R.mrid = mate_ref ? r->rid[pm] : -1;
+    R.mpos = mate_pos; R.tlen = tlen;
+    R.seq.swap(seq); R.qual.swap(qual);
+    R.n_tags = 0;
     // ---- tags, in the reference's order ----
-    auto tagz = [&](const char* t, const std::string& v) { o += '\t'; o += t; o += ":Z:"; o += v; };
-    auto tagi = [&](const char* t, long long v) { o += '\t'; o += t; o += ":i:"; put_int(o, (int32_t)v); };
+    auto tagz = [&](const char* t, const std::string& v) { R.tag(t, 'Z').z = v; };
+    auto tagi = [&](const char* t, long long v) { R.tag(t, 'i').i = (int32_t)v; };
     tagz("RX", col(in->rawbc, in->rawbc_off, pair));
     tagz("QX", col(in->bcqual, in->bcqual_off, pair));
     if (read1) { tagz("TR", col(in->trim_bases, in->trim_off, pair)); tagz("TQ", col(in->trim_quals, in->trim_off, pair)); }
@@ -178,13 +176,36 @@ void append_bam(Ctx& c, std::string& o, int64_t read, int64_t aln, int64_t prima
         tagz("BX", bc);
         if (r->active_molecule[aln]) { char b[64]; snprintf(b, sizeof b, "%.6f", r->molecule_difference[aln]); tagz("DM", b); }
     }
+}
+
+// one tab-separated line per record with BAM-native values (lh_records_text)
+void emit_text(const Ctx& c, const LhRec& R, std::string& o) {
+    o.append(R.name, R.name_len); o += '\t';
+    put_int(o, R.flags); o += '\t';
+    o += R.rid >= 0 ? c.names[R.rid] : "*"; o += '\t';
+    put_int(o, R.pos); o += '\t';
+    put_int(o, R.mapq); o += '\t';
+    if (R.cig_len.empty()) o += '*';
+    for (size_t i = 0; i < R.cig_len.size(); ++i) { put_int(o, R.cig_len[i]); o += R.cig_op[i]; }
+    o += '\t';
+    o += R.mrid >= 0 ? c.names[R.mrid] : "*"; o += '\t';
+    put_int(o, R.mpos); o += '\t';
+    put_int(o, R.tlen); o += '\t';
+    o += R.seq.empty() ? "*" : R.seq; o += '\t';
+    o += R.qual.empty() ? "*" : R.qual;
+    for (size_t k = 0; k < R.n_tags; ++k) {
+        const LhRecTag& g = R.tags[k];
+        o += '\t'; o += g.tag[0]; o += g.tag[1];
+        if (g.type == 'i') { o += ":i:"; put_int(o, g.i); }
+        else { o += ":Z:"; o += g.z; }
+    }
     o += '\n';
 }
 
 }   // namespace
 
-// the records of a batch as one text block per range of pairs (used as is by bamfile.cpp, joined by lh_records_text)
-int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, std::vector<std::string>& part) {
+int lh_records_visit_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, int* n_threads,
+                      const std::function<void(int)>& begin_thread, const std::function<void(int, const LhRec&)>& sink) {
     if (!res || !in) return lh_set_error_(LH_E_ARG, "lh_records_text: null argument");
     if (res->n_reads != 2 * in->batch.n_pairs) return lh_set_error_(LH_E_ARG, "lh_records_text: result and batch describe different reads");
     Ctx c;
@@ -194,25 +215,26 @@ int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n
     for (int64_t read = 0; read < res->n_reads; ++read)
         if (res->active_idx[read] < 0) return lh_set_error_(LH_E_ARG, "lh_records_text: a read has no active alignment (inference was not run?)");
     // AppendBam's edits stay inside a pair (an alignment, its mate, their splits), so pairs are independent: ranges of pairs
-    // are rendered by several host threads and concatenated in order.
+    // are rendered by several host threads, in order inside a range.
     const int64_t n_pairs = in->batch.n_pairs;
     int nt = (int)std::thread::hardware_concurrency();
     if (const char* e = getenv("LH_HOST_THREADS")) nt = atoi(e);
     if (nt < 1) nt = 1;
     if ((int64_t)nt > (n_pairs + 255) / 256) nt = (int)((n_pairs + 255) / 256);
     if (nt < 1) nt = 1;
-    part.assign((size_t)nt, std::string());
+    if (n_threads) *n_threads = nt;
+    for (int t = 0; t < nt; ++t) begin_thread(t);
     auto work = [&](int t) {
         const int64_t p0 = n_pairs * t / nt, p1 = n_pairs * (t + 1) / nt;
-        std::string& o = part[(size_t)t];
-        o.reserve((size_t)(p1 - p0) * 1300);
+        LhRec R;
         int32_t set = 0;
         for (int64_t read = 2 * p0; read < 2 * p1; ++read) {   // DoDumpToBam: reads in read_id order, the active alignment then its split
             while (set + 1 < in->n_sets && (read >> 1) >= in->batch.bc_pair_off[set + 1]) ++set;
             const bool attach_bx = in->set_complete[set] != 0;   // Data.attach_bx = WorkUnit.unique_barcode (lariat.go:493,546)
             const int64_t a = res->active_idx[read];
-            append_bam(c, o, read, a, a, attach_bx);
-            if (res->split_idx[read] >= 0) append_bam(c, o, read, res->split_idx[read], a, attach_bx);
+            append_bam(c, R, read, a, a, attach_bx);
+            sink(t, R);
+            if (res->split_idx[read] >= 0) { append_bam(c, R, read, res->split_idx[read], a, attach_bx); sink(t, R); }
         }
     };
     std::vector<std::thread> th;
@@ -220,6 +242,15 @@ int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n
     work(0);
     for (auto& t : th) t.join();
     return LH_OK;
+}
+
+// the records of a batch as one text block per range of pairs (joined by lh_records_text)
+int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, std::vector<std::string>& part) {
+    Ctx names_only;
+    names_only.names = contig_names;
+    return lh_records_visit_(res, in, n_contigs, contig_names, nullptr,
+                             [&](int t) { if ((size_t)t >= part.size()) part.resize((size_t)t + 1); part[(size_t)t].reserve(1 << 20); },
+                             [&](int t, const LhRec& R) { emit_text(names_only, R, part[(size_t)t]); });
 }
 
 extern "C" int lh_records_text(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, char** text, int64_t* text_len) {

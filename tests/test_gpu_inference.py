@@ -156,7 +156,8 @@ def test_fastq_ingest_to_alignment(lib, oracle, tmp_path):
 
 
 def test_fastq_to_bam_records(lib, oracle, tmp_path):
-    """N2 -> K1..K8 -> N1: the BAM record content produced from the HIP result equals the one produced from the oracle's"""
+    """N2 -> K1..K8 -> N1: the BAM record content the product derives from the HIP result equals what the Python restatement of
+    AppendBam (oracle/bam_oracle.py) derives from the ORACLE's result: independent implementation on independent input"""
     from lariat_amd import synth
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
@@ -166,9 +167,16 @@ def test_fastq_to_bam_records(lib, oracle, tmp_path):
     p.write_text(synth.to_fastq9(rs, trim_prefix=7))
     ctx = idx.context(rs.n_pairs)
     n = 0
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(helpers.ROOT, "oracle"))
+    import bam_oracle   # the independent restatement of bamwriter.go:286-568 (flags, the unmapping rule's side effects, TLEN, tags)
+    cols_wanted = ("name", "rgid", "qual1", "qual2", "trim_bases", "trim_quals", "bc", "rawbc", "bcqual", "si", "siqual")
     for b in lib.ingest(str(p), trim=7, max_pairs=120):
-        got = lib.records_text(ctx.align_barcodes(b), b, names)
-        want = lib.records_text(oidx.align_barcodes(b, threads=8), b, names)
+        got = lib.records_text(ctx.align_barcodes(b), b, names)                     # product records from the HIP result
+        ores = oidx.align_barcodes(b, threads=8)
+        cols = {c: b.column(c) for c in cols_wanted}
+        want = bam_oracle.records_text(ores, cols, b.seq, b.seq_off, b.bc_pair_off, b.set_complete, names)   # oracle records from the oracle's result
         assert got == want
         n += len(got.splitlines())
     assert n >= 2 * rs.n_pairs
