@@ -158,3 +158,33 @@ def test_emu_kmer_tree_levels(emu, oracle):
         assert res.counters["n_ext"] < ref.counters["n_ext"]
         used[levels] = sum(res.counters["n_ktree_p%d" % k] for k in (1, 2, 3))
     assert used[-1] == 0 < used[2] < used[7] < used[11]
+
+
+def test_emu_two_lanes(emu, oracle):
+    """lh_context_opts.lanes = 2: the batch is cut at a barcode boundary, the two parts run side by side from two host threads on
+    two pipelines, the merged result equals the oracle's for the whole batch (and a one-barcode batch stays on the first lane)"""
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=5, pairs=24, junk=0.05, seed=17)
+    rfa = np.array([1, 1, 0, 1, 1], dtype=np.uint8)
+    b = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed, bc_do_rfa=rfa)
+    ctx = idx.context(rs.n_pairs, lanes=2)
+    ref = oidx.align_barcodes(b)
+    res = ctx.align_barcodes(b)
+    helpers.assert_same_result(res, ref, inference=True)
+    for k in ("n_sa", "glob_cells", "n_rescue", "rescue_cells"):
+        assert res.counters[k] == ref.counters[k], k
+    # slots: two different batches resident, selected in turn
+    one = rs.slice_barcodes(1, 2)
+    b1 = helpers.batch_of(one)
+    ctx.upload_slot(3, b1)
+    ctx.upload_slot(1, b)
+    ctx.select(3)
+    ctx.align_resident(emu.opts())
+    helpers.assert_same_result(ctx.download(), oidx.align_barcodes(b1), inference=True)
+    ctx.select(1)
+    ctx.align_resident(emu.opts())
+    helpers.assert_same_result(ctx.download(), ref, inference=True)
+    with pytest.raises(capi.LhError):
+        ctx.stage_dump()

@@ -203,3 +203,16 @@ def test_simulated_accounting_on_hip_result(lib, oracle, tmp_path):
         to += lib.records_text(ro, b, names).splitlines()
     assert sg.as_dict() == so.as_dict() and sg.total > 0
     assert simulated.check_report(tg, mate_aware=True) == simulated.check_report(to, mate_aware=True)
+
+
+def test_two_lanes_equal_one(lib, oracle, small):
+    """lh_context_opts.lanes = 2 on the device: two halves of a batch side by side from two host threads; merged result == oracle"""
+    names, contigs, oidx, idx = small
+    rs = helpers.small_reads(names, contigs, n_barcodes=12, pairs=70, seed=37, junk=0.04)
+    b = helpers.batch_of(rs)
+    ref = oidx.align_barcodes(b, threads=8)
+    ctx = idx.context(rs.n_pairs, lanes=2)
+    for _ in range(2):
+        helpers.assert_same_result(ctx.align_barcodes(b), ref, inference=True)
+    one = helpers.batch_of(rs.slice_barcodes(4, 5))   # a single barcode cannot be cut: first lane only
+    helpers.assert_same_result(ctx.align_barcodes(one), oidx.align_barcodes(one, threads=2), inference=True)
