@@ -303,6 +303,10 @@ int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, 
  * occurrence table reaches that suffix's row.  A size-independent property for indexes the oracle cannot hold. */
 int lh_diag_index_check(const lh_index* idx, uint64_t stride, uint64_t* n_checked, uint64_t* n_bad_order, uint64_t* n_bad_lf);
 
+/* diagnostics: order-sensitive checksums of the resident LCP array and k-mer tree table (0 when absent) — the tables
+ * lh_index_build_device derives from its sort keys must equal the ones derived from the text for a loaded index */
+int lh_diag_index_digest(const lh_index* idx, uint64_t* lcp_digest, uint64_t* ktree_digest, int32_t* ktree_levels);
+
 /* Workload generators for bench.py and the tests (no genome but PhiX exists offline).  Host-only, threaded.
  * lh_synth_genome: iid ACGT with GC fraction `gc` as a .pac image (l_pac/4+1 bytes, MSB-first 2-bit), reproducible from `seed`
  * whatever the thread count.  lh_synth_reads: barcode-sorted FR read pairs under the linked-read model — per barcode

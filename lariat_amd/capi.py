@@ -553,6 +553,13 @@ class Index:
         self.lib.check(self.lib.L.lh_diag_index_check(self.h, int(stride), C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def digest(self):
+        """(lcp checksum, k-mer tree checksum, tree levels) — lh_diag_index_digest"""
+        a, b, l = C.c_uint64(), C.c_uint64(), C.c_int32()
+        self.lib.L.lh_diag_index_digest.argtypes = [C.c_void_p, c_u64p, c_u64p, c_i32p]
+        self.lib.check(self.lib.L.lh_diag_index_digest(self.h, C.byref(a), C.byref(b), C.byref(l)))
+        return a.value, b.value, l.value
+
     def set_holes(self, holes):
         n = len(holes)
         ho = np.array([h[0] for h in holes], dtype=np.int64)
@@ -759,5 +766,5 @@ EXPORTED_SYMBOLS = [
     "lh_records_text", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read", "lh_diag_go_rand",
-    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes",
+    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest",
 ]

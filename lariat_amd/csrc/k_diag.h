@@ -72,3 +72,13 @@ __global__ void __launch_bounds__(256) k_diag_index_check(DIndex ix, u64 stride,
     if (bad_order) atomicAdd(&out[1], bad_order);
     if (bad_lf) atomicAdd(&out[2], bad_lf);
 }
+
+// order-sensitive checksums of the LCP array and of the k-mer tree table (tests: the builder's key-derived tables against the
+// generic text-derived ones)
+__global__ void __launch_bounds__(256) k_diag_digest(const uint8_t* __restrict__ lcp, u64 n_lcp, const u64* __restrict__ tree, u64 n_tree_words, unsigned long long* __restrict__ out) {
+    unsigned long long a = 0, b = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_lcp; i += (u64)gridDim.x * blockDim.x) a += (i + 1) * (u64)lcp[i];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_tree_words; i += (u64)gridDim.x * blockDim.x) b += (i * 0x9E3779B97F4A7C15ull + 1) * tree[i];
+    if (a) atomicAdd(&out[0], a);
+    if (b) atomicAdd(&out[1], b);
+}

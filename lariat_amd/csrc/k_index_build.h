@@ -174,6 +174,57 @@ __global__ void __launch_bounds__(256) k_ib_rep_bits(const u64* __restrict__ key
     if (mine) atomicAdd(n_rep, mine);
 }
 
+// LCP array and k-mer tree bounds from the sorted chunk (sequential reads of the keys; lh_index.inc has the generic versions that
+// read the text through the suffix array, for indexes loaded from files).  lcp[row] = symbols shared with the previous row's suffix
+// (capped at 255): from the 32-symbol keys, by direct comparison when they are equal.  raw[2e], raw[2e+1] = first row / last row + 1
+// of the group of rows whose suffix starts with the string of tree entry e (level L at (4^L - 4) / 3, code with symbol t at bits 2t).
+__device__ __forceinline__ uint32_t ib_code_lsb(u64 key) {   // the first 16 symbols of an MSB-first key, symbol t at bits 2t..2t+1
+    u64 r = __brevll(key);
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    return (uint32_t)r;
+}
+__global__ void __launch_bounds__(256) k_ib_lcp_ktree(const u64* __restrict__ W, u64 n, const u64* __restrict__ keys, const u64* __restrict__ vals, u64 cnt, u64 row0,
+                                                      const u64* __restrict__ sa, uint8_t* __restrict__ lcp, int levels, u64* __restrict__ raw) {
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += (u64)gridDim.x * blockDim.x) {
+        const u64 row = row0 + j, v = vals[j], k = keys[j];
+        u64 vp = 0, kp = 0;
+        bool have = true;
+        if (j > 0) { vp = vals[j - 1]; kp = keys[j - 1]; }
+        else if (row0 > 1) { vp = sa[row0 - 1]; kp = ib_key(W, vp); }
+        else have = false;
+        u64 la = n - v, lb = have ? n - vp : 0, lim = la < lb ? la : lb;
+        u64 l = 0;
+        if (have) {
+            u64 x = k ^ kp;
+            l = x ? (u64)(__clzll((long long)x) >> 1) : 32;
+            if (l >= 32)
+                for (; l < 256 && l < lim; l += 32) {
+                    u64 wa = ib_key(W, v + l), wb = ib_key(W, vp + l);
+                    if (wa != wb) { l += (u64)(__clzll((long long)(wa ^ wb)) >> 1); break; }
+                }
+            l = l < lim ? l : lim;
+        }
+        if (lcp) lcp[row] = (uint8_t)(l > 255 ? 255 : l);
+        if (raw) {
+            const uint32_t c = ib_code_lsb(k), cp = ib_code_lsb(kp);
+            for (int L = (int)(l < 32 ? l : 32) + 1; L <= levels; ++L) {
+                const uint32_t m = (1u << (2 * L)) - 1u;
+                const u64 off = ((1ull << (2 * L)) - 4) / 3;
+                if ((u64)L <= la) raw[2 * (off + (c & m))] = row;
+                if (have && (u64)L <= lb) raw[2 * (off + (cp & m)) + 1] = row;
+            }
+        }
+    }
+}
+// the last row's groups end behind the last row
+__global__ void k_ib_ktree_close(const u64* __restrict__ W, u64 n, const u64* __restrict__ sa, int levels, u64* __restrict__ raw) {
+    if (threadIdx.x || blockIdx.x) return;
+    const u64 v = sa[n], la = n - v;
+    const uint32_t c = ib_code_lsb(ib_key(W, v));
+    for (int L = 1; L <= levels; ++L)
+        if ((u64)L <= la) raw[2 * ((((1ull << (2 * L)) - 4) / 3) + (c & ((1u << (2 * L)) - 1u))) + 1] = n + 1;
+}
+
 // chunk -> its rows of the full suffix array (row 0 is the sentinel's); the row of suffix 0 is `primary`
 __global__ void __launch_bounds__(256) k_ib_write_sa(const u64* __restrict__ vals, u64 cnt, u64 row0, u64* __restrict__ sa, unsigned long long* __restrict__ primary) {
     for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += (u64)gridDim.x * blockDim.x) {

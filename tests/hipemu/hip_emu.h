@@ -129,6 +129,7 @@ static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long l
 static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
 static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+static inline unsigned long long __brevll(unsigned long long x);
 static inline unsigned __brev(unsigned x) {
     x = (x >> 16) | (x << 16);
     x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
@@ -136,6 +137,7 @@ static inline unsigned __brev(unsigned x) {
     x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
     return ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
 }
+static inline unsigned long long __brevll(unsigned long long x) { return ((unsigned long long)__brev((unsigned)x) << 32) | __brev((unsigned)(x >> 32)); }
 template <class T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 template <class T> static inline T atomicMax(T* p, T v) {
     T o = __atomic_load_n(p, __ATOMIC_RELAXED);

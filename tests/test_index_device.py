@@ -35,6 +35,9 @@ def check_against(lib, oidx, names, contigs, **index_opts):
     ctg = [(names[i], len(contigs[i]), int(offs[i])) for i in range(len(names))]
     idx = lib.index_build_device(pac, l_pac, ctg, **index_opts)
     want = oidx.arrays()
+    if index_opts.get("sa_intv", 0) in (0, 1):   # LCP array and k-mer tree: from the builder's sort keys == from the text of an uploaded index
+        up = lib.index_from_arrays(want, **{k: v for k, v in index_opts.items() if k != "build_chunk_log2"})
+        assert idx.digest() == up.digest() and idx.digest()[2] > 0 and idx.digest()[0] > 0
     got = idx.export(sa_intv=32)
     assert got["primary"] == want["primary"]
     assert list(got["L2"]) == list(want["L2"])
