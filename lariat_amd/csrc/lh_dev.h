@@ -114,6 +114,8 @@ struct DIndex {
     const uint8_t* pac;      // 2-bit forward reference, MSB first
     const i64* contig_off;   // [n_contigs]
     const int32_t* contig_len;
+    const int32_t* rid_bins; // contig holding forward position (b << rid_bin_shift), b = 0 .. l_pac >> shift: bns_pos2rid in one read + a short walk
+    int32_t rid_bin_shift;
     u64 primary, L2[5], seq_len;
     i64 l_pac;
     int32_t sa_intv, n_contigs;
@@ -372,6 +374,11 @@ struct LaneTgt {
 __device__ __forceinline__ int dev_pos2rid(const DIndex& ix, i64 pos_f) {
     int left, mid, right;
     if (pos_f >= ix.l_pac) return -1;
+    if (ix.rid_bins) {   // the contig of the bin's first base, then forward: the same contig bns_pos2rid's binary search finds
+        int rid = ix.rid_bins[pos_f >> ix.rid_bin_shift];
+        while (rid + 1 < ix.n_contigs && pos_f >= ix.contig_off[rid + 1]) ++rid;
+        return rid;
+    }
     left = 0; mid = 0; right = ix.n_contigs;
     while (left < right) {
         mid = (left + right) >> 1;
