@@ -73,10 +73,18 @@ __global__ void __launch_bounds__(256) k_scan_final(int n, const int32_t* __rest
     if (blockIdx.x == 0 && t == 0) out[n] = tile_sum[n_tiles];
 }
 
+// owner[g] = the read seed slot g belongs to (one lane per read writes its few slots): spares K2 a 21-step binary search per seed
+__global__ void __launch_bounds__(256) k_seed_owner(int n_reads, const i64* __restrict__ seed_off, i64 pool_cap, int32_t* __restrict__ owner) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+        i64 e = seed_off[r + 1] < pool_cap ? seed_off[r + 1] : pool_cap;
+        for (i64 g = seed_off[r]; g < e; ++g) owner[g] = r;
+    }
+}
+
 // K2.  one lane per seed; grid-stride over the pool.
 __global__ void __launch_bounds__(256) k_seed(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seed_off, i64 pool_cap,
                                               const DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv, DSeed* __restrict__ seeds,
-                                              int32_t* __restrict__ s_rid, DCounters* __restrict__ ctr) {
+                                              int32_t* __restrict__ s_rid, DCounters* __restrict__ ctr, const int32_t* __restrict__ owner) {
     i64 total = seed_off[n_reads];
     if (total > pool_cap) total = pool_cap;
     i64 stride = (i64)gridDim.x * blockDim.x;
@@ -85,9 +93,7 @@ __global__ void __launch_bounds__(256) k_seed(DIndex ix, DOpts o, int n_reads, c
         i64 g = rd * stride + (i64)blockIdx.x * blockDim.x + threadIdx.x;
         int nlf = 0, nsa = 0;
         if (g < total) {
-            int lo = 0, hi = n_reads;   // largest r with seed_off[r] <= g
-            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (seed_off[mid] <= g) lo = mid; else hi = mid; }
-            int r = lo;
+            int r = owner[g];
             i64 u = g - seed_off[r];
             const DIntv* iv = intv + (size_t)r * LH_MAX_INTV;
             int n = n_intv[r];
