@@ -162,7 +162,7 @@ def main():
                        "lanes_per_context": a.lanes,
                        "parallelism": "barcode-range shards, index replicated, no collective"},
             "roofline": roofline(lib, idx, avg, cnt, first[0], local_rank, a),
-            "kernel_ms_note": "HIP-event durations of the first lane's launches" + (" (each launch = half a batch; the other half runs beside it)" if a.lanes == 2 else ""),
+            "kernel_ms_note": "HIP-event durations of the first lane's launches" + ((" (each launch = 1/%d of a batch; the other parts run beside it)" % a.lanes if a.lanes > 1 else "")),
             "kernel_ms": {k: round(v, 3) for k, v in avg.items()},
             "work_per_step": cnt,
             "setup_s": {"genome": round(t_genome, 2), "index_build_device": round(t_index, 2), "reads_synth+upload(all steps)": round(t_reads_upload, 2)},
@@ -190,7 +190,7 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
     recompute from profiles/.  reference_work_equiv is the reference's bookkeeping (64 B x ALL its bwt_extend calls) priced
     at this kernel's time: how much of the reference's traffic the filters make unnecessary, not a bandwidth."""
     dom = max(avg, key=avg.get)
-    share = 0.5 if a.lanes == 2 else 1.0   # a launch of the timed lane covers this share of the step's pairs (uniform barcodes: the cut is at the middle)
+    share = 1.0 / a.lanes   # a launch of the timed lane covers this share of the step's pairs (uniform barcodes: the cut is at the middle)
     k1 = {"k_smem4": ("k_smem4_t<3>", "n_ext_exec_p1", "n_ktree_p1"), "k_smem4_p2": ("k_smem4_t<4>", "n_ext_exec_p2", "n_ktree_p2"),
           "k_smem4_p3": ("k_smem4_t<2>", "n_ext_exec_p3", "n_ktree_p3")}
     n_bases = int(reads["seq_off"][-1])
@@ -232,7 +232,7 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
     # the whole K1 stage in the reference's bookkeeping (informational)
     k1_ms = sum(avg.get(k, 0.0) for k in k1)
     if k1_ms > 0:
-        r["K1_stage"] = {"ms_first_lane": round(k1_ms, 3), "counts_are_for": "the whole step (both lanes)", "bwt_extend_reference_or_accounted": cnt["n_ext"],
+        r["K1_stage"] = {"ms_first_lane": round(k1_ms, 3), "counts_are_for": "the whole step (all lanes)", "bwt_extend_reference_or_accounted": cnt["n_ext"],
                          "bwt_extend_executed": cnt["n_ext_exec_p1"] + cnt["n_ext_exec_p2"] + cnt["n_ext_exec_p3"],
                          "executed_GBps": round(share * 64.0 * (cnt["n_ext_exec_p1"] + cnt["n_ext_exec_p2"] + cnt["n_ext_exec_p3"]) / (k1_ms * 1e-3) / 1e9, 1),
                          "reference_work_equiv_GBps": round(share * 64.0 * cnt["n_ext"] / (k1_ms * 1e-3) / 1e9, 1)}

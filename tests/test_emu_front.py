@@ -169,10 +169,11 @@ def test_emu_two_lanes(emu, oracle):
     rs = helpers.small_reads(names, contigs, n_barcodes=5, pairs=24, junk=0.05, seed=17)
     rfa = np.array([1, 1, 0, 1, 1], dtype=np.uint8)
     b = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed, bc_do_rfa=rfa)
-    ctx = idx.context(rs.n_pairs, lanes=2)
     ref = oidx.align_barcodes(b)
-    res = ctx.align_barcodes(b)
-    helpers.assert_same_result(res, ref, inference=True)
+    for lanes in (3, 2):
+        ctx = idx.context(rs.n_pairs, lanes=lanes)
+        res = ctx.align_barcodes(b)
+        helpers.assert_same_result(res, ref, inference=True)
     for k in ("n_sa", "glob_cells", "n_rescue", "rescue_cells"):
         assert res.counters[k] == ref.counters[k], k
     # slots: two different batches resident, selected in turn
