@@ -189,3 +189,27 @@ def test_emu_two_lanes(emu, oracle):
     helpers.assert_same_result(ctx.download(), ref, inference=True)
     with pytest.raises(capi.LhError):
         ctx.stage_dump()
+
+
+def _check_get_seq(lib, oracle):
+    """GoBwaReference.GetSeq (gobwa.go:50-80) through lh_get_seq: the reference's own vector (gobwa_test.go:13-28 reads PhiX
+    210..280), then windows that cross contig ends (bns_fetch_seq clips to the contig of the midpoint) and reversed ones"""
+    idx = lib.index_load(helpers.PHIX); oidx = oracle.index_load(helpers.PHIX)
+    assert idx.get_seq(0, 210, 280, False).decode() == helpers.PHIX_READ_A
+    assert idx.get_seq(0, 100, 160, True) == oidx.get_seq(0, 100, 160, True)
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rng = np.random.default_rng(5)
+    for rid in range(len(names)):
+        n = len(contigs[rid])
+        for _ in range(40):
+            s = int(rng.integers(-50, n)); e = s + int(rng.integers(0, 300))
+            if s < 0 and rng.random() < 0.5: s = 0
+            for rev in (False, True):
+                if s < 0: continue   # GetSeq is never called with a negative start (lariat.go:640-647 clamps)
+                assert idx.get_seq(rid, s, e, rev) == oidx.get_seq(rid, s, e, rev), (rid, s, e, rev)
+
+
+def test_emu_get_seq(emu, oracle):
+    _check_get_seq(emu, oracle)

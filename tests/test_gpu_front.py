@@ -46,3 +46,9 @@ def test_occ_superblocks_and_sparse_sa(lib, oracle):
     rs = helpers.small_reads(names, contigs, n_barcodes=8, pairs=60, junk=0.05, seed=11)
     b = helpers.batch_of(rs)
     helpers.assert_same_dump(idx.context(rs.n_pairs).stage_dump(b), oidx.stage_dump(b), helpers.DUMP_FRONT)
+
+
+def test_get_seq(lib, oracle):
+    """lh_get_seq == GoBwaReference.GetSeq (gobwa.go:50-80): reference vector + windows over contig ends, both strands"""
+    from test_emu_front import _check_get_seq
+    _check_get_seq(lib, oracle)
