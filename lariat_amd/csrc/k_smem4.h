@@ -70,6 +70,8 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_P3_JUMP2 25
 #define S4_TRI_LCP 26    // the sweep of a forward list whose longest entry is unique, decided from the LCP array (see BWD_ROW_BODY)
 #define S4_TRI_LCP2 27
+#define S4_FJUMP 28      // forward extension: the first levels of the walk in one read of the k-mer tree (see START_SMEM1)
+#define S4_FJUMP2 29
 #define LH_KMER 12
 
 #ifndef LH_SLOW_BATCH
@@ -175,27 +177,53 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         }                                                                                                    \
     }
 #define FWD_PUSH_OK() ((bword & bmask) == bmask)
+    // wkey for the LH_BLOOM_K bases that end at read position p_ (positions before the read count as non-bases); last_ = the last
+    // non-base at or before p_ (p_ - LH_BLOOM_K if there is none in the window)
+#define WKEY_AT(p_, last_)                                                                                   \
+    {                                                                                                        \
+        uint32_t w0_, w1_, w2_;                                                                              \
+        Q8((p_) - 18, w0_) Q8((p_) - 10, w1_) Q8((p_) - 2, w2_)                                              \
+        w2_ &= 0xfffu;                                                                                       \
+        uint32_t n0_ = w0_ & 0x44444444u, n1_ = w1_ & 0x44444444u, n2_ = w2_ & 0x444u;                       \
+        last_ = n2_ ? (p_) - 2 + ((31 - __clz((int)n2_)) >> 2) : n1_ ? (p_) - 10 + ((31 - __clz((int)n1_)) >> 2) \
+              : n0_ ? (p_) - 18 + ((31 - __clz((int)n0_)) >> 2) : (p_) - 19;                                 \
+        uint32_t t0_ = w0_ & 0x33333333u, t1_ = w1_ & 0x33333333u, t2_ = w2_ & 0x333u;                       \
+        t0_ = (t0_ | t0_ >> 2) & 0x0f0f0f0fu; t0_ = (t0_ | t0_ >> 4) & 0x00ff00ffu; t0_ = (t0_ | t0_ >> 8) & 0xffffu; \
+        t1_ = (t1_ | t1_ >> 2) & 0x0f0f0f0fu; t1_ = (t1_ | t1_ >> 4) & 0x00ff00ffu; t1_ = (t1_ | t1_ >> 8) & 0xffffu; \
+        t2_ = (t2_ | t2_ >> 2) & 0x0f0fu; t2_ = (t2_ | t2_ >> 4) & 0x3fu;                                    \
+        wkey = (u64)t0_ | (u64)t1_ << 16 | (u64)t2_ << 32;                                                   \
+    }
+    // FORWARD JUMP.  While the walk's interval ends before filt_from nothing can be pushed to the forward list (the window of the
+    // sweep filter is not all bases: the start of the read, usually), so the steps up to level J = min(tree depth, filt_from - x,
+    // valid bases from x) only matter through the interval they arrive at: the tree's entry for the J bases, one read.  Sizes do
+    // not grow along the walk, so "size at level J >= min_intv" is bwt_smem1a's loop condition for every skipped step; otherwise
+    // the walk ends inside the skipped levels and is made step by step.  (A size of 1 reached inside them: the unique run that
+    // would have started there finds the same end from level J.)
 #define START_SMEM1()                                                                                        \
     {                                                                                                        \
         int s_ = QB(x);                                                                                      \
         c0 = ix.L2[s_] + 1; c2 = ix.L2[s_ + 1] - ix.L2[s_]; c1 = ix.L2[3 - s_] + 1; cinfo = x + 1;          \
         ncurr = 0; i = x + 1; curA = 1; fcode = (uint32_t)s_; tri = 0; tri_failed = 0;                       \
-        if (filt) {   /* the LH_BLOOM_K bases that end at x (positions before the read count as non-bases) */ \
-            uint32_t w0_, w1_, w2_;                                                                          \
-            Q8(x - 18, w0_) Q8(x - 10, w1_) Q8(x - 2, w2_)                                                   \
-            w2_ &= 0xfffu;                                                                                   \
-            uint32_t n0_ = w0_ & 0x44444444u, n1_ = w1_ & 0x44444444u, n2_ = w2_ & 0x444u;                   \
-            int last_ = n2_ ? x - 2 + ((31 - __clz((int)n2_)) >> 2) : n1_ ? x - 10 + ((31 - __clz((int)n1_)) >> 2) \
-                      : n0_ ? x - 18 + ((31 - __clz((int)n0_)) >> 2) : x - 19;   /* last non-base at or before x */ \
-            filt_from = last_ + 1 + LH_BLOOM_K;                                                              \
-            uint32_t t0_ = w0_ & 0x33333333u, t1_ = w1_ & 0x33333333u, t2_ = w2_ & 0x333u;                   \
-            t0_ = (t0_ | t0_ >> 2) & 0x0f0f0f0fu; t0_ = (t0_ | t0_ >> 4) & 0x00ff00ffu; t0_ = (t0_ | t0_ >> 8) & 0xffffu; \
-            t1_ = (t1_ | t1_ >> 2) & 0x0f0f0f0fu; t1_ = (t1_ | t1_ >> 4) & 0x00ff00ffu; t1_ = (t1_ | t1_ >> 8) & 0xffffu; \
-            t2_ = (t2_ | t2_ >> 2) & 0x0f0fu; t2_ = (t2_ | t2_ >> 4) & 0x3fu;                                \
-            wkey = (u64)t0_ | (u64)t1_ << 16 | (u64)t2_ << 32;                                               \
+        if (filt) { int last_; WKEY_AT(x, last_) filt_from = last_ + 1 + LH_BLOOM_K; }                       \
+        int J_ = 0;                                                                                          \
+        if (filt && ktl > 1) {                                                                               \
+            uint32_t a_, b_;                                                                                 \
+            Q8(x, a_) Q8(x + 8, b_)                                                                          \
+            a_ &= 0x44444444u; b_ &= 0x44444444u;                                                            \
+            int v_ = a_ ? (__ffs((int)a_) - 1) >> 2 : 8 + (b_ ? (__ffs((int)b_) - 1) >> 2 : 8);   /* valid bases from x on */ \
+            J_ = ktl < v_ ? ktl : v_;                                                                        \
+            if (filt_from - x < J_) J_ = filt_from - x;                                                      \
         }                                                                                                    \
-        BLOOM_ISSUE()                                                                                        \
-        FWD_ADVANCE()                                                                                        \
+        if (J_ >= 2) {                                                                                       \
+            uint32_t cd_;                                                                                    \
+            CODE16(x, cd_)                                                                                   \
+            cd_ &= (1u << (2 * J_)) - 1u;                                                                    \
+            ld64 = (((1ull << (2 * J_)) - 4) / 3) + cd_; j = J_; rcode = cd_;                                \
+            st = S4_FJUMP;                                                                                   \
+        } else {                                                                                             \
+            BLOOM_ISSUE()                                                                                    \
+            FWD_ADVANCE()                                                                                    \
+        }                                                                                                    \
     }
     // pass 3: next base of the forward-only walk
 #define P3_ADVANCE()                                                                                         \
@@ -325,6 +353,16 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 ce = pe_pack(c0, c1, c2, cinfo);
                 ncurr++;
                 st = S4_BWD_INIT;
+            }
+            else if (DO12 && st == S4_FJUMP) { pn = kt[ld64]; st = S4_FJUMP2; }
+            else if (DO12 && st == S4_FJUMP2) {
+                if (PE_X2(pn) >= (u64)min_intv) {   // as if the bwt_extend steps up to level j had been made
+                    c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn);
+                    n_ext_total += j - 1; n_ktree_total++;
+                    i = x + j; cinfo = i; fcode = rcode;
+                    if (runs && c2 == 1 && min_intv == 1) st = S4_FRUN_INIT;
+                    else { int last_; WKEY_AT(i - 1, last_) (void)last_; BLOOM_ISSUE() FWD_ADVANCE() }
+                } else { BLOOM_ISSUE() FWD_ADVANCE() }   // the walk ends inside the skipped levels: step by step from level 1
             }
             else if (DO3 && st == S4_P3_JUMP) { pn = kt ? kt[ld64] : ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
             else if (DO3 && st == S4_P3_JUMP2) {   // as if the bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
@@ -474,23 +512,53 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             if (lane == 0) { atomicAdd(&lh_dbg[b_], ns_); atomicAdd(&lh_dbg[b_ + 1], na_); }
         }
 #endif
-        if (st >= S4_REQ_FWD && st <= S4_REQ_P3) {
-            const int lnew = st == S4_REQ_BWD ? cinfo - i : i + 1 - x;   // bases of the match this bwt_extend yields: [i, cinfo) or [x, i]
-            if (lnew <= ktl) {
-                uint32_t code;
-                if (st == S4_REQ_BWD) code = rcode & ((1u << (2 * lnew)) - 1u);
-                else { fcode |= (uint32_t)(3 - ec) << (2 * (lnew - 1)); code = fcode; }   // forward steps complement the base (ec = 3 - base)
-                PEnt e = kt[(((1ull << (2 * lnew)) - 4) / 3) + code];
-                ok.x0 = PE_X0(e); ok.x1 = PE_X1(e); ok.x2 = PE_X2(e);
-                n_ktree_total++;
-            } else {
-                DIntv a;
-                a.x0 = c0; a.x1 = c1; a.x2 = c2; a.info = 0;
-                ok = dev_extend_c(ix, a, ec, st == S4_REQ_BWD);
-                n_exec_total++;
-            }
-            n_ext_total++;
+        // Both kinds of lanes ISSUE their reads before either kind uses them: as an if / else the tree lanes' read would have to land
+        // before the occurrence records of the other lanes are even requested (two memory latencies per turn instead of one).
+        const bool req = st >= S4_REQ_FWD && st <= S4_REQ_P3;
+        const int lnew = st == S4_REQ_BWD ? cinfo - i : i + 1 - x;   // bases of the match this bwt_extend yields: [i, cinfo) or [x, i]
+        const bool by_tree = req && lnew <= ktl, by_occ = req && !by_tree;
+        PEnt te; te.lo = te.hi = 0;
+        uint4 hk = {0, 0, 0, 0}, dk = hk, hl = hk, dl = hk;
+        u64 k2 = 0, l2 = 0;
+        const u64 xa = st == S4_REQ_BWD ? c0 : c1;   // x[!is_back]
+        if (by_tree) {
+            uint32_t code;
+            if (st == S4_REQ_BWD) code = rcode & ((1u << (2 * lnew)) - 1u);
+            else { fcode |= (uint32_t)(3 - ec) << (2 * (lnew - 1)); code = fcode; }   // forward steps complement the base (ec = 3 - base)
+            te = kt[(((1ull << (2 * lnew)) - 4) / 3) + code];
         }
+        if (by_occ) {   // dev_2occ4(xa - 1, xa - 1 + c2): the records of the interval's two ends (one read if they share it)
+            const u64 k = xa - 1, l = xa - 1 + c2;
+            l2 = l - (l >= ix.primary);
+            const uint4* pl = ix.occ + ((l2 >> 6) << 1);
+            hl = pl[0]; dl = pl[1];
+            if (k != (u64)-1) {
+                k2 = k - (k >= ix.primary);
+                hk = hl; dk = dl;
+                if ((k2 >> 6) != (l2 >> 6)) { const uint4* pk = ix.occ + ((k2 >> 6) << 1); hk = pk[0]; dk = pk[1]; }
+            }
+        }
+        if (by_tree) {
+            ok.x0 = PE_X0(te); ok.x1 = PE_X1(te); ok.x2 = PE_X2(te);
+            n_ktree_total++;
+        }
+        if (by_occ) {   // dev_extend_c on the records read above
+            u64 tk[4], tl[4];
+            if (xa - 1 == (u64)-1) { tk[0] = tk[1] = tk[2] = tk[3] = 0; }
+            else dev_occ4_rec(ix, k2, hk, dk, tk);
+            dev_occ4_rec(ix, l2, hl, dl, tl);
+            const int isb = st == S4_REQ_BWD;
+            const u64 xb = isb ? c1 : c0;
+            u64 s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+            u64 acc = xb + ((xa <= ix.primary && xa + c2 - 1 >= ix.primary) ? 1 : 0);
+            u64 o3 = acc, o2 = o3 + s3, o1 = o2 + s2, o0 = o1 + s1;
+            u64 na = ec == 0 ? ix.L2[0] + 1 + tk[0] : ec == 1 ? ix.L2[1] + 1 + tk[1] : ec == 2 ? ix.L2[2] + 1 + tk[2] : ix.L2[3] + 1 + tk[3];
+            u64 nb = ec == 0 ? o0 : ec == 1 ? o1 : ec == 2 ? o2 : o3;
+            ok.x2 = ec == 0 ? s0 : ec == 1 ? s1 : ec == 2 ? s2 : s3;
+            if (isb) { ok.x0 = na; ok.x1 = nb; } else { ok.x1 = na; ok.x0 = nb; }
+            n_exec_total++;
+        }
+        if (req) n_ext_total++;
         // ---- E. bookkeeping of the loop the lane is in, and its next request ----
         if (DO12 && st == S4_REQ_FWD) {
             if (ok.x2 != c2) {
@@ -564,6 +632,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #undef CURR
 #undef PREV
 #undef START_SMEM1
+#undef WKEY_AT
 #undef BLOOM_ISSUE
 #undef FWD_PUSH_OK
 #undef FWD_ADVANCE

@@ -26,12 +26,13 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--smem-grid", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0, help="lh_opts.flags (e.g. 32 = K4 classes one after the other)")
+    ap.add_argument("--lib", default=None, help="a development build of the library (e.g. with -DLH_SMEM_TURNS)")
     a = ap.parse_args()
     info = {"genome_mb": a.genome_mb, "nproc": os.cpu_count()}
     for line in open("/proc/meminfo"):
         if line.startswith(("MemTotal", "MemAvailable")):
             info[line.split(":")[0]] = line.split()[1] + " kB"
-    lib = capi.load_library()
+    lib = capi.load_library(a.lib)
     t = time.time()
     ctg = workload.hg38_like_contigs(int(a.genome_mb * 1e6))
     l_pac = sum(c[1] for c in ctg)
