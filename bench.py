@@ -34,10 +34,10 @@ HBM_PEAK_GBPS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome-mb", type=float, default=3100.0, help="synthetic hg38-like genome (configs[2]: hg38 full); smaller values for development")
-    ap.add_argument("--barcodes", type=int, default=10000, help="barcodes per batch (= per step)")
+    ap.add_argument("--barcodes", type=int, default=20000, help="barcodes per batch (= per step); default 2 M pairs per batch: 25 steps = the 50 M pairs of configs[2]")
     ap.add_argument("--pairs-per-barcode", type=int, default=100)
     ap.add_argument("--lanes", type=int, default=2, help="lh_context_opts.lanes: 2 = every batch is cut at a barcode boundary and its two halves are aligned "
                                                           "side by side inside ONE lh_align_resident call (1 = one pipeline)")
@@ -108,15 +108,18 @@ def main():
     opts = lib.opts()
     t0 = time.time()
     first = None
+    n_slots = 0
     for slot, g in enumerate(my_batches):
+        if slot and lib.device_memory(local_rank)[0] < (16 << 30):   # leave room for the kernels' scratch: later steps reuse the resident batches in turn
+            break
         r = lib.synth_reads(pac, l_pac, ctg, seed=workload.READS_SEED + g, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode,
                             threads=max(1, (os.cpu_count() or 8) // max(1, world)))
         b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
         ctx.upload_slot(slot, b)
+        n_slots = slot + 1
         if first is None:
             first = (r, b)
     t_reads_upload = time.time() - t0
-    n_slots = len(my_batches)
 
     def sync_all():
         if dist is not None:
@@ -131,13 +134,14 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     kern = {}
-    for s in range(n_slots):
-        ctx.select(s)
+    for s in range(len(my_batches)):
+        ctx.select(s % n_slots)
         ctx.align_resident(opts)   # enqueues every kernel of the hot path on the context's stream and synchronises it
         for name, ms in ctx.timings():   # HIP events recorded on that stream around each launch
             kern.setdefault(name, []).append(ms)
     sync_all()
     elapsed = time.perf_counter() - t0
+    hbm_free, hbm_total = lib.device_memory(local_rank)
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -159,7 +163,8 @@ def main():
                                    "%d steps x %d pairs 2x150 (143+150 post-trim) / %d barcodes per step per GPU, every step a different batch, RFA on device"
                                    % (l_pac / 1e6, workload.GENOME_SEED, a.steps, n_pairs, a.barcodes),
                        "pairs_per_step": n_pairs, "barcodes_per_step": a.barcodes, "genome_bases": l_pac, "suffix_array_interval": idx.sa_interval,
-                       "lanes_per_context": a.lanes,
+                       "lanes_per_context": a.lanes, "distinct_batches_resident": n_slots,
+                       "hbm_GiB": {"free_during_run": round(hbm_free / 2**30, 1), "total": round(hbm_total / 2**30, 1)},
                        "parallelism": "barcode-range shards, index replicated, no collective"},
             "roofline": roofline(lib, idx, avg, cnt, first[0], local_rank, a),
             "kernel_ms_note": "HIP-event durations of the first lane's launches" + ((" (each launch = 1/%d of a batch; the other parts run beside it)" % a.lanes if a.lanes > 1 else "")),

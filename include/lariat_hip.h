@@ -296,6 +296,8 @@ int lh_get_seq(const lh_index* idx, int32_t rid, int64_t start, int64_t end, int
 
 /* diagnostics: rate (GB/s of requested bytes) of independent random reads of `granule_bytes` blocks (multiple of 16)
  * from a `table_bytes` table in HBM — the practical ceiling for the FM-index walks */
+/* free / total bytes of device memory right now (hipMemGetInfo): hosts sizing batches and lanes leave room for the kernels' scratch */
+int lh_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes);
 int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, int64_t n_access, double* gbps, double* ms);
 
 /* diagnostics: self-check of a resident index with a dense suffix array, on every stride-th row: adjacent suffixes are in

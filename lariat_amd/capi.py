@@ -300,6 +300,7 @@ def _declare(L):
     L.lh_stage_dump_resident.argtypes = [C.c_void_p, C.POINTER(LhOpts), C.POINTER(C.POINTER(LhStageDump))]
     L.lh_stage_dump_free.argtypes = [C.POINTER(LhStageDump)]
     L.lh_get_seq.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_char_p]
+    L.lh_device_memory.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.lh_diag_random_read.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return L
 
@@ -326,6 +327,12 @@ class Library:
 
     def device_count(self):
         return self.L.lh_device_count()
+
+    def device_memory(self, device=0):
+        """(free, total) bytes of device memory"""
+        f, t = C.c_int64(0), C.c_int64(0)
+        self.check(self.L.lh_device_memory(device, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def opts(self, **kw):
         o = LhOpts()
@@ -765,6 +772,6 @@ EXPORTED_SYMBOLS = [
     "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
     "lh_records_text", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
-    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_diag_random_read", "lh_diag_go_rand",
+    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_random_read", "lh_diag_go_rand",
     "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest",
 ]

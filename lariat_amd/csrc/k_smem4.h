@@ -72,6 +72,9 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_TRI_LCP2 27
 #define S4_FJUMP 28      // forward extension: the first levels of the walk in one read of the k-mer tree (see START_SMEM1)
 #define S4_FJUMP2 29
+#define S4_P2_PROBE 30   // pass 2: can the re-seeding inside this SMEM yield a seed at all? (DIndex::rep_t, see S4_P2_NEXT)
+#define S4_P2_PROBE2 31
+#define S4_P2_PROBE3 32
 #define LH_KMER 12
 
 #ifndef LH_SLOW_BATCH
@@ -364,6 +367,17 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     else { int last_; WKEY_AT(i - 1, last_) (void)last_; BLOOM_ISSUE() FWD_ADVANCE() }
                 } else { BLOOM_ISSUE() FWD_ADVANCE() }   // the walk ends inside the skipped levels: step by step from level 1
             }
+            else if (DO2 && st == S4_P2_PROBE) { ld64 = ix.sa[ld64]; st = S4_P2_PROBE2; }
+            else if (DO2 && st == S4_P2_PROBE2) {   // the bits of the K windows' first positions: text position of the SMEM's start + i on
+                const u64 t0 = ld64 + (u64)i;
+                pn.lo = ix.rep_t[t0 >> 6]; pn.hi = ix.rep_t[(t0 >> 6) + 1]; tw_sh = (uint32_t)(t0 & 63);
+                st = S4_P2_PROBE3;
+            }
+            else if (DO2 && st == S4_P2_PROBE3) {
+                const u64 bits = tw_sh ? (pn.lo >> tw_sh) | (pn.hi << (64 - tw_sh)) : pn.lo;
+                if (bits & ((1ull << LH_BLOOM_K) - 1)) START_SMEM1()
+                else st = S4_P2_NEXT;
+            }
             else if (DO3 && st == S4_P3_JUMP) { pn = kt ? kt[ld64] : ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
             else if (DO3 && st == S4_P3_JUMP2) {   // as if the bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
                 const int jl = kt ? ktl : LH_KMER;
@@ -382,11 +396,22 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 st = S4_TRI_LCP2;
             }
             else if (DO1 && st == S4_TRI_LCP2) {
+#ifdef LH_SMEM_TURNS
+                atomicAdd(&lh_dbg[ec < emin - (i + 1) ? 22 : 23], 1);
+#endif
                 if (ec < emin - (i + 1)) {   // the shortest entry is unique from u = i + 1 on: the list is its longest entry
                     c0 = ld64;
                     if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
                     st = S4_SMEM_DONE;
-                } else {   // not provable: the sweep as written, from its first row
+                } else {
+                    // Not the whole list, but its tail: an entry [x, e) with e - u > ec is unique from row u on, so by then it has merged
+                    // into the entry before it (equal sizes of nested occurrence sets are equal sets, and stay equal in later rows); an
+                    // entry that is NOT unique at row u was never merged into one that is.  Down to row u nothing is emitted, so the
+                    // sweep over the longest entry and the entries that may still be distinct at row u leaves the same list there as
+                    // the sweep over all of them.  The list's ends are distinct and ascending from emin: at most u + ec - emin + 1 of
+                    // them are <= u + ec, the first ones of the forward list.  The sweep as written over those, from its first row.
+                    const int m_ = i + 1 + ec - emin + 1;
+                    if (m_ < nprev - 1) nprev = m_ + 1;
                     tri_failed = 1; tri = 0;
                     i = x - 1;
                     BWD_ROW_BODY()
@@ -408,6 +433,13 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             }
             if (DO12 && st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
                 ret = cinfo; curA ^= 1; nprev = ncurr; rev = 1; have_mem = 0; last_mem_start = 0; i = x - 1;
+#ifdef LH_SMEM_TURNS
+                if (MODE == 3) {
+                    if (nprev == 1) atomicAdd(&lh_dbg[24], 1);
+                    else if (PE_X2(ce) == 1) { atomicAdd(&lh_dbg[25], 1); atomicAdd(&lh_dbg[26], nprev); }
+                    else { atomicAdd(&lh_dbg[27], 1); atomicAdd(&lh_dbg[28], nprev); if (x == 0) atomicAdd(&lh_dbg[29], 1); }
+                }
+#endif
                 BWD_ROW_BODY()
             }
             if (DO12 && st == S4_BWD_EMIT0) {
@@ -433,7 +465,15 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     int xm = ((int)(p.info >> 32) + (int)(uint32_t)p.info) >> 1;
                     if (QB(xm) > 3) continue;   // bwt_smem1a returns at once on an ambiguous base
                     x = xm; min_intv = (int)p.x2 + 1;
-                    START_SMEM1()
+                    // Every MEM this bwt_smem1a call can contribute covers xm, is min_seed_len >= LH_BLOOM_K bases long and occurs
+                    // min_intv >= 2 times: it contains one of the LH_BLOOM_K-mers [w, w + K) with xm - K < w <= xm, which then occurs twice
+                    // or more.  If those windows all lie inside the SMEM, the read equals the text there (at any occurrence: the first
+                    // row's), and the text's bits say whether a k-mer occurs again.  None does (the usual case in unique sequence): the
+                    // call cannot contribute and is left out, like the intervals the sweep filter drops (off when the filter is off).
+                    if (filt && ix.rep_t && xm - (LH_BLOOM_K - 1) >= (int)(p.info >> 32) && xm + LH_BLOOM_K <= (int)(uint32_t)p.info) {
+                        ld64 = p.x0; i = xm - (LH_BLOOM_K - 1) - (int)(p.info >> 32);
+                        st = S4_P2_PROBE;
+                    } else START_SMEM1()
                     break;
                 }
             }
@@ -521,6 +561,12 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         uint4 hk = {0, 0, 0, 0}, dk = hk, hl = hk, dl = hk;
         u64 k2 = 0, l2 = 0;
         const u64 xa = st == S4_REQ_BWD ? c0 : c1;   // x[!is_back]
+#ifdef LH_SMEM_TURNS   // which extensions pass 1 still makes (lh_dbg[16..21])
+        if (MODE == 3) {
+            int cls_ = !req ? -1 : st == S4_REQ_FWD ? (by_tree ? 0 : 1) : (by_tree ? 2 : 4) + (nprev > 1 ? 1 : 0);
+            for (int kk_ = 0; kk_ < 6; ++kk_) { int n_ = (int)__popcll(__ballot(cls_ == kk_)); if (lane == 0 && n_) atomicAdd(&lh_dbg[16 + kk_], n_); }
+        }
+#endif
         if (by_tree) {
             uint32_t code;
             if (st == S4_REQ_BWD) code = rcode & ((1u << (2 * lnew)) - 1u);

@@ -97,6 +97,10 @@ struct DIndex {
     // lcp[r] = bases shared by the suffixes of rows r - 1 and r, capped at 255 (rows 0, 1 and n + 1: 0); next to isa / tn, else null.
     // K1 (pass 1) reads from it whether every entry of a forward list is unique at the point where its longest one ends (k_smem4.h).
     const uint8_t* lcp;
+    // rep_t: one bit per position of the text fwd||rev, next to lcp, else null: the LH_BLOOM_K-mer that starts there occurs again elsewhere
+    // (its row shares LH_BLOOM_K bases with a neighbouring row).  K1's pass 2 reads from it that a re-seeding inside a unique SMEM
+    // cannot yield a seed (k_smem4.h, S4_P2_PROBE).
+    const u64* rep_t;
     // the bi-interval of every 12-mer (packed like K1's list entries, 16 B each): bwt_seed_strategy1's walks start there
     const void* kmer12;
     // the bi-interval of EVERY string of 1 .. ktree_levels bases (only next to isa / tn; packed like kmer12's entries): level L
