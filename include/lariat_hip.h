@@ -374,6 +374,11 @@ uint64_t lh_name_seed(const char* name, int64_t n);
  * (positions 0-based, -1 = none, as bam.Record holds them).  The binary encoding / BGZF / bucketing into files is the
  * second half of N1.  `res` and `in` must describe the same batch; contig_names[rid] as from lh_index_contigs. */
 int lh_records_text(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, char** text, int64_t* text_len);
+/* the same with options: LH_REC_DEBUG_TAGS adds the tags of -debugBamTags (bamwriter.go:498-558: XM XZ XX XL XP XR XC for the second-best
+ * alignment, AA CP CM CU CS RD MS MC PP PS PL AC PC), all derived from the result's per-candidate fields; AA is empty, as it is in the
+ * reference without -debug */
+#define LH_REC_DEBUG_TAGS 1
+int lh_records_text_ex(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, int32_t flags, char** text, int64_t* text_len);
 void lh_records_free(char* text);
 
 /* N1, second half — the BAM container (bamwriter.go:46-191 CreateBAM / CreateBAMs, :281-284 AppendBams): BGZF-compressed
@@ -388,6 +393,7 @@ int lh_bam_open(const char* dir, int32_t n_contigs, const char* const* contig_na
                 int32_t position_chunk_size, int32_t first_chunk, const char* command_line, int32_t threads, lh_bam_writer** out);
 /* appends the records of one batch (lh_records_text order) to bc_sorted_bam.bam and to their position bucket */
 int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_ingest_batch* in);
+int lh_bam_set_flags(lh_bam_writer* w, int32_t flags); /* LH_REC_* for the records appended from now on (CreateBAMs' debugTags, bamwriter.go:133) */
 int lh_bam_close(lh_bam_writer* w); /* flushes, writes the BGZF end-of-file blocks, frees w */
 /* The host-side step of the multi-GPU path: every rank aligns a contiguous barcode range and writes its own file set
  * (lh_bam_open with first_chunk only on rank 0); the job's files are the rank-ordered concatenation, file by file — for

@@ -16,6 +16,7 @@ LH_OK = 0
 LH_ABI_VERSION = 2
 LH_E_ARG, LH_E_IO, LH_E_HIP, LH_E_CAPACITY, LH_E_NODEVICE, LH_E_LIMIT = 1, 2, 3, 4, 5, 6
 # lh_opts.flags
+LH_REC_DEBUG_TAGS = 1
 LH_F_NO_SWEEP_FILTER, LH_F_SMEM_FUSED, LH_F_SMEM_P12, LH_F_SMEM_LANE, LH_F_EXT_WAVE, LH_F_EXT_SERIAL = 1, 2, 4, 8, 16, 32
 LH_MAX_READ_LEN = 250
 
@@ -271,6 +272,10 @@ def _declare(L):
     L.lh_ingest_close.restype = None
     L.lh_records_text.argtypes = [C.POINTER(LhResult), C.POINTER(LhIngestBatch), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.lh_records_text.restype = C.c_int
+    L.lh_records_text_ex.argtypes = [C.POINTER(LhResult), C.POINTER(LhIngestBatch), C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.lh_records_text_ex.restype = C.c_int
+    L.lh_bam_set_flags.argtypes = [C.c_void_p, C.c_int32]
+    L.lh_bam_set_flags.restype = C.c_int
     L.lh_bam_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), c_i64p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
     L.lh_bam_open.restype = C.c_int
     L.lh_bam_append.argtypes = [C.c_void_p, C.POINTER(LhResult), C.POINTER(LhIngestBatch)]
@@ -463,12 +468,12 @@ class Library:
     def bam_writer(self, directory, contig_names, contig_lens, read_groups="", position_chunk_size=40000000, first_chunk=True, command_line="", threads=0):
         return BamWriter(self, directory, contig_names, contig_lens, read_groups, position_chunk_size, first_chunk, command_line, threads)
 
-    def records_text(self, result, ingest_batch, contig_names):
-        """BAM record content (bamwriter.go AppendBam) for one batch: `result` = Result of aligning `ingest_batch`"""
+    def records_text(self, result, ingest_batch, contig_names, debug_tags=False):
+        """BAM record content (bamwriter.go AppendBam) for one batch: `result` = Result of aligning `ingest_batch`; debug_tags = -debugBamTags"""
         rs = result.as_struct()
         names = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
         txt, n = C.c_void_p(), C.c_int64()
-        self.check(self.L.lh_records_text(C.byref(rs), ingest_batch.ptr, len(contig_names), names, C.byref(txt), C.byref(n)))
+        self.check(self.L.lh_records_text_ex(C.byref(rs), ingest_batch.ptr, len(contig_names), names, LH_REC_DEBUG_TAGS if debug_tags else 0, C.byref(txt), C.byref(n)))
         out = C.string_at(txt, n.value).decode()
         self.L.lh_records_free(txt)
         return out
@@ -716,6 +721,9 @@ class BamWriter:
         lib.check(lib.L.lh_bam_open(directory.encode(), len(contig_names), names, lens.ctypes.data_as(c_i64p), read_groups.encode(), int(position_chunk_size),
                                     int(bool(first_chunk)), command_line.encode(), int(threads), C.byref(self.h)))
 
+    def set_debug_tags(self, on=True):
+        self.lib.check(self.lib.L.lh_bam_set_flags(self.h, LH_REC_DEBUG_TAGS if on else 0))
+
     def append(self, result, ingest_batch):
         rs = result.as_struct()
         self.lib.check(self.lib.L.lh_bam_append(self.h, C.byref(rs), ingest_batch.ptr))
@@ -770,7 +778,7 @@ EXPORTED_SYMBOLS = [
     "lh_last_error", "lh_device_count", "lh_opts_init", "lh_index_load", "lh_index_from_arrays", "lh_index_contigs", "lh_index_l_pac",
     "lh_index_resample_sa", "lh_index_sa_interval",
     "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
-    "lh_records_text", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_close",
+    "lh_records_text", "lh_records_text_ex", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_set_flags", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_random_read", "lh_diag_go_rand",
     "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest",

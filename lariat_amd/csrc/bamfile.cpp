@@ -74,6 +74,7 @@ int reg2bin(int64_t beg, int64_t end) {   // SAM spec section 5.3
 }   // namespace
 
 struct lh_bam_writer {
+    int32_t rec_flags = 0;   // LH_REC_*
     std::vector<std::string> names;
     std::vector<int64_t> lens;
     std::map<std::string, int> rid_of;
@@ -260,7 +261,7 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
     // (no text form in between); per-file byte strings are joined in order
     std::vector<std::vector<std::string>> local;
     int nt = 0;
-    int rc = lh_records_visit_(res, in, (int32_t)names.size(), names.data(), &nt,
+    int rc = lh_records_visit_(res, in, (int32_t)names.size(), names.data(), w->rec_flags, &nt,
                                [&](int t) { if ((size_t)t >= local.size()) local.resize((size_t)t + 1); local[(size_t)t].assign(w->outs.size(), std::string()); },
                                [&](int t, const LhRec& R) {
                                    std::string& bc = local[(size_t)t][0];          // BarcodeSortedBam
@@ -293,6 +294,12 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
     double t3 = now();
     if (!flush(w, false)) { w->failed = true; return lh_set_error_(LH_E_IO, "lh_bam_append: compression or write failed"); }
     if (timing) fprintf(stderr, "[lh_bam_append] records %.3f s, join %.3f s, compress+write %.3f s (%d threads)\n", t1 - t0, t3 - t2, now() - t3, nt);
+    return LH_OK;
+}
+
+extern "C" int lh_bam_set_flags(lh_bam_writer* w, int32_t flags) {
+    if (!w) return lh_set_error_(LH_E_ARG, "lh_bam_set_flags: null writer");
+    w->rec_flags = flags;
     return LH_OK;
 }
 

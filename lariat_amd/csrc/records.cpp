@@ -52,8 +52,37 @@ void put_int(std::string& s, long long v) {   // decimal, without the cost of sn
     while (n) s += b[--n];
 }
 
-// AppendBam(aln, primary, debugTags = false, attach_bx): fills R
-void append_bam(Ctx& c, LhRec& R, int64_t read, int64_t aln, int64_t primary, bool attach_bx) {
+// what -debugBamTags reads from the molecules of a barcode (MapQData fields filled by updateAlignmentsMoleculeStatus, lariat.go:687-719,
+// and estimateMapQualities, lariat.go:917-958): a molecule's number of active alignments and its confidence, taken from its active
+// alignments (a molecule the optimizer emptied has none: 0 reads, and moleculeConfidence of 0 active alignments is 0)
+struct BcMolecules {
+    int32_t set = -1;
+    bool ran = false;   // worthRunningRFA: candidate_molecules != nil
+    std::vector<int32_t> reads; std::vector<double> conf;
+    void load(const Ctx& c, int32_t s) {
+        set = s;
+        const lh_result* r = c.r;
+        const lh_batch& b = c.in->batch;
+        ran = b.bc_do_rfa ? b.bc_do_rfa[s] != 0 : true;
+        reads.clear(); conf.clear();
+        for (int64_t a = r->cand_off[2 * (int64_t)b.bc_pair_off[s]]; a < r->cand_off[2 * (int64_t)b.bc_pair_off[s + 1]]; ++a) {
+            const int32_t m = r->molecule_id[a];
+            if (m < 0 || !r->in_filtered[a]) continue;
+            if ((size_t)m >= reads.size()) { reads.resize((size_t)m + 1, 0); conf.resize((size_t)m + 1, 0.0); }
+            if (r->active[a]) { reads[(size_t)m]++; conf[(size_t)m] = r->molecule_confidence[a]; }
+        }
+    }
+};
+
+void put_f6(std::string& s, double v) { char b[400]; snprintf(b, sizeof b, "%.6f", v); s += b; }   // strconv.FormatFloat(v, 'f', 6, 64)
+std::string op_counts(const lh_result* r, int64_t a) {
+    std::string s = "Match:"; put_int(s, r->matches[a]); s += ":Mismatches:"; put_int(s, r->mismatches[a]); s += ":Indels:"; put_int(s, r->indels[a]);
+    s += ":soft_clipped:"; put_int(s, r->soft_clipped[a]);
+    return s;
+}
+
+// AppendBam(aln, primary, debugTags, attach_bx): fills R
+void append_bam(Ctx& c, LhRec& R, int64_t read, int64_t aln, int64_t primary, bool attach_bx, const BcMolecules* dbg) {
     const lh_result* r = c.r;
     const lh_ingest_batch* in = c.in;
     const int64_t pair = read >> 1;
@@ -171,6 +200,45 @@ void append_bam(Ctx& c, LhRec& R, int64_t read, int64_t aln, int64_t primary, bo
         put_int(sa, c.mapq[other]); sa += ','; put_int(sa, (r->mm_off[other + 1] - r->mm_off[other]) + indel); sa += ';';
         tagz("SA", sa);
     }
+    if (dbg) {   // bamwriter.go:498-558, in the order the tags are appended there (AC and XC appear a second time, as in the reference)
+        auto zi = [&](const char* t, long long v) { std::string s; put_int(s, v); tagz(t, s); };
+        auto zf = [&](const char* t, double v) { std::string s; put_f6(s, v); tagz(t, s); };
+        long long copies = 0, in_act = 0, out_act = 0, uniq = 0, rd = 0;
+        if (!is_split) {   // a split's MapQData holds the two scores only (split.go:154)
+            std::vector<int32_t> seen;
+            for (int64_t a = r->cand_off[read]; a < r->cand_off[read + 1]; ++a) {
+                if (!r->in_filtered[a]) continue;
+                ++copies;
+                if (!dbg->ran) continue;
+                if (r->active_molecule[a]) {
+                    ++in_act;
+                    bool has = false;
+                    for (int32_t m : seen) has = has || m == r->molecule_id[a];
+                    if (!has) seen.push_back(r->molecule_id[a]);
+                } else ++out_act;
+            }
+            uniq = (long long)seen.size();
+            if (dbg->ran && r->molecule_id[aln] >= 0) rd = dbg->reads[(size_t)r->molecule_id[aln]];
+        }
+        if (sb >= 0) {
+            const int64_t sm = r->mate_idx[sb];
+            if (sm >= 0) { zf("XM", r->log_alignment_probability[sm]); tagz("XZ", op_counts(r, sm)); }
+            tagz("XX", op_counts(r, sb));
+            zf("XL", r->log_alignment_probability[sb]);
+            tagz("XP", r->is_proper[sb] ? "true" : "false");
+            const int32_t m = r->molecule_id[sb];
+            zi("XR", m >= 0 ? dbg->reads[(size_t)m] : -1);
+            zf("XC", m >= 0 ? dbg->conf[(size_t)m] : -1.0);
+        }
+        tagz("AA", "");   // active_alignments_in_molecules is only filled under -debug (lariat.go:995)
+        zi("CP", copies); zi("CM", in_act); zi("CU", uniq); zi("CS", out_act); zi("RD", rd);
+        zf("MS", r->sum_move_probability_change[aln]);
+        zf("MC", r->molecule_confidence[aln]);
+        tagz("PP", r->is_proper[aln] ? "true" : "false");
+        if (pm >= 0) { zi("PS", r->score[pm]); zf("PL", r->log_alignment_probability[pm]); }   // (the reference dereferences primary.mate_alignment unconditionally)
+        tagz("AC", op_counts(r, aln));
+        if (pm >= 0) tagz("PC", op_counts(r, pm));
+    }
     std::string bc = col(in->bc, in->bc_off, pair);
     if (bc.find('-') != std::string::npos && attach_bx) {
         tagz("BX", bc);
@@ -204,7 +272,7 @@ void emit_text(const Ctx& c, const LhRec& R, std::string& o) {
 
 }   // namespace
 
-int lh_records_visit_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, int* n_threads,
+int lh_records_visit_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, int32_t flags, int* n_threads,
                       const std::function<void(int)>& begin_thread, const std::function<void(int, const LhRec&)>& sink) {
     if (!res || !in) return lh_set_error_(LH_E_ARG, "lh_records_text: null argument");
     if (res->n_reads != 2 * in->batch.n_pairs) return lh_set_error_(LH_E_ARG, "lh_records_text: result and batch describe different reads");
@@ -227,14 +295,17 @@ int lh_records_visit_(const lh_result* res, const lh_ingest_batch* in, int32_t n
     auto work = [&](int t) {
         const int64_t p0 = n_pairs * t / nt, p1 = n_pairs * (t + 1) / nt;
         LhRec R;
+        BcMolecules mol;
+        const bool debug = (flags & LH_REC_DEBUG_TAGS) != 0;
         int32_t set = 0;
         for (int64_t read = 2 * p0; read < 2 * p1; ++read) {   // DoDumpToBam: reads in read_id order, the active alignment then its split
             while (set + 1 < in->n_sets && (read >> 1) >= in->batch.bc_pair_off[set + 1]) ++set;
             const bool attach_bx = in->set_complete[set] != 0;   // Data.attach_bx = WorkUnit.unique_barcode (lariat.go:493,546)
             const int64_t a = res->active_idx[read];
-            append_bam(c, R, read, a, a, attach_bx);
+            if (debug && mol.set != set) mol.load(c, set);
+            append_bam(c, R, read, a, a, attach_bx, debug ? &mol : nullptr);
             sink(t, R);
-            if (res->split_idx[read] >= 0) { append_bam(c, R, read, res->split_idx[read], a, attach_bx); sink(t, R); }
+            if (res->split_idx[read] >= 0) { append_bam(c, R, read, res->split_idx[read], a, attach_bx, debug ? &mol : nullptr); sink(t, R); }
         }
     };
     std::vector<std::thread> th;
@@ -245,18 +316,22 @@ int lh_records_visit_(const lh_result* res, const lh_ingest_batch* in, int32_t n
 }
 
 // the records of a batch as one text block per range of pairs (joined by lh_records_text)
-int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, std::vector<std::string>& part) {
+int lh_records_parts_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, int32_t flags, std::vector<std::string>& part) {
     Ctx names_only;
     names_only.names = contig_names;
-    return lh_records_visit_(res, in, n_contigs, contig_names, nullptr,
+    return lh_records_visit_(res, in, n_contigs, contig_names, flags, nullptr,
                              [&](int t) { if ((size_t)t >= part.size()) part.resize((size_t)t + 1); part[(size_t)t].reserve(1 << 20); },
                              [&](int t, const LhRec& R) { emit_text(names_only, R, part[(size_t)t]); });
 }
 
 extern "C" int lh_records_text(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, char** text, int64_t* text_len) {
+    return lh_records_text_ex(res, in, n_contigs, contig_names, 0, text, text_len);
+}
+
+extern "C" int lh_records_text_ex(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, int32_t flags, char** text, int64_t* text_len) {
     if (!text || !text_len) return lh_set_error_(LH_E_ARG, "lh_records_text: null argument");
     std::vector<std::string> part;
-    int rc = lh_records_parts_(res, in, n_contigs, contig_names, part);
+    int rc = lh_records_parts_(res, in, n_contigs, contig_names, flags, part);
     if (rc) return rc;
     size_t total = 0;
     for (auto& o : part) total += o.size();

@@ -25,5 +25,5 @@ struct LhRec {
 };
 // every record of the batch in the reference's order (DoDumpToBam), ranges of pairs handled by host threads: sink(thread, record)
 // is called from thread `thread` (0 .. n_threads-1) in order; threads own consecutive ranges of pairs.
-int lh_records_visit_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, int* n_threads,
+int lh_records_visit_(const lh_result* res, const lh_ingest_batch* in, int32_t n_contigs, const char* const* contig_names, int32_t flags /* LH_REC_* */, int* n_threads,
                       const std::function<void(int)>& begin_thread, const std::function<void(int, const LhRec&)>& sink);

@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE ONLY — Python restatement of the CONTENT of lariat's BAM records, used to check
 lariat_amd/csrc/records.cpp.  Follows go/src/inference/bamwriter.go: DoDumpToBam (:634-657), AppendBam (:286-568, without
 -debugTags), HardClip (:663-688), fixCigar (:266-279), reverseComp/reverseQual/reverseCigar (:575-612), and lariat.go:1102-1133
-(isPair).  No reference test asserts a BAM record, so this is parity-unpinned: two independent restatements agree."""
+(isPair); debug_tags=True adds the tags of -debugBamTags (:498-558; MapQData as filled at lariat.go:687-719,917-958, split.go:154).
+No reference test asserts a BAM record, so this is parity-unpinned: two independent restatements agree."""
 import numpy as np
 
 _COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
@@ -13,7 +14,7 @@ def _go_int(x):
     return v - (1 << 32) if v & 0x80000000 else v
 
 
-def records_text(res, cols, seq, seq_off, bc_pair_off, set_complete, contig_names):
+def records_text(res, cols, seq, seq_off, bc_pair_off, set_complete, contig_names, debug_tags=False, bc_do_rfa=None, md_int=None, md_sb_conf=None):
     """res: capi.Result (HIP or oracle); cols: dict of per-pair byte-string lists (IngestBatch.column); returns the text"""
     pos = np.array(res.pos, dtype=np.int64).copy()
     mapq = np.array(res.mapq, dtype=np.int64).copy()
@@ -36,7 +37,73 @@ def records_text(res, cols, seq, seq_off, bc_pair_off, set_complete, contig_name
     def mm_string(a):
         return "".join("%d,%d,1;" % (res.mm_ref_loc[k], res.mm_read_loc[k]) for k in range(res.mm_off[a], res.mm_off[a + 1]))
 
-    def append_bam(read, aln, primary, attach_bx):
+    def counts(a):
+        return "Match:%d:Mismatches:%d:Indels:%d:soft_clipped:%d" % (res.matches[a], res.mismatches[a], res.indels[a], res.soft_clipped[a])
+
+    def molecules_of(s):
+        """molecule id -> [active alignments, confidence] for barcode s (updateAlignmentsMoleculeStatus reads them off the molecules)"""
+        mols = {}
+        for a in range(int(res.cand_off[2 * bc_pair_off[s]]), int(res.cand_off[2 * bc_pair_off[s + 1]])):
+            m = int(res.molecule_id[a])
+            if m >= 0 and res.in_filtered[a] and res.active[a]:
+                e = mols.setdefault(m, [0, 0.0])
+                e[0] += 1
+                e[1] = float(res.molecule_confidence[a])
+        return mols
+
+    def debug_fields(read, aln, primary, s):
+        is_split = aln != primary
+        pm = int(res.mate_idx[primary])
+        if md_int is not None:   # MapQData straight from the oracle's molecules (tests/oracle_py.py: Result.md_int / md_sb_conf)
+            v = md_int[aln]
+            f = []
+            sb = -1 if is_split else int(res.second_best_idx[read])
+            if sb >= 0:
+                sm = int(res.mate_idx[sb])
+                if sm >= 0:
+                    f += ["XM:Z:%.6f" % res.log_alignment_probability[sm], "XZ:Z:" + counts(sm)]
+                f += ["XX:Z:" + counts(sb), "XL:Z:%.6f" % res.log_alignment_probability[sb], "XP:Z:" + ("true" if v[6] else "false"),
+                      "XR:Z:%d" % v[5], "XC:Z:%.6f" % md_sb_conf[aln]]
+            f += ["AA:Z:", "CP:Z:%d" % v[0], "CM:Z:%d" % v[1], "CU:Z:%d" % v[2], "CS:Z:%d" % v[3], "RD:Z:%d" % v[4],
+                  "MS:Z:%.6f" % res.sum_move_probability_change[aln], "MC:Z:%.6f" % res.molecule_confidence[aln], "PP:Z:" + ("true" if res.is_proper[aln] else "false")]
+            if pm >= 0:
+                f += ["PS:Z:%d" % res.score[pm], "PL:Z:%.6f" % res.log_alignment_probability[pm]]
+            f.append("AC:Z:" + counts(aln))
+            if pm >= 0:
+                f.append("PC:Z:" + counts(pm))
+            return f
+        # without them (a HIP result): the same values derived from the per-candidate fields
+        ran = True if bc_do_rfa is None else bool(bc_do_rfa[s])
+        mols = molecules_of(s)
+        f = []
+        md = dict(copies=0, cm=0, cu=0, cs=0, rd=0)   # a split's MapQData is made anew with its two scores only
+        sb = -1
+        if not is_split:
+            mine = [a for a in range(int(res.cand_off[read]), int(res.cand_off[read + 1])) if res.in_filtered[a]]
+            md["copies"] = len(mine)
+            if ran:
+                act = [a for a in mine if res.active_molecule[a]]
+                md["cm"], md["cs"], md["cu"] = len(act), len(mine) - len(act), len({int(res.molecule_id[a]) for a in act})
+                if res.molecule_id[aln] >= 0:
+                    md["rd"] = mols.get(int(res.molecule_id[aln]), [0, 0.0])[0]
+            sb = int(res.second_best_idx[read])
+        if sb >= 0:
+            sm = int(res.mate_idx[sb])
+            if sm >= 0:
+                f += ["XM:Z:%.6f" % res.log_alignment_probability[sm], "XZ:Z:" + counts(sm)]
+            m = int(res.molecule_id[sb])
+            f += ["XX:Z:" + counts(sb), "XL:Z:%.6f" % res.log_alignment_probability[sb], "XP:Z:" + ("true" if res.is_proper[sb] else "false"),
+                  "XR:Z:%d" % (mols.get(m, [0, 0.0])[0] if m >= 0 else -1), "XC:Z:%.6f" % (mols.get(m, [0, 0.0])[1] if m >= 0 else -1.0)]   # (the optimizer can leave a molecule without active alignments)
+        f += ["AA:Z:", "CP:Z:%d" % md["copies"], "CM:Z:%d" % md["cm"], "CU:Z:%d" % md["cu"], "CS:Z:%d" % md["cs"], "RD:Z:%d" % md["rd"],
+              "MS:Z:%.6f" % res.sum_move_probability_change[aln], "MC:Z:%.6f" % res.molecule_confidence[aln], "PP:Z:" + ("true" if res.is_proper[aln] else "false")]
+        if pm >= 0:
+            f += ["PS:Z:%d" % res.score[pm], "PL:Z:%.6f" % res.log_alignment_probability[pm]]
+        f.append("AC:Z:" + counts(aln))
+        if pm >= 0:
+            f.append("PC:Z:" + counts(pm))
+        return f
+
+    def append_bam(read, aln, primary, attach_bx, s_i=0):
         pair, read1 = read >> 1, (read & 1) == 0
         ref = contig(aln)
         flags = 0
@@ -126,6 +193,8 @@ def records_text(res, cols, seq, seq_off, bc_pair_off, set_complete, contig_name
                 cs += "%d%s" % (ln, ch)
             nmm = int(res.mm_off[other + 1] - res.mm_off[other])
             f.append("SA:Z:%s,%d,%s,%s,%d,%d;" % (contig(other) or "", int(pos[other]), "-" if res.reversed[other] else "+", cs, int(mapq[other]), nmm + indel))
+        if debug_tags:
+            f += debug_fields(read, aln, primary, s_i)
         bc = cols["bc"][pair].decode()
         if len(bc.split("-")) > 1 and attach_bx:
             f.append("BX:Z:" + bc)
@@ -138,7 +207,7 @@ def records_text(res, cols, seq, seq_off, bc_pair_off, set_complete, contig_name
         while s_i + 1 < len(set_complete) and (read >> 1) >= bc_pair_off[s_i + 1]:
             s_i += 1
         a = int(res.active_idx[read])
-        append_bam(read, a, a, bool(set_complete[s_i]))
+        append_bam(read, a, a, bool(set_complete[s_i]), s_i)
         if res.split_idx[read] >= 0:
-            append_bam(read, int(res.split_idx[read]), a, bool(set_complete[s_i]))
+            append_bam(read, int(res.split_idx[read]), a, bool(set_complete[s_i]), s_i)
     return "\n".join(out) + ("\n" if out else "")

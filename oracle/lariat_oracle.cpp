@@ -306,6 +306,8 @@ static void estimateMapQualities(Ctx& x, std::vector<std::vector<int>>& alignmen
             }
     }
     // updateAlignmentsMoleculeStatus, lariat.go:687-719
+    std::vector<int> copies_in(alignments.size(), 0), copies_out(alignments.size(), 0);
+    std::vector<std::vector<int>> unique_active(alignments.size());
     if (mols) {
         for (Molecule& m : *mols) {   // setMoleculeConfidences, lariat.go:1048-1059
             m.molecule_confidence = (double)m.active_alignments.Len() / (double)m.best_alignment_for_read.Len();
@@ -315,8 +317,8 @@ static void estimateMapQualities(Ctx& x, std::vector<std::vector<int>>& alignmen
             }
         }
         setMoleculeDifferences(x, *mols);
-        for (auto& arr : alignments)
-            for (int a : arr) {
+        for (size_t read_id = 0; read_id < alignments.size(); ++read_id)
+            for (int a : alignments[read_id]) {
                 Cand& A = x.c[a];
                 bool act = false;
                 if (A.molecule_id != -1) {
@@ -324,7 +326,14 @@ static void estimateMapQualities(Ctx& x, std::vector<std::vector<int>>& alignmen
                     act = m.active_alignments.Len() - m.soft_clipped > 4 && m.molecule_confidence > 0.1;
                     A.active_molecule = act;
                 }
-                if (act) (*mols)[A.molecule_id].active_molecule = true;
+                if (act) {
+                    (*mols)[A.molecule_id].active_molecule = true;
+                    copies_in[read_id]++;
+                    bool has = false;
+                    for (int m : unique_active[read_id]) has = has || m == A.molecule_id;
+                    if (!has) unique_active[read_id].push_back(A.molecule_id);
+                } else copies_out[read_id]++;
+                if (A.molecule_id != -1) A.md_reads_in_molecule = (*mols)[A.molecule_id].active_alignments.Len();
             }
     }
     // calculateLogMoleculePenalty, lariat.go:792-825
@@ -376,6 +385,9 @@ static void estimateMapQualities(Ctx& x, std::vector<std::vector<int>>& alignmen
         double second_best_raw_score = scores.empty() ? 0.0 : scores[0];
         double second_best_log_probability = -1000.0;
         int second_best_alignment = -1;
+        bool second_best_proper_pair = false;
+        int second_best_molecule_reads = -1;
+        double second_best_molecule_confidence = -1.0;
         for (int a : arr)
             for (int m : alignments[x.c[a].mate_id]) {
                 double s = scoreAlignment(x, &x.c[a], &x.c[m], lmp);
@@ -384,10 +396,23 @@ static void estimateMapQualities(Ctx& x, std::vector<std::vector<int>>& alignmen
                     second_best_raw_score = scoreAlignment(x, &x.c[a], &x.c[m], 0.0);
                     second_best_alignment = a;
                     x.c[a].mate_alignment = m;
+                    second_best_proper_pair = x.c[a].is_proper;
+                    if (x.c[a].molecule_id != -1) {
+                        Molecule& alt = (*mols)[x.c[a].molecule_id];
+                        second_best_molecule_confidence = alt.molecule_confidence;
+                        second_best_molecule_reads = alt.active_alignments.Len();
+                    }
                 }
             }
         for (int a : arr)   // lariat.go:946-961
             if (x.c[a].active) {
+                x.c[a].md_sb_proper = second_best_proper_pair;
+                x.c[a].md_sb_molecule_confidence = second_best_molecule_confidence;
+                x.c[a].md_sb_molecule_reads = second_best_molecule_reads;
+                x.c[a].md_copies = (int)arr.size();
+                x.c[a].md_copies_in_active = copies_in[x.c[a].read_id];
+                x.c[a].md_copies_outside = copies_out[read_id];
+                x.c[a].md_unique_active = (int)unique_active[read_id].size();
                 x.c[a].second_best = second_best_alignment;
                 x.c[a].second_best_score = second_best_raw_score;
                 x.c[a].md_score = scoreAlignment(x, &x.c[a], x.c[a].mate_alignment >= 0 ? &x.c[x.c[a].mate_alignment] : nullptr, 0.0);
@@ -665,7 +690,8 @@ void do_rfa_for_one_barcode(const LariatOpts& o, const Index& idx, const std::ve
         int split = GetSplitAlignment(x, active, full, cen_start, cen_end, &second_best);
         C[active].secondary = split;
         if (split >= 0) {
-            C[split].has_split_md = true;
+            C[split].has_split_md = true;   // a new MapQData with the two scores: the other fields are zero again
+            C[split].md_copies = C[split].md_copies_in_active = C[split].md_unique_active = C[split].md_copies_outside = C[split].md_reads_in_molecule = 0;
             C[split].split_second_best = second_best;
             C[split].split_score = scoreAlignment(x, &C[split], C[active].mate_alignment >= 0 ? &C[C[active].mate_alignment] : nullptr, 0.0);
             C[split].primary = active;

@@ -47,6 +47,10 @@ struct Cand {
     // mapq_data
     int second_best = -1;
     double second_best_score = 0, md_score = 0;
+    // the rest of MapQData (lariat.go:150-163), read by -debugBamTags only
+    int md_copies = 0, md_copies_in_active = 0, md_unique_active = 0, md_copies_outside = 0, md_reads_in_molecule = 0, md_sb_molecule_reads = 0;
+    bool md_sb_proper = false;
+    double md_sb_molecule_confidence = 0;
     bool has_split_md = false;
     double split_second_best = 0, split_score = 0;
 };

@@ -24,6 +24,8 @@ struct ResultArena {
     std::vector<uint8_t> reversed, in_filtered, active, is_proper, bwa_pick, active_molecule, duplicate;
     std::vector<uint32_t> cigar;
     std::vector<double> lap, mol_diff, mol_conf, sum_move, second_best_score, as_score, split_second_best, split_score;
+    std::vector<int32_t> md_int;   // 7 per candidate: copies, in active, unique active, outside, reads in molecule, second best: molecule reads, proper
+    std::vector<double> md_sb_conf;
 };
 
 struct DumpArena {
@@ -225,6 +227,8 @@ int lo_align_barcodes(const Index* idx, const lh_opts* opts, const lh_batch* b, 
             A->molecule_id.push_back(c.molecule_id); A->mapq.push_back(c.mapq);
             A->mol_diff.push_back(c.molecule_difference); A->mol_conf.push_back(c.molecule_confidence); A->sum_move.push_back(c.sum_move_probability_change);
             A->mate_idx.push_back(c.mate_alignment >= 0 ? base + c.mate_alignment : -1);
+            for (int v : {c.md_copies, c.md_copies_in_active, c.md_unique_active, c.md_copies_outside, c.md_reads_in_molecule, c.md_sb_molecule_reads, (int)c.md_sb_proper}) A->md_int.push_back(v);
+            A->md_sb_conf.push_back(c.md_sb_molecule_confidence);
             if (c.active) {
                 int64_t r = r0 + c.read_id;
                 A->active_idx[r] = base + (int64_t)i;
@@ -264,6 +268,16 @@ int lo_align_barcodes(const Index* idx, const lh_opts* opts, const lh_batch* b, 
     r.ext_cells = tot.ext_cells; r.glob_cells = tot.glob_cells; r.n_rescue = tot.n_rescue; r.rescue_cells = tot.rescue_cells;
     r.arena_ = A;
     *out = &A->r;
+    return LH_OK;
+}
+
+// MapQData as the oracle's molecules left it (the fields -debugBamTags prints), for a result of lo_align_barcodes: md_int = 7 values per
+// candidate (copies, copies_in_active_molecules, unique_molecules_active, copies_outside_active_molecules, reads_in_molecule,
+// second_best_molecule_reads, second_best_proper_pair), md_sb_conf = second_best_molecule_confidence
+int lo_result_mapq_data(const lh_result* r, const int32_t** md_int, const double** md_sb_conf) {
+    if (!r || !r->arena_ || !md_int || !md_sb_conf) { g_err = "lo_result_mapq_data: bad argument"; return LH_E_ARG; }
+    ResultArena* A = (ResultArena*)r->arena_;
+    *md_int = A->md_int.data(); *md_sb_conf = A->md_sb_conf.data();
     return LH_OK;
 }
 

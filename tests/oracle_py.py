@@ -148,6 +148,12 @@ class OracleIndex:
         if rc:
             raise RuntimeError(self.o.L.lo_last_error().decode())
         out = capi.Result(res.contents)
+        # MapQData of every candidate as the oracle's molecules left it (what -debugBamTags prints): [n_cand, 7] ints + a confidence
+        mi, mc = C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
+        self.o.L.lo_result_mapq_data.argtypes = [C.POINTER(capi.LhResult), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_double))]
+        if self.o.L.lo_result_mapq_data(res, C.byref(mi), C.byref(mc)) == 0 and out.n_cand:
+            out.md_int = np.ctypeslib.as_array(mi, shape=(out.n_cand, 7)).copy()
+            out.md_sb_conf = np.ctypeslib.as_array(mc, shape=(out.n_cand,)).copy()
         self.o.L.lo_result_free(res)
         return out
 

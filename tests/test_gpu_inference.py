@@ -178,6 +178,10 @@ def test_fastq_to_bam_records(lib, oracle, tmp_path):
         cols = {c: b.column(c) for c in cols_wanted}
         want = bam_oracle.records_text(ores, cols, b.seq, b.seq_off, b.bc_pair_off, b.set_complete, names)   # oracle records from the oracle's result
         assert got == want
+        # -debugBamTags: product records from the HIP result against the MapQData of the oracle's molecules (bamwriter.go:498-558)
+        got_d = lib.records_text(ctx.align_barcodes(b), b, names, debug_tags=True)
+        want_d = bam_oracle.records_text(ores, cols, b.seq, b.seq_off, b.bc_pair_off, b.set_complete, names, debug_tags=True, md_int=ores.md_int, md_sb_conf=ores.md_sb_conf)
+        assert got_d == want_d
         n += len(got.splitlines())
     assert n >= 2 * rs.n_pairs
 

@@ -71,6 +71,44 @@ def test_record_content(hostlib, oracle, tmp_path):
     assert "BX:Z:" in all_text and "AS:i:" in all_text and "XS:i:" in all_text and "AM:Z:" in all_text
 
 
+def test_debug_tags(hostlib, oracle, tmp_path):
+    """-debugBamTags (bamwriter.go:498-558): records.cpp derives MapQData from the result's per-candidate fields; the expected text
+    prints the MapQData the oracle's molecule structures hold (lariat.go:687-719, 917-958; split.go:154)"""
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = synth.make_reads(contigs, names, n_barcodes=6, pairs_per_barcode=40, seed=67, sub_lo=0.002, sub_hi=0.04, indel_rate=0.003, junk_frac=0.08)
+    rs.bc_pair_off = np.array([0, 3] + list(rs.bc_pair_off[2:]), dtype=rs.bc_pair_off.dtype)   # a barcode below the RFA threshold (candidate_molecules == nil)
+    for p in range(3, rs.n_pairs, 9):   # chimeric reads -> split records (their MapQData holds the two scores only)
+        a, d = 2 * p, 2 * ((p * 7 + 11) % rs.n_pairs)
+        la, ld = int(rs.seq_off[a + 1] - rs.seq_off[a]), int(rs.seq_off[d + 1] - rs.seq_off[d])
+        h = min(la, ld) // 2
+        rs.seq[rs.seq_off[a] + la - h:rs.seq_off[a] + la] = rs.seq[rs.seq_off[d] + ld - h:rs.seq_off[d] + ld]
+    path = write_fastq(tmp_path, rs)
+    seen = set()
+    n_sb = n_rd = n_norfa = 0
+    for b in hostlib.ingest(path, trim=7, max_pairs=120):
+        res = oidx.align_barcodes(b, threads=4)
+        got = hostlib.records_text(res, b, names, debug_tags=True)
+        cols = {c: b.column(c) for c in COLS}
+        want = bam_oracle.records_text(res, cols, b.seq, b.seq_off, b.bc_pair_off, b.set_complete, names, debug_tags=True, md_int=res.md_int, md_sb_conf=res.md_sb_conf)
+        assert got == want
+        # and the derivation restated in Python (what the GPU test uses, where no oracle molecules exist)
+        assert got == bam_oracle.records_text(res, cols, b.seq, b.seq_off, b.bc_pair_off, b.set_complete, names, debug_tags=True, bc_do_rfa=b.bc_do_rfa)
+        plain = hostlib.records_text(res, b, names).splitlines()
+        for ln, pl in zip(got.splitlines(), plain):
+            f = ln.split("\t")
+            tags = [t[:2] for t in f[11:]]
+            seen.update(tags)
+            n_sb += "XX" in tags
+            rd = [t for t in f[11:] if t.startswith("RD:Z:")]
+            n_rd += int(rd[0][5:]) > 0
+            n_norfa += "CS:Z:0" in f and "CM:Z:0" in f and "CP:Z:0" not in f and not int(f[1]) & 256
+            base = [t for k, t in enumerate(f) if k < 11 or t[:2] in ("RX", "QX", "TR", "TQ", "BC", "QT", "RG", "XS", "AS", "AM", "XT", "SA", "BX", "DM")]
+            assert base == [t for k, t in enumerate(pl.split("\t")) if k < 11 or t[:2] not in ("XC", "AC", "XM")]   # everything else is unchanged
+    assert {"AA", "CP", "CM", "CU", "CS", "RD", "MS", "MC", "PP", "PS", "PL", "AC", "PC", "XX", "XL", "XP", "XR", "XC"} <= seen
+    assert n_sb > 0 and n_rd > 0 and n_norfa > 0
+
+
 def test_pair_flags_are_consistent(hostlib, oracle, tmp_path):
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
@@ -114,6 +152,17 @@ def test_bam_files_round_trip(hostlib, oracle, tmp_path):
         want += hostlib.records_text(res, b, names).splitlines()
         w.append(res, b)
     w.close()
+    dbg = tmp_path / "dbg"
+    dbg.mkdir()
+    w2 = hostlib.bam_writer(str(dbg), names, lens, position_chunk_size=chunk)   # CreateBAMs(..., debugTags = true, ...)
+    w2.set_debug_tags(True)
+    want_dbg = []
+    for b in hostlib.ingest(path, trim=7, max_pairs=100):
+        res = oidx.align_barcodes(b, threads=4)
+        want_dbg += hostlib.records_text(res, b, names, debug_tags=True).splitlines()
+        w2.append(res, b)
+    w2.close()
+    assert [ln for ln, _ in bam_reader.read_bam(str(dbg / "bc_sorted_bam.bam"))[2]] == want_dbg and "\tCP:Z:" in want_dbg[0]
     files = sorted(os.listdir(outdir))
     assert files == ["000000-chrA_0000000000_pos_bucketed.bam", "000000-chrA_0000150000_pos_bucketed.bam", "000001-chrB_0000000000_pos_bucketed.bam",
                      "000001-chrB_0000150000_pos_bucketed.bam", "000002-chrC_0000000000_pos_bucketed.bam", "ZZZ_unmapped_pos_bucketed.bam", "bc_sorted_bam.bam"]
