@@ -466,11 +466,15 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             WAVE_SYNC();
             for (int i = lane; i < NCf; i += 64) T.plist[i] = sidx[i];
         } else {
-            for (int k = lane; k < ncont; k += 64) {
-                int32_t* pl = T.plist + T.coff[k];
-                int n = T.coff[k + 1] - T.coff[k];
-                dev_gosort(n, [&](int i, int j) { return R.pos[c_lo + pl[i]] < R.pos[c_lo + pl[j]]; }, [&](int i, int j) { int t = pl[i]; pl[i] = pl[j]; pl[j] = t; });
-            }
+            // a large barcode (the reader's cap is 30,000 pairs): keys next to the list (sval is free until the molecules are scored), every
+            // contig's sort at once with the ranges of Go's quickSort spread over the lanes (lh_sort.h: wave_gosort; molraw / rdl / firstf
+            // are free until inferMolecules and hold the queue of ranges)
+            i64* const kp = (i64*)T.sval;
+            int32_t* const pl = T.plist;
+            for (int i = lane; i < NCf; i += 64) kp[i] = R.pos[c_lo + pl[i]];
+            WAVE_SYNC();
+            wave_gosort(ncont, T.coff, [&](int i, int j) { return kp[i] < kp[j]; },
+                        [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = pl[i]; pl[i] = pl[j]; pl[j] = u; }, T.molraw, T.rdl, T.firstf);
         }
         WAVE_SYNC();
         RFA_T(3)

@@ -180,3 +180,62 @@ template <class L, class S> __device__ inline void dev_gosort(int n, L less, S s
         }
     }
 }
+
+// ---- the same sort by a whole wave ----
+// quickSort's two sides after a doPivot are disjoint index ranges, and so are the index spaces of separate sorts: whichever lane works
+// on a range, and whenever, the Less / Swap calls inside that range are those of the serial algorithm, so the result (tie order
+// included) is the same.  Ranges wait in a queue (qa / qb / qd: first, end, remaining depth; at most one entry per doPivot call, i.e.
+// fewer than the number of elements); each turn the lanes take one range each and make ONE step of quickSort on it: a doPivot (the
+// two sides are queued, or finished at once if they are short), or the heap sort of a range whose depth is used up.
+// Called by all lanes of the wave; `nsort` sorts over [first[k], first[k + 1]) with Go's depth limit for their sizes.
+template <class L, class S> __device__ inline void wave_gosort(int nsort, const int32_t* first, L less, S swp, int32_t* qa, int32_t* qb, int32_t* qd) {
+    const int lane = LANE();
+    int head = 0, tail = 0;
+    for (int base = 0; base < nsort; base += 64) {
+        const int k = base + lane;
+        int a = 0, b = 0;
+        if (k < nsort) { a = first[k]; b = first[k + 1]; }
+        const int want = b - a > 1;
+        const int at = tail + wave_scan_add_i32(want) - want;
+        if (want) {
+            int depth = 0;
+            for (int i = b - a; i > 0; i >>= 1) depth++;
+            qa[at] = a; qb[at] = b; qd[at] = depth * 2;
+        }
+        tail += __popcll(__ballot(want));
+    }
+    WAVE_SYNC();
+    auto finish_short = [&](int a, int b) {   // the tail of quickSort for a range of at most 12 elements
+        if (b - a > 1) {
+            for (int i = a + 6; i < b; i++)
+                if (less(i, i - 6)) swp(i, i - 6);
+            gs_insertion(less, swp, a, b);
+        }
+    };
+    while (head < tail) {
+        const int take = tail - head < 64 ? tail - head : 64;
+        int c0a = 0, c0b = 0, c1a = 0, c1b = 0, cd = 0, n0 = 0, n1 = 0;
+        if (lane < take) {
+            const int a = qa[head + lane], b = qb[head + lane];
+            int maxDepth = qd[head + lane];
+            if (b - a > 12) {
+                if (maxDepth == 0) gs_heapsort(less, swp, a, b);
+                else {
+                    maxDepth--;
+                    int mlo, mhi;
+                    gs_pivot(less, swp, a, b, &mlo, &mhi);
+                    cd = maxDepth;
+                    if (mlo - a > 12) { c0a = a; c0b = mlo; n0 = 1; } else finish_short(a, mlo);
+                    if (b - mhi > 12) { c1a = mhi; c1b = b; n1 = 1; } else finish_short(mhi, b);
+                }
+            } else finish_short(a, b);
+        }
+        head += take;
+        const int cnt = n0 + n1;
+        const int at = tail + wave_scan_add_i32(cnt) - cnt;
+        if (n0) { qa[at] = c0a; qb[at] = c0b; qd[at] = cd; }
+        if (n1) { qa[at + n0] = c1a; qb[at + n0] = c1b; qd[at + n0] = cd; }
+        tail += wave_sum_i32(cnt);
+        WAVE_SYNC();
+    }
+}

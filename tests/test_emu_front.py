@@ -213,3 +213,22 @@ def _check_get_seq(lib, oracle):
 
 def test_emu_get_seq(emu, oracle):
     _check_get_seq(emu, oracle)
+
+
+def test_emu_large_barcode_position_sort(emu, oracle):
+    """a barcode with more filtered candidates than K8 stages in LDS: the position sort of inferMolecules (lariat.go:1545-1547, Go's
+    unstable sort.Sort) runs as the wave-wide restatement (lh_sort.h wave_gosort); duplicated pairs give equal positions, whose
+    order is the algorithm's"""
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=1, pairs=460, junk=0.02, seed=23)
+    for p in range(5, rs.n_pairs, 7):   # PCR duplicates: the pair before, again
+        for k in (0, 1):
+            d, s = 2 * p + k, 2 * (p - 1) + k
+            n = min(int(rs.seq_off[d + 1] - rs.seq_off[d]), int(rs.seq_off[s + 1] - rs.seq_off[s]))
+            rs.seq[rs.seq_off[d]:rs.seq_off[d] + n] = rs.seq[rs.seq_off[s]:rs.seq_off[s] + n]
+    b = helpers.batch_of(rs)
+    ref = oidx.align_barcodes(b)
+    assert int((ref.in_filtered != 0).sum()) > 800   # past LH_RFA_SORT_LDS
+    helpers.assert_same_result(idx.context(rs.n_pairs).align_barcodes(b), ref, inference=True)
