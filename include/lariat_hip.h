@@ -78,6 +78,7 @@ typedef struct lh_opts {
 #define LH_F_SMEM_LANE 8u        /* K1 as BWA's loop nest, one lane per read (k_smem3.h) */
 #define LH_F_EXT_WAVE 16u        /* K4 wave-per-read only */
 #define LH_F_EXT_SERIAL 32u      /* K4's classes one after the other on one stream (per-class timings) */
+#define LH_F_SMEM_SPLIT 64u      /* K1 pass 1 as two kernels: the forward walks of every read, then the backward sweeps as independent work items */
 
 /* how an index is made resident (lh_index_load / lh_index_from_arrays / lh_index_build_device); NULL = defaults */
 typedef struct lh_index_opts {

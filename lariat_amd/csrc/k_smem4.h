@@ -75,6 +75,12 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_P2_PROBE 30   // pass 2: can the re-seeding inside this SMEM yield a seed at all? (DIndex::rep_t, see S4_P2_NEXT)
 #define S4_P2_PROBE2 31
 #define S4_P2_PROBE3 32
+#define S4_FETCH_SKIP 33
+#define S4_PENDING 34     // one of the shared blocks below runs for this lane before the turn's extensions (todo says which)
+#define TD_ROW 1          // BWD_ROW_BODY
+#define TD_SMEM 2         // START_SMEM1
+#define TD_FADV 4         // BLOOM_ISSUE + FWD_ADVANCE
+#define TD_KEY 8          // ... after the filter key has been taken from the read again (a jump moved the interval's end)
 #define LH_KMER 12
 
 #ifndef LH_SLOW_BATCH
@@ -87,18 +93,37 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 // long SMEMs pass 1 left, recognised from the stored intervals); 2: pass 3 only, appended to the
 // intervals the earlier launches left (pass 3 depends on the read alone, and the intervals are sorted afterwards: running it as
 // its own small kernel — a quarter of the instructions per turn, twice the waves — gives the same interval array).
+// MODE 5 / 6: pass 1 as TWO kernels.  A bwt_smem1a call is a forward walk (which alone decides where the next call starts: its
+// return value is the end of the longest forward match) and a backward sweep over the list the walk leaves.  MODE 5 makes the
+// forward walks of a read one after the other and hands every list to MODE 6 as an ITEM (start, end, the list's entries copied to a
+// pool, its last entry, emin); MODE 6 sweeps items, one per lane, whatever read they belong to, and appends the MEMs to the read's
+// interval array through its counter (their order does not matter: k_smem_fin sorts by `info`, and equal keys are equal intervals).
+// Each kernel carries half of the states — fewer instructions per turn, so the memory system rather than instruction issue sets the
+// pace — and the unit of work in the second one is a sweep, not a read (short tails).  Same Less / extend sequence per call.
+struct __attribute__((aligned(16))) K1Item { int32_t r, x, ret, nlist; PEnt ce; int32_t emin, list_off, pad0, pad1; };
+struct K1Split {
+    K1Item* items; PEnt* pool;
+    int32_t* ctr;          // [0] item slots handed out, [1] pool entries handed out, [2] set when either ran out, [3] MODE 6's fetch cursor
+    int32_t item_cap, pool_cap;
+};
+#define LH_K1_ITEM_CHUNK 256
+#define LH_K1_POOL_CHUNK 1024
 template <int MODE>
 __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
-                                               int32_t* __restrict__ next_read, DCounters* __restrict__ ctr) {
+                                               int32_t* __restrict__ next_read, DCounters* __restrict__ ctr, K1Split sp) {
     __shared__ uint32_t qn[32 * 64];
-    constexpr bool DO1 = MODE == 0 || MODE == 1 || MODE == 3, DO2 = MODE == 0 || MODE == 1 || MODE == 4, DO12 = DO1 || DO2, DO3 = MODE == 0 || MODE == 2;
+    constexpr bool FWD_ONLY = MODE == 5, BWD_ONLY = MODE == 6;
+    constexpr bool DO1 = MODE == 0 || MODE == 1 || MODE == 3 || MODE == 5 || MODE == 6, DO2 = MODE == 0 || MODE == 1 || MODE == 4, DO12 = DO1 || DO2, DO3 = MODE == 0 || MODE == 2;
     const int lane = LANE();
     const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)lane;
     PEnt* const LA = slab + t;                                    // entry e of list A at LA[e * T]
     PEnt* const LB = slab + (size_t)(LH_MAXLEN + 2) * T + t;
     const int split_len = (int)(o.min_seed_len * o.split_factor + .499);
-    int chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of reads
+    int chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of reads (MODE 6: of items)
+    int it_next = 0, it_end = 0, pl_next = 0, pl_end = 0;   // MODE 5, wave-uniform: the wave's chunks of item slots and pool entries
+    int list_off = 0;                    // MODE 6: the item's forward list in the pool
+    const int n_work = BWD_ONLY ? (sp.ctr[0] < sp.item_cap ? sp.ctr[0] : sp.item_cap) : n_reads;
     int st = S4_FETCH;
     int r = -1, len = 0, rst = 0, on = 0, ovf = 0;
     DIntv* out = intv_out;
@@ -125,6 +150,11 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     // LCP shortcut of the backward sweep (pass 1): emin = end of the first entry pushed to the forward list (the shortest string),
     // tri = the unique run in progress stands for a list of several entries, tri_failed = it was tried for this SMEM and did not apply
     int emin = 0, tri = 0, tri_failed = 0;
+    // The blocks that several states lead to — the start of a bwt_smem1a call, the start of a backward row, the next step of a
+    // forward walk — exist ONCE, between the transitions and the extensions of a turn; a state that needs one sets its bit in todo and
+    // parks the lane (S4_PENDING) instead of carrying a copy of the block (the compiler pays for every copy, and for every level of
+    // nesting around it, with register moves on the paths of ALL lanes).
+    int todo = 0;
     // sixteen read bases from s_ on, 2 bits each (base t at bits 2t; non-bases squeeze to arbitrary digits: callers mask)
 #define CODE16(s_, out_)                                                                                     \
     {                                                                                                        \
@@ -151,6 +181,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #define T16_B() (tw_sh ? (tw1 >> tw_sh) | (tw2 << (32 - tw_sh)) : tw1)
 #define CURR (curA ? LA : LB)
 #define PREV (curA ? LB : LA)
+    // entry e_ of the list being swept; MODE 6 reads an item's forward list (rev: the first row's) from the pool
+#define PREV_AT(e_) ((BWD_ONLY && rev) ? sp.pool[list_off + (e_)] : PREV[(uint32_t)(e_) * T])
     // forward extension: the next base decides between another bwt_extend and the end of the forward list
 #define FWD_ADVANCE()                                                                                        \
     {                                                                                                        \
@@ -223,10 +255,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             cd_ &= (1u << (2 * J_)) - 1u;                                                                    \
             ld64 = (((1ull << (2 * J_)) - 4) / 3) + cd_; j = J_; rcode = cd_;                                \
             st = S4_FJUMP;                                                                                   \
-        } else {                                                                                             \
-            BLOOM_ISSUE()                                                                                    \
-            FWD_ADVANCE()                                                                                    \
-        }                                                                                                    \
+        } else todo |= TD_FADV;                                                                              \
     }
     // pass 3: next base of the forward-only walk
 #define P3_ADVANCE()                                                                                         \
@@ -256,7 +285,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         else if (runs && filt && ix.lcp && rev && nprev > 1 && c2 == 1 && min_intv == 1 && !tri_failed) { tri = 1; st = S4_BRUN_INIT; } \
         else {                                                                                               \
             ec = c_; st = S4_REQ_BWD;                                                                        \
-            if (nprev > 1) pn = PREV[(uint32_t)(rev ? nprev - 2 : 1) * T];                                   \
+            if (nprev > 1) pn = PREV_AT(rev ? nprev - 2 : 1);                                                \
             if (ktl) CODE16(i, rcode)                                                                        \
         }                                                                                                    \
     }
@@ -267,23 +296,24 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         if (j < nprev) {                                                                                     \
             c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn); cinfo = PE_INFO(pn);                             \
             st = S4_REQ_BWD;                                                                                 \
-            if (j + 1 < nprev) pn = PREV[(uint32_t)(rev ? nprev - 2 - j : j + 1) * T];                       \
+            if (j + 1 < nprev) pn = PREV_AT(rev ? nprev - 2 - j : j + 1);                                    \
         } else if (ncurr == 0) st = S4_SMEM_DONE;                                                            \
         else {                                                                                               \
             curA ^= 1; nprev = ncurr; rev = 0; --i;                                                          \
             if (i < -1) st = S4_SMEM_DONE;                                                                   \
-            else BWD_ROW_BODY()                                                                              \
+            else { todo |= TD_ROW; st = S4_PENDING; }                                                        \
         }                                                                                                    \
     }
     // a backward-sweep interval that cannot be extended and is not contained in the previous MEM becomes a MEM
 #define EMIT_MEM()                                                                                           \
     {                                                                                                        \
         if (cinfo - (i + 1) >= o.min_seed_len) {                                                             \
-            if (on >= LH_MAX_INTV) ovf = 1;                                                                  \
+            if (BWD_ONLY) on = atomicAdd(&n_intv[r], 1);   /* sweeps of one read run in different lanes */    \
+            if (on >= LH_MAX_INTV) { ovf = 1; if (BWD_ONLY) atomicOr(&status[r], LH_ST_INTV_OVERFLOW); }     \
             else {                                                                                           \
                 DIntv m_; m_.x0 = c0; m_.x1 = c1; m_.x2 = c2; m_.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32; \
                 if (phase == 1 && cinfo - (i + 1) >= split_len && c2 <= (u64)o.split_width) p2mask |= 1ull << on; \
-                out[on++] = m_;                                                                              \
+                out[on] = m_; if (!BWD_ONLY) on++;                                                           \
             }                                                                                                \
         }                                                                                                    \
         have_mem = 1; last_mem_start = i + 1;                                                                \
@@ -299,7 +329,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             int cnt = __popcll(need), newbase = 0;
             if (chunk_next + cnt > chunk_end) {
                 int nb = 0;
-                if (lane == 0) nb = atomicAdd(next_read, 64);
+                if (lane == 0) nb = atomicAdd(BWD_ONLY ? sp.ctr + 3 : next_read, 64);
                 newbase = wave_readlane(nb, 0);
             }
             i64 off = 0;
@@ -307,30 +337,54 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             if (st == S4_FETCH) {
                 int idx = chunk_next + lanes_below(need, lane);
                 rr = idx < chunk_end ? idx : newbase + (idx - chunk_end);
-                if (rr >= n_reads) st = S4_DONE;
-                else { off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
+                if (rr >= n_work) st = S4_DONE;
+                else {
+                    if (BWD_ONLY) {   // rr is an item: its read is staged like any other
+                        const K1Item it = sp.items[rr];
+                        x = it.x; ret = it.ret; ncurr = it.nlist; ce = it.ce; emin = it.emin; list_off = it.list_off;
+                        rr = it.r;   // -1: a slot its wave did not use
+                    }
+                    if (rr >= 0) { off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
+                    else st = S4_FETCH_SKIP;
+                }
             }
             if (chunk_next + cnt > chunk_end) { chunk_next = newbase + (chunk_next + cnt - chunk_end); chunk_end = newbase + 64; }
             else chunk_next += cnt;
             u64 got = __ballot(st == S4_FETCH);
-            while (got) {
-                int L = __ffsll((unsigned long long)got) - 1;
-                got &= got - 1;
-                i64 offL = shfl_i64(off, L);
-                int lnL = wave_readlane(ln, L);
-                if (lnL > LH_MAXLEN) lnL = 0;
-                uint32_t w = 0;
-                if (4 * lane < lnL) __builtin_memcpy(&w, seq + offL + 4 * lane, 4);   // the batch buffer is padded: a read's tail word is readable
-                uint32_t nb16 = 0;
-                for (int b = 0; b < 4; ++b) {
-                    uint32_t v = (w >> (8 * b)) & 0xff;
-                    v = (4 * lane + b < lnL && v < 4) ? v : 4;
-                    nb16 |= v << (4 * b);
+            while (got) {   // four reads per round: their words are requested together, one memory latency per round
+                int Lk[4], lnk[4];
+                uint32_t wk[4];
+                for (int k = 0; k < 4; ++k) {
+                    Lk[k] = -1; lnk[k] = 0; wk[k] = 0;
+                    if (got) {
+                        Lk[k] = __ffsll((unsigned long long)got) - 1;
+                        got &= got - 1;
+                        const i64 offL = shfl_i64(off, Lk[k]);
+                        lnk[k] = wave_readlane(ln, Lk[k]);
+                        if (lnk[k] > LH_MAXLEN) lnk[k] = 0;
+                        if (4 * lane < lnk[k]) __builtin_memcpy(&wk[k], seq + offL + 4 * lane, 4);   // the batch buffer is padded: a read's tail word is readable
+                    }
                 }
-                uint32_t other = __shfl_xor(nb16, 1);
-                if (!(lane & 1)) qn[(lane >> 1) * 64 + L] = nb16 | other << 16;
+                for (int k = 0; k < 4; ++k) {
+                    if (Lk[k] < 0) break;
+                    uint32_t nb16 = 0;
+                    for (int b = 0; b < 4; ++b) {
+                        uint32_t v = (wk[k] >> (8 * b)) & 0xff;
+                        v = (4 * lane + b < lnk[k] && v < 4) ? v : 4;
+                        nb16 |= v << (4 * b);
+                    }
+                    uint32_t other = __shfl_xor(nb16, 1);
+                    if (!(lane & 1)) qn[(lane >> 1) * 64 + Lk[k]] = nb16 | other << 16;
+                }
             }
-            if (st == S4_FETCH) {
+            if (st == S4_FETCH_SKIP) st = S4_FETCH;   // (staged nothing; takes another item in the next slow turn)
+            else if (BWD_ONLY && st == S4_FETCH) {
+                r = rr; len = ln; if (len > LH_MAXLEN) len = 0;
+                out = intv_out + (size_t)r * LH_MAX_INTV;
+                phase = 1; min_intv = 1; cinfo = ret; curA = 1; tri = 0; tri_failed = 0;
+                st = S4_BWD_INIT;
+            }
+            else if (st == S4_FETCH) {
                 r = rr; len = ln; rst = 0; on = 0; ovf = 0; p2mask = 0;
                 if (len > LH_MAXLEN) { rst |= LH_ST_TOO_LONG; len = 0; }
                 out = intv_out + (size_t)r * LH_MAX_INTV;
@@ -364,8 +418,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     n_ext_total += j - 1; n_ktree_total++;
                     i = x + j; cinfo = i; fcode = rcode;
                     if (runs && c2 == 1 && min_intv == 1) st = S4_FRUN_INIT;
-                    else { int last_; WKEY_AT(i - 1, last_) (void)last_; BLOOM_ISSUE() FWD_ADVANCE() }
-                } else { BLOOM_ISSUE() FWD_ADVANCE() }   // the walk ends inside the skipped levels: step by step from level 1
+                    else { todo |= TD_FADV | TD_KEY; st = S4_PENDING; }
+                } else { todo |= TD_FADV; st = S4_PENDING; }   // the walk ends inside the skipped levels: step by step from level 1
             }
             else if (DO2 && st == S4_P2_PROBE) { ld64 = ix.sa[ld64]; st = S4_P2_PROBE2; }
             else if (DO2 && st == S4_P2_PROBE2) {   // the bits of the K windows' first positions: text position of the SMEM's start + i on
@@ -375,7 +429,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             }
             else if (DO2 && st == S4_P2_PROBE3) {
                 const u64 bits = tw_sh ? (pn.lo >> tw_sh) | (pn.hi << (64 - tw_sh)) : pn.lo;
-                if (bits & ((1ull << LH_BLOOM_K) - 1)) START_SMEM1()
+                if (bits & ((1ull << LH_BLOOM_K) - 1)) { todo |= TD_SMEM; st = S4_PENDING; }
                 else st = S4_P2_NEXT;
             }
             else if (DO3 && st == S4_P3_JUMP) { pn = kt ? kt[ld64] : ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
@@ -386,23 +440,22 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 i = x + jl;
                 P3_ADVANCE()
             }
-            else if (DO1 && st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
-            else if (DO1 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }
-            else if (DO1 && st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
-            else if (DO1 && st == S4_TRI_LCP) {   // ld64 = the row of the suffix that starts where the unique match ends on the left
+            else if (DO1 && !FWD_ONLY && st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
+            else if (DO1 && !FWD_ONLY && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }
+            else if (DO1 && !FWD_ONLY && st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
+            else if (DO1 && !FWD_ONLY && st == S4_TRI_LCP) {   // ld64 = the row of the suffix that starts where the unique match ends on the left
                 const uint8_t* lp = ix.lcp + ld64;
                 int l0 = lp[0], l1 = lp[1];
                 ec = l0 > l1 ? l0 : l1;   // (ec is free outside the extension states)
                 st = S4_TRI_LCP2;
             }
-            else if (DO1 && st == S4_TRI_LCP2) {
+            else if (DO1 && !FWD_ONLY && st == S4_TRI_LCP2) {
 #ifdef LH_SMEM_TURNS
                 atomicAdd(&lh_dbg[ec < emin - (i + 1) ? 22 : 23], 1);
 #endif
                 if (ec < emin - (i + 1)) {   // the shortest entry is unique from u = i + 1 on: the list is its longest entry
                     c0 = ld64;
-                    if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
-                    st = S4_SMEM_DONE;
+                    st = S4_BWD_EMIT0;   // a MEM unless contained in the previous one, then the call is over
                 } else {
                     // Not the whole list, but its tail: an entry [x, e) with e - u > ec is unique from row u on, so by then it has merged
                     // into the entry before it (equal sizes of nested occurrence sets are equal sets, and stay equal in later rows); an
@@ -414,24 +467,62 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     if (m_ < nprev - 1) nprev = m_ + 1;
                     tri_failed = 1; tri = 0;
                     i = x - 1;
-                    BWD_ROW_BODY()
+                    todo |= TD_ROW; st = S4_PENDING;
                 }
             }
-            else if (DO1) {   // S4_BRUN_END2: the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
+            else if (DO1 && !FWD_ONLY && st == S4_BRUN_END2) {   // the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
                 if (tri) st = S4_TRI_LCP;
-                else {
-                    c0 = ld64;
-                    if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
-                    st = S4_SMEM_DONE;
-                }
+                else { c0 = ld64; st = S4_BWD_EMIT0; }
             }
         }
         while (slow_turn && __any(st >= 8 && st < S4_FRUN_INIT)) {
-            if (DO12 && st == S4_BWD_EMIT) {
+            if (DO12 && !FWD_ONLY && st == S4_BWD_EMIT) {
                 EMIT_MEM()
                 BWD_ADVANCE()
             }
-            if (DO12 && st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
+            if (FWD_ONLY) {   // the forward list is complete: hand it to the sweep kernel, go on with the read where the next call starts
+                // a list whose sweep cannot start (nothing before x, or a non-base there) yields its longest entry at once (S4_BWD_EMIT0 of a
+                // sweep's first row: have_mem is 0): no item for those — the first call of every read is one
+                if (st == S4_BWD_INIT && (x == 0 || QB(x - 1) > 3)) {
+                    if (cinfo - x >= o.min_seed_len) {
+                        const int slot = atomicAdd(&n_intv[r], 1);
+                        if (slot >= LH_MAX_INTV) rst |= LH_ST_INTV_OVERFLOW;
+                        else { DIntv m_; m_.x0 = PE_X0(ce); m_.x1 = PE_X1(ce); m_.x2 = PE_X2(ce); m_.info = (u64)(uint32_t)cinfo | (u64)x << 32; intv_out[(size_t)r * LH_MAX_INTV + slot] = m_; }
+                    }
+                    x = cinfo; st = S4_P1_SCAN;
+                }
+                const bool give = st == S4_BWD_INIT;
+                const u64 gm = __ballot(give);
+                if (gm) {   // wave-wide: item slots and pool entries come from the wave's chunks (one device atomic per chunk)
+                    const int ng = __popcll(gm), mine = lanes_below(gm, lane);
+                    const int nl = give ? ncurr - 1 : 0;   // entries before the last one (which travels in the item)
+                    const int pl_pre = wave_scan_add_i32(nl) - nl, pl_tot = wave_sum_i32(nl);
+                    if (it_next + ng > it_end) {   // the rest of the old chunk stays unused: marked empty
+                        for (int e = it_next + lane; e < it_end; e += 64) sp.items[e].r = -1;
+                        int nb = 0;
+                        if (lane == 0) nb = atomicAdd(sp.ctr, LH_K1_ITEM_CHUNK);
+                        it_next = wave_readlane(nb, 0); it_end = it_next + LH_K1_ITEM_CHUNK;
+                        if (it_end > sp.item_cap) { if (lane == 0) sp.ctr[2] = 1; it_end = it_next < sp.item_cap ? sp.item_cap : it_next; }
+                    }
+                    if (pl_next + pl_tot > pl_end) {
+                        const int want = pl_tot > LH_K1_POOL_CHUNK ? pl_tot : LH_K1_POOL_CHUNK;
+                        int nb = 0;
+                        if (lane == 0) nb = atomicAdd(sp.ctr + 1, want);
+                        pl_next = wave_readlane(nb, 0); pl_end = pl_next + want;
+                        if (pl_end > sp.pool_cap) { if (lane == 0) sp.ctr[2] = 1; pl_end = pl_next; }
+                    }
+                    const bool fits = it_next + ng <= it_end && pl_next + pl_tot <= pl_end;   // else the overflow flag is up: the host redoes pass 1 in one kernel
+                    if (give && fits) {
+                        K1Item it;
+                        it.r = r; it.x = x; it.ret = cinfo; it.nlist = ncurr; it.ce = ce; it.emin = emin; it.list_off = pl_next + pl_pre; it.pad0 = it.pad1 = 0;
+                        sp.items[it_next + mine] = it;
+                        for (int e = 0; e < nl; ++e) sp.pool[it.list_off + e] = CURR[(uint32_t)e * T];
+                    }
+                    if (fits) { it_next += ng; pl_next += pl_tot; }
+                    if (give) { x = cinfo; st = S4_P1_SCAN; }
+                }
+            }
+            if (!FWD_ONLY && DO12 && st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
                 ret = cinfo; curA ^= 1; nprev = ncurr; rev = 1; have_mem = 0; last_mem_start = 0; i = x - 1;
 #ifdef LH_SMEM_TURNS
                 if (MODE == 3) {
@@ -440,20 +531,21 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     else { atomicAdd(&lh_dbg[27], 1); atomicAdd(&lh_dbg[28], nprev); if (x == 0) atomicAdd(&lh_dbg[29], 1); }
                 }
 #endif
-                BWD_ROW_BODY()
+                todo |= TD_ROW; st = S4_PENDING;
             }
-            if (DO12 && st == S4_BWD_EMIT0) {
+            if (DO12 && !FWD_ONLY && st == S4_BWD_EMIT0) {
                 if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
                 st = S4_SMEM_DONE;
             }
-            if (DO12 && st == S4_SMEM_DONE) {
-                if (phase == 1) { x = ret; st = S4_P1_SCAN; }
+            if (DO12 && !FWD_ONLY && st == S4_SMEM_DONE) {
+                if (BWD_ONLY) st = S4_FETCH;
+                else if (phase == 1) { x = ret; st = S4_P1_SCAN; }
                 else st = S4_P2_NEXT;
             }
             if (DO1 && st == S4_P1_SCAN) {   // first pass: all SMEMs
                 while (x < len && QB(x) > 3) ++x;
                 if (x >= len) { phase = 2; st = DO2 ? S4_P2_NEXT : S4_READ_DONE; }
-                else { min_intv = 1; START_SMEM1() }
+                else { min_intv = 1; todo |= TD_SMEM; st = S4_PENDING; }
             }
             if (DO2 && st == S4_P2_NEXT) {   // second pass: re-seed inside long, rare SMEMs of the first pass
                 st = S4_P3_SCAN; x = 0;
@@ -473,7 +565,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     if (filt && ix.rep_t && xm - (LH_BLOOM_K - 1) >= (int)(p.info >> 32) && xm + LH_BLOOM_K <= (int)(uint32_t)p.info) {
                         ld64 = p.x0; i = xm - (LH_BLOOM_K - 1) - (int)(p.info >> 32);
                         st = S4_P2_PROBE;
-                    } else START_SMEM1()
+                    } else { todo |= TD_SMEM; st = S4_PENDING; }
                     break;
                 }
             }
@@ -520,10 +612,20 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             }
             if (st == S4_READ_DONE) {
                 if (ovf) rst |= LH_ST_INTV_OVERFLOW;
-                n_intv[r] = on; status[r] = rst;
+                if (!FWD_ONLY) n_intv[r] = on;   // (MODE 5: the sweeps count the read's intervals)
+                status[r] = rst;
                 st = S4_FETCH;
             }
         }
+        // ---- B'. the shared blocks (see todo) ----
+        if (DO12 && (todo & TD_SMEM)) START_SMEM1()
+        if (DO12 && !FWD_ONLY && (todo & TD_ROW)) BWD_ROW_BODY()
+        if (DO12 && (todo & TD_FADV)) {
+            if (todo & TD_KEY) { int last_; WKEY_AT(i - 1, last_) (void)last_; }
+            BLOOM_ISSUE()
+            FWD_ADVANCE()
+        }
+        todo = 0;
         // ---- C. anything left to extend? ----
         if (!__any(st >= S4_REQ_FWD && st < 8)) {   // parked lanes advance in A / B of the next turn
             if (!__any(st != S4_DONE)) break;
@@ -616,9 +718,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i;
                 wkey = wkey >> 2 | (u64)(3 - ec) << (2 * LH_BLOOM_K - 2);   // the base just matched enters the window
                 if (runs && c2 == 1 && min_intv == 1) st = S4_FRUN_INIT;   // a single occurrence: follow it through the text (it ends the list: no filter)
-                else { BLOOM_ISSUE() FWD_ADVANCE() }
+                else { todo |= TD_FADV; st = S4_PENDING; }
             }
-        } else if (DO12 && st == S4_REQ_BWD) {
+        } else if (DO12 && !FWD_ONLY && st == S4_REQ_BWD) {
             if (ok.x2 < (u64)min_intv) {
                 if (ncurr == 0 && (!have_mem || i + 1 < last_mem_start)) st = S4_BWD_EMIT;   // no longer match survived, not contained in the previous MEM
             } else if (ncurr == 0 || ok.x2 != last_size) {
@@ -643,7 +745,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 cinfo = i;
                 st = S4_FRUN_END;
             }
-        } else if (DO1 && st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
+        } else if (DO1 && !FWD_ONLY && st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
             uint32_t qa, qb;
             Q8(i - 15, qa)
             Q8(i - 7, qb)
@@ -677,6 +779,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #undef T16_B
 #undef CURR
 #undef PREV
+#undef PREV_AT
 #undef START_SMEM1
 #undef WKEY_AT
 #undef BLOOM_ISSUE
@@ -686,12 +789,19 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #undef BWD_ROW_BODY
 #undef BWD_ADVANCE
 #undef EMIT_MEM
+    if (FWD_ONLY) for (int e = it_next + lane; e < it_end; e += 64) sp.items[e].r = -1;
     if (ctr) {
         unsigned tot = (unsigned)wave_sum_i32((int)n_ext_total);
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->n_ext, (u64)tot);
         unsigned ex = (unsigned)wave_sum_i32((int)n_exec_total);
-        if (lane == 0 && ex) atomicAdd(&LH_CTR(ctr)->n_ext_exec[MODE == 3 || MODE == 1 || MODE == 0 ? 0 : MODE == 4 ? 1 : 2], (u64)ex);
+        if (lane == 0 && ex) atomicAdd(&LH_CTR(ctr)->n_ext_exec[MODE == 3 || MODE == 1 || MODE == 0 || MODE == 5 || MODE == 6 ? 0 : MODE == 4 ? 1 : 2], (u64)ex);
         unsigned kx = (unsigned)wave_sum_i32((int)n_ktree_total);
-        if (lane == 0 && kx) atomicAdd(&LH_CTR(ctr)->n_ktree[MODE == 3 || MODE == 1 || MODE == 0 ? 0 : MODE == 4 ? 1 : 2], (u64)kx);
+        if (lane == 0 && kx) atomicAdd(&LH_CTR(ctr)->n_ktree[MODE == 3 || MODE == 1 || MODE == 0 || MODE == 5 || MODE == 6 ? 0 : MODE == 4 ? 1 : 2], (u64)kx);
     }
+}
+
+// after the sweeps of the split pass 1: a read's counter may have run past its array (the read is flagged; the one-kernel pass stops at the limit)
+__global__ void __launch_bounds__(256) k_clamp_intv(int n_reads, int32_t* __restrict__ n_intv) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads && n_intv[r] > LH_MAX_INTV) n_intv[r] = LH_MAX_INTV;
 }

@@ -100,12 +100,12 @@ def test_emu_k1_launch_variants_and_sweep_filter(emu, oracle):
     want_ext = oidx.align_barcodes(b, oracle.opts(run_inference=0)).counters["n_ext"]
     ctx = idx.context(rs.n_pairs)
     seen = {}
-    P12, FUSED, NOF = capi.LH_F_SMEM_P12, capi.LH_F_SMEM_FUSED, capi.LH_F_NO_SWEEP_FILTER
-    for flags in (0, P12, FUSED, NOF, NOF | FUSED):
+    P12, FUSED, NOF, SPLIT = capi.LH_F_SMEM_P12, capi.LH_F_SMEM_FUSED, capi.LH_F_NO_SWEEP_FILTER, capi.LH_F_SMEM_SPLIT
+    for flags in (0, SPLIT, P12, FUSED, NOF, NOF | FUSED, NOF | SPLIT):
         helpers.assert_same_dump(ctx.stage_dump(b, emu.opts(flags=flags)), want, helpers.DUMP_FRONT)
         seen[flags] = ctx.align_barcodes(b, emu.opts(run_inference=0, flags=flags)).counters["n_ext"]
-    assert seen[NOF] == want_ext == seen[NOF | FUSED]
-    assert seen[0] == seen[P12] == seen[FUSED] < want_ext
+    assert seen[NOF] == want_ext == seen[NOF | FUSED] == seen[NOF | SPLIT]
+    assert seen[0] == seen[P12] == seen[FUSED] == seen[SPLIT] < want_ext
 
 
 def test_emu_many_candidate_pairs_go_rng_ring(emu, oracle):
