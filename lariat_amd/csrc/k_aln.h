@@ -20,6 +20,10 @@ struct DCand {   // device-side result arrays (one entry per candidate unless no
     int32_t* matches; int32_t* mismatches; int32_t* indels; int32_t* soft_clipped; int32_t* soft_clipped_length; uint8_t* in_filtered;
     int32_t* n_cigar; uint32_t* cigar;   // LH_MAX_CIGAR slots per candidate
     int32_t* n_mm; int32_t* mm_ref; int32_t* mm_read;   // LH_MAX_MM slots per candidate
+    // a candidate with more mismatch loci than slots (a long noisy read: up to one per base) continues in a pool shared by the batch: locus
+    // k >= LH_MAX_MM of candidate c is entry mm_xoff[c] + k - LH_MAX_MM of mm_xref / mm_xread (space for the rest of the read is taken
+    // from *mm_xctr when slot LH_MAX_MM is first needed)
+    int32_t* mm_xoff; int32_t* mm_xref; int32_t* mm_xread; int32_t* mm_xctr; int32_t mm_xcap;
     double* lap;
     int32_t* read_len;   // per candidate (psuedoCountAlignmentScore needs len(read_seq))
 };
@@ -194,7 +198,7 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
             i64 refStart = Offset, refEnd = End;
             if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
             // CIGAR walk in READ orientation (lariat.go:1591-1632).  refSeq[k] == base at fwd||rev coordinate rb + k.
-            int matches = 0, indels = 0, indel_length = 0, soft_clipping = 0, soft_clipping_length = 0, refSeqOffset = 0, readOffset = 0, nmm = 0, mm_ovf = 0;
+            int matches = 0, indels = 0, indel_length = 0, soft_clipping = 0, soft_clipping_length = 0, refSeqOffset = 0, readOffset = 0, nmm = 0, mm_ovf = 0, xo = -2;
             int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
             int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
             int refLen = (int)(refEnd - refStart);
@@ -211,9 +215,19 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
                             mm = rbase != q[readOffset + t];
                         }
                         u64 bm = __ballot(mm);
+                        if (nmm + (int)__popcll(bm) > LH_MAX_MM && xo == -2) {   // the slots run out here: the rest of the loci go to the pool
+                            int v = 0;
+                            if (lane == 0) {
+                                v = atomicAdd(R.mm_xctr, l_query - LH_MAX_MM);
+                                if (v + l_query - LH_MAX_MM > R.mm_xcap) v = -1;
+                                R.mm_xoff[c] = v;
+                            }
+                            xo = wave_readlane(v, 0);
+                        }
                         if (mm) {
                             int slot = nmm + lanes_below(bm, lane);
                             if (slot < LH_MAX_MM) { mref[slot] = is_rev ? (int)refEnd - k : k + (int)refStart; mread[slot] = readOffset + t; }
+                            else if (xo >= 0) { R.mm_xref[xo + slot - LH_MAX_MM] = is_rev ? (int)refEnd - k : k + (int)refStart; R.mm_xread[xo + slot - LH_MAX_MM] = readOffset + t; }
                         }
                         nmm += __popcll(bm);
                     }
@@ -222,7 +236,7 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
                 else if (op == 2) { indels += 1; indel_length += len; refSeqOffset += len; }
                 else if (op == 3) { soft_clipping += 1; soft_clipping_length += len; readOffset += len; }
             }
-            if (nmm > LH_MAX_MM) { mm_ovf = 1; nmm = LH_MAX_MM; }
+            if (nmm > LH_MAX_MM && xo < 0) { mm_ovf = 1; nmm = LH_MAX_MM; }   // the pool is full as well
             if (lane < no) R.cigar[(size_t)c * LH_MAX_CIGAR + lane] = cgo[lane];
             if (lane == 0) {
                 int rid = dev_pos2rid(ix, posf);
@@ -316,7 +330,7 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                 int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
                 LaneTgt tg;
                 tg.init(ix, rb, 1);
-                int nmm = 0, n_amb = 0;   // n_amb: mismatching pairs with an ambiguous base (scored -1, not -b)
+                int nmm = 0, n_amb = 0, xo = -2;   // n_amb: mismatching pairs with an ambiguous base (scored -1, not -b)
                 for (int t0 = 0; t0 < lq; t0 += 16) {   // 16 query bases per round trip (the batch buffer is padded past the last read)
                     uint32_t qw[4];
                     __builtin_memcpy(qw, q + qb + t0, 16);
@@ -327,6 +341,14 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                             int rbase = tg.base(t), qv = (int)((qw[u >> 2] >> ((u & 3) * 8)) & 0xff);
                             if (rbase != qv) {
                                 if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
+                                else {   // (rare: the pool, see DCand)
+                                    if (xo == -2) {
+                                        xo = atomicAdd(R.mm_xctr, l_query - LH_MAX_MM);
+                                        if (xo + l_query - LH_MAX_MM > R.mm_xcap) xo = -1;
+                                        R.mm_xoff[c] = xo;
+                                    }
+                                    if (xo >= 0) { R.mm_xref[xo + nmm - LH_MAX_MM] = is_rev ? (int)refEnd - t : t + (int)refStart; R.mm_xread[xo + nmm - LH_MAX_MM] = qb + t; }
+                                }
                                 nmm++;
                                 n_amb += qv > 3;
                             }
@@ -359,6 +381,7 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                     } while (++it < 3 && S0 < ar.truesc - o.a);
                 }
                 int mm_ovf = 0;
+                if (nmm > LH_MAX_MM && xo < 0) { mm_ovf = 1; nmm = LH_MAX_MM; }   // (NM keeps the true count)
                 int clip5 = 0, clip3 = 0, no = 0;
                 if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
                 uint32_t* cgo = R.cigar + (size_t)c * LH_MAX_CIGAR;

@@ -7,14 +7,9 @@ import numpy as np
 import helpers, oracle_py
 from lariat_amd import capi, synth
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-lib = capi.load_library()
-oracle = oracle_py.load()
-t_end = time.time() + budget
-it = 0
-while time.time() < t_end:
-    seed = seed0 + it
+
+def run_case(lib, oracle, seed):
+    """one random genome / index path / read set / option set, product against oracle; raises on a difference"""
     rng = np.random.default_rng(seed)
     ncont = int(rng.integers(1, 5))
     lens = [int(rng.integers(60000, 400000)) for _ in range(ncont)]
@@ -49,13 +44,28 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         kw = dict(b=int(rng.integers(2, 7)), o_del=int(rng.integers(3, 9)), o_ins=int(rng.integers(3, 9)), e_del=int(rng.integers(1, 3)), e_ins=int(rng.integers(1, 3)),
                   w=int(rng.choice([20, 100])), zdrop=int(rng.choice([50, 100])), min_seed_len=int(rng.choice([15, 19, 25])))
+    what = "contigs %s, reads %dx%d/%d, opts %s, index %s" % (lens, l1, l2, rs.n_pairs, kw, iopts)
     try:
         ctx = idx.context(rs.n_pairs)
         okw = {k: v for k, v in kw.items() if k != "flags"}
         helpers.assert_same_dump(ctx.stage_dump(b, lib.opts(**kw)), oidx.stage_dump(b, oracle.opts(**okw)), helpers.DUMP_FRONT + helpers.DUMP_REGS)
         helpers.assert_same_result(ctx.align_barcodes(b, lib.opts(**kw)), oidx.align_barcodes(b, oracle.opts(**okw), threads=16), inference=True)
     except Exception as e:
-        print("DIFF at seed %d (contigs %s, reads %dx%d/%d, opts %s, index %s): %s" % (seed, lens, l1, l2, rs.n_pairs, kw, iopts, str(e)[:600]), flush=True)
-        sys.exit(1)
-    it += 1
-print("fuzz ok: %d cases from seed %d in %.0f s" % (it, seed0, budget))
+        raise AssertionError("seed %d (%s): %s" % (seed, what, str(e)[:600]))
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    lib = capi.load_library()
+    oracle = oracle_py.load()
+    t_end = time.time() + budget
+    it = 0
+    while time.time() < t_end:
+        try:
+            run_case(lib, oracle, seed0 + it)
+        except AssertionError as e:
+            print("DIFF at " + str(e), flush=True)
+            sys.exit(1)
+        it += 1
+    print("fuzz ok: %d cases from seed %d in %.0f s" % (it, seed0, budget))

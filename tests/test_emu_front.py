@@ -232,3 +232,4 @@ def test_emu_large_barcode_position_sort(emu, oracle):
     ref = oidx.align_barcodes(b)
     assert int((ref.in_filtered != 0).sum()) > 800   # past LH_RFA_SORT_LDS
     helpers.assert_same_result(idx.context(rs.n_pairs).align_barcodes(b), ref, inference=True)
+

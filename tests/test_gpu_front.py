@@ -52,3 +52,14 @@ def test_get_seq(lib, oracle):
     """lh_get_seq == GoBwaReference.GetSeq (gobwa.go:50-80): reference vector + windows over contig ends, both strands"""
     from test_emu_front import _check_get_seq
     _check_get_seq(lib, oracle)
+
+
+def test_fuzz_regressions(lib, oracle):
+    """cases the differential fuzzer (tests/checkers/fuzz_gpu.py) once found: seed 72337 holds a 235-base read with a candidate of 89
+    mismatch loci — past the 64 slots per candidate, continued in the batch's pool (k_aln.h DCand::mm_x*)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(helpers.ROOT, "tests", "checkers"))
+    import fuzz_gpu
+    for seed in (72337,):
+        fuzz_gpu.run_case(lib, oracle, seed)
