@@ -175,6 +175,17 @@ def main():
         ctx.close()   # its pools and the resident batches (~70 GB next to the 131 GB index) make room for the informational runs
         if not a.no_extras:
             out.update(extras(lib, idx, first[1], n_pairs, opts, elapsed / max(1, len(my_batches))))
+            alone = out.get("single_lane_kernel_ms", {}).get("k_smem4")
+            rf = out["roofline"]
+            if alone and rf.get("pairs_per_launch"):   # the same kernel without the other lane's launches beside it (one launch = the whole batch)
+                scale = n_pairs / rf["pairs_per_launch"]
+                rf["alone"] = {"pairs_per_launch": n_pairs, "launch_ms": alone, "achieved": round(rf["algorithmic_bytes_per_launch"] * scale / (alone * 1e-3) / 1e9, 2)}
+                rf["alone"]["frac"] = round(rf["alone"]["achieved"] / HBM_PEAK_GBPS, 5)
+                if rf.get("traffic"):
+                    rf["alone"]["traffic_GBps"] = round(rf["traffic"] * scale / (alone * 1e-3) / 1e9, 2)
+                    rf["alone"]["traffic_frac"] = round(rf["alone"]["traffic_GBps"] / HBM_PEAK_GBPS, 5)
+                if rf.get("l2_misses_per_s_G"):
+                    rf["alone"]["request_rate_frac"] = round(rf["l2_misses_per_s_G"] * rf["avg_launch_ms"] * scale / alone / rf["request_rate_ceiling_G"], 4)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, idx, pac, first[0])
         print(json.dumps(out), flush=True)
@@ -194,7 +205,9 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
     passes, committed as profiles/r02_pmc_bench.json with the commit it was measured at); traffic_frac is what the judge can
     recompute from profiles/.  reference_work_equiv is the reference's bookkeeping (64 B x ALL its bwt_extend calls) priced
     at this kernel's time: how much of the reference's traffic the filters make unnecessary, not a bandwidth."""
-    dom = max(avg, key=avg.get)
+    # the roofline is reported for K1 pass 1: the largest memory-bound kernel and the one the occurrence-table traffic of north_star is about
+    # (K4's lane kernels take as long per step, but they are integer DP out of LDS: neither an HBM nor an MFMA roofline applies to them)
+    dom = "k_smem4" if "k_smem4" in avg else max(avg, key=avg.get)
     share = 1.0 / a.lanes   # a launch of the timed lane covers this share of the step's pairs (uniform barcodes: the cut is at the middle)
     k1 = {"k_smem4": ("k_smem4_t<3>", "n_ext_exec_p1", "n_ktree_p1"), "k_smem4_p2": ("k_smem4_t<4>", "n_ext_exec_p2", "n_ktree_p2"),
           "k_smem4_p3": ("k_smem4_t<2>", "n_ext_exec_p3", "n_ktree_p3")}
@@ -233,6 +246,7 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
             if k.get("TCC_MISS") and pmc.get("random_read_ceiling_Gaccess_per_s"):
                 r["l2_misses_per_s_G"] = round(k["TCC_MISS"] / k["calls"] / (ms * 1e-3) / 1e9, 2)
                 r["request_rate_ceiling_G"] = pmc["random_read_ceiling_Gaccess_per_s"]
+                r["request_rate_frac"] = round(r["l2_misses_per_s_G"] / r["request_rate_ceiling_G"], 4)   # of what independent random 32-B reads reach
     r["traffic"] = traffic
     # the whole K1 stage in the reference's bookkeeping (informational)
     k1_ms = sum(avg.get(k, 0.0) for k in k1)
@@ -266,6 +280,7 @@ def extras(lib, idx, batch, n_pairs, opts, step_s):
         for _ in range(4):
             c1.align_resident(opts)
         out["single_lane_pairs_per_s"] = round(4 * n_pairs / (time.perf_counter() - t0), 1)
+        out["single_lane_kernel_ms"] = {k: round(v, 3) for k, v in c1.timings()}   # every kernel with the device to itself, one launch = the whole batch
         c1.close()
     except Exception as e:
         out["single_lane_pairs_per_s"] = "failed: %s" % e
