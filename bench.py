@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--pairs-per-barcode", type=int, default=100)
     ap.add_argument("--lanes", type=int, default=2, help="lh_context_opts.lanes: 2 = every batch is cut at a barcode boundary and its two halves are aligned "
                                                           "side by side inside ONE lh_align_resident call (1 = one pipeline)")
+    ap.add_argument("--repeats", action="store_true", help="configs[4]-like input on this GPU: segmental duplications and repeat families planted in the genome, every read drawn "
+                                                              "from on and around them (several candidates per read; informational, not the headline workload)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --steps batches in total, split over the ranks (default weak: --steps per rank)")
     ap.add_argument("--cpu-sample-barcodes", type=int, default=10000, help="barcodes of the first batch timed on the host cores (cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,6 +94,11 @@ def main():
     ctg = workload.hg38_like_contigs(int(a.genome_mb * 1e6))
     l_pac = sum(c[1] for c in ctg)
     pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED, threads=max(1, (os.cpu_count() or 8) // max(1, world)))
+    read_ctg = ctg
+    if a.repeats:
+        dups = workload.plant_segdups(pac, ctg, 1500, 20000, 0.99, seed=41, n_families=40, family_len=320, family_copies=60)
+        dups += workload.plant_segdups(pac, ctg, 300, 20000, 1.0, seed=42)
+        read_ctg = workload.repeat_windows(ctg, dups[:1500] + dups[-300:], flank=50000)
     t_genome = time.time() - t0
     t0 = time.time()
     idx = lib.index_build_device(pac, l_pac, ctg, device=local_rank)
@@ -112,7 +119,7 @@ def main():
     for slot, g in enumerate(my_batches):
         if slot and lib.device_memory(local_rank)[0] < (16 << 30):   # leave room for the kernels' scratch: later steps reuse the resident batches in turn
             break
-        r = lib.synth_reads(pac, l_pac, ctg, seed=workload.READS_SEED + g, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode,
+        r = lib.synth_reads(pac, l_pac, read_ctg, seed=workload.READS_SEED + g, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode,
                             threads=max(1, (os.cpu_count() or 8) // max(1, world)))
         b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
         ctx.upload_slot(slot, b)
@@ -159,7 +166,9 @@ def main():
             "value": round(value, 1), "unit": "read-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / max(1, len(my_batches)) * 1e3, 3), "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": "u64/i32 (FM-index + integer DP), f64 (RFA scores)", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: hg38-scale synthetic genome (%.0f Mb in 24 contigs, seed %d, index built in HBM by lh_index_build_device), "
+            "config": {"workload": ("BASELINE.json configs[4]-like on one GPU: 1,800 planted 20-kb segmental duplications (99 % / 100 %) + 40 repeat families, reads drawn from on and around them; "
+                                    if a.repeats else "BASELINE.json configs[2]: ") +
+                                   "hg38-scale synthetic genome (%.0f Mb in 24 contigs, seed %d, index built in HBM by lh_index_build_device), "
                                    "%d steps x %d pairs 2x150 (143+150 post-trim) / %d barcodes per step per GPU, every step a different batch, RFA on device"
                                    % (l_pac / 1e6, workload.GENOME_SEED, a.steps, n_pairs, a.barcodes),
                        "pairs_per_step": n_pairs, "barcodes_per_step": a.barcodes, "genome_bases": l_pac, "suffix_array_interval": idx.sa_interval,

@@ -19,3 +19,66 @@ def hg38_like_contigs(total_bases):
         out.append((name, n, off))
         off += n
     return out
+
+
+def plant_segdups(pac, contigs, n_dup, dup_len, identity, seed, n_families=0, family_len=300, family_copies=0):
+    """configs[4]-like repeat structure on a packed genome (4 bases per byte, as lh_synth_genome writes it), in place: `n_dup`
+    segmental duplications of `dup_len` bases at `identity` (substitutions only; sources and copies are multiples of 4 so that the copy
+    is a byte copy), plus `n_families` interspersed-repeat families of `family_copies` copies each.  Returns [(src, dst, len)] in
+    global coordinates (the windows that reads biased to repeats are drawn from, see repeat_windows)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lens = np.array([c[1] for c in contigs], dtype=np.int64)
+    offs = np.array([c[2] for c in contigs], dtype=np.int64)
+    w = lens / lens.sum()
+
+    def place(n_bases):
+        k = int(rng.choice(len(contigs), p=w))
+        p = int(rng.integers(0, max(1, (lens[k] - n_bases) // 4))) * 4
+        return int(offs[k] + p)
+
+    def copy(src, dst, n, ident):
+        seg = pac[src >> 2:(src + n) >> 2].copy()
+        n_mut = int(round((1.0 - ident) * n))
+        if n_mut:
+            at = rng.integers(0, n, size=n_mut)
+            delta = rng.integers(1, 4, size=n_mut).astype(np.uint8)            # a different base: add 1..3 mod 4 to the 2-bit code
+            sh = ((~at & 3) << 1).astype(np.uint8)
+            for a, d, s_ in zip(at, delta, sh):                                  # (few thousand per copy)
+                b = int(seg[a >> 2])
+                code = ((b >> int(s_)) + int(d)) & 3
+                seg[a >> 2] = (b & ~(3 << int(s_)) & 0xff) | (code << int(s_))
+        pac[dst >> 2:(dst + n) >> 2] = seg
+
+    out = []
+    dup_len = dup_len // 4 * 4
+    for _ in range(n_dup):
+        src, dst = place(dup_len), place(dup_len)
+        if abs(src - dst) < dup_len:
+            continue
+        copy(src, dst, dup_len, identity)
+        out.append((src, dst, dup_len))
+    family_len = family_len // 4 * 4
+    for _ in range(n_families):
+        src = place(family_len)
+        for _ in range(family_copies):
+            dst = place(family_len)
+            if abs(src - dst) >= family_len:
+                copy(src, dst, family_len, float(rng.uniform(0.9, 1.0)))
+                out.append((src, dst, family_len))
+    return out
+
+
+def repeat_windows(contigs, dups, flank=60000):
+    """[(name, len, offset)] of windows around both copies of every planted repeat, clipped to their contigs: passed to lh_synth_reads as
+    its contig list, the molecules (and so the reads) fall on and around the repeats"""
+    out = []
+    for k, (src, dst, n) in enumerate(dups):
+        for tag, p in (("s", src), ("d", dst)):
+            for name, ln, off in contigs:
+                if off <= p < off + ln:
+                    b = max(off, p - flank) // 4 * 4
+                    e = min(off + ln, p + n + flank)
+                    out.append(("%s%d" % (tag, k), int(e - b), int(b)))
+                    break
+    return out

@@ -5,6 +5,7 @@
   work units of the reference's own size: barcodes of 5,000 and 30,000 pairs (fastqreader/reader.go:205 caps a set at 30,000)
   configs[2]  hg38-scale genome (3.1 Gb, index built in HBM): index self-check, oracle parity on a sample of barcodes, and
               size-independent properties on a whole 1 M-pair batch (idempotence; barcode-range split == whole batch)
+  configs[4]  (one GPU) the same size with planted segmental duplications and repeat families, reads drawn from on and around them
 
 Integer / index fields bit-exact, MAPQ within +-1, float scores within 1e-9 relative (helpers.assert_same_result).
 """
@@ -144,3 +145,36 @@ def test_config2_hg38_scale(lib, oracle):
         n = {"cand_off": 2 * ph + 1, "cigar_off": nc + 1, "mm_off": nc + 1, "cigar": int(res.cigar_off[nc]), "mm_ref_loc": int(res.mm_off[nc]),
              "mm_read_loc": int(res.mm_off[nc])}.get(f, nc)
         assert np.array_equal(a[:n], w[:n]), f
+
+
+def test_config4_like_segdup_biased(lib, oracle):
+    """configs[4] on one GPU: the hg38-scale genome with planted segmental duplications (1,500 x 20 kb at 99 %, 300 x 20 kb identical)
+    and interspersed repeat families, every read drawn from on and around them — several candidates per read, equal pair scores
+    (Go's generator decides), the RFA stress case: a sample of barcodes against the oracle on the same index, every field"""
+    ctg = workload.hg38_like_contigs(3100000000)
+    l_pac = sum(c[1] for c in ctg)
+    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED + 4)
+    dups = workload.plant_segdups(pac, ctg, 1500, 20000, 0.99, seed=41, n_families=40, family_len=320, family_copies=60)
+    dups += workload.plant_segdups(pac, ctg, 300, 20000, 1.0, seed=42)
+    idx = lib.index_build_device(pac, l_pac, ctg)
+    win = workload.repeat_windows(ctg, dups[:1500] + dups[-300:], flank=50000)
+    r = lib.synth_reads(pac, l_pac, win, seed=workload.READS_SEED + 4, n_barcodes=3000, pairs_per_barcode=100, sub_hi=0.02, junk_frac=0.01)
+    b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
+    ctx = idx.context(r["n_pairs"])
+    t0 = time.time()
+    res = ctx.align_barcodes(b)
+    dt = time.time() - t0
+    nf = np.add.reduceat(res.in_filtered.astype(np.int64), res.cand_off[:-1])
+    multi = float((nf >= 2).mean())
+    print("segdup-biased reads: %d pairs in %.2f s, %.1f candidates per read, %.0f %% of the reads with two or more equally plausible ones"
+          % (r["n_pairs"], dt, res.n_cand / res.n_reads, 100 * multi))
+    assert multi > 0.15
+    oidx = oracle.index_from_arrays(idx.export(), pac)
+    nb = 300
+    p1 = int(r["bc_pair_off"][nb])
+    sub = capi.Batch.from_arrays(r["seq"][: r["seq_off"][2 * p1]], r["seq_off"][: 2 * p1 + 1], r["bc_pair_off"][: nb + 1], r["name_seed"][:p1])
+    ref = oidx.align_barcodes(sub, threads=THREADS)
+    got = idx.context(p1).align_barcodes(sub)
+    helpers.assert_same_result(got, ref, inference=True)
+    again = ctx.align_barcodes(b)
+    helpers.assert_same_result(again, res, inference=True, mapq_tol=0, rel=0)
