@@ -272,6 +272,11 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
             int32_t* od = ord + base;
             int32_t* st = srt + base;
             int nch = 0;
+            // the chain the previous seed was tested against stays in registers (cc, index cci; dirty = it differs from C[cci]): consecutive
+            // seeds of a read mostly meet the same chain, and every field update used to be a store of its own
+            DChainTmp cc;
+            cc.pos = 0; cc.last_rbeg = 0; cc.first_qbeg = cc.last_qbeg = cc.last_len = cc.rid = cc.n = cc.head = cc.tail = cc.w = cc.kept = cc.first = cc.beg = cc.end = 0;
+            int cci = -1, dirty = 0;
             for (int s = 0; s < S; ++s) {
                 int rid = rid_[s];
                 if (rid < 0) continue;   // bridging contigs / the forward-reverse boundary
@@ -279,10 +284,14 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
                 int to_add = 1, lo = 0;
                 if (nch > 0) {
                     int hi = nch;
-                    while (lo < hi) { int m = (lo + hi) >> 1; if (C[od[m]].pos <= p.rbeg) lo = m + 1; else hi = m; }
+                    while (lo < hi) { int m = (lo + hi) >> 1; if (C[od[m]].pos <= p.rbeg) lo = m + 1; else hi = m; }   // (pos never changes once a chain exists)
                     if (lo > 0) {
                         int ci = od[lo - 1];
-                        DChainTmp c = C[ci];
+                        if (ci != cci) {
+                            if (dirty) C[cci] = cc;
+                            cc = C[ci]; cci = ci; dirty = 0;
+                        }
+                        const DChainTmp c = cc;
                         i64 qend = c.last_qbeg + c.last_len, rend = c.last_rbeg + c.last_len;   // test_and_merge
                         int res = 0;   // 0: new chain, 1: contained, 2: appended
                         if (rid != c.rid) res = 0;
@@ -294,7 +303,8 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
                         }
                         if (res == 2) {
                             nx[c.tail] = s; nx[s] = -1;
-                            C[ci].tail = s; C[ci].n = c.n + 1; C[ci].last_rbeg = p.rbeg; C[ci].last_qbeg = p.qbeg; C[ci].last_len = p.len;
+                            cc.tail = s; cc.n = c.n + 1; cc.last_rbeg = p.rbeg; cc.last_qbeg = p.qbeg; cc.last_len = p.len;
+                            dirty = 1;
                         }
                         to_add = (res == 0);
                     }
@@ -310,6 +320,7 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
                     nch++;
                 }
             }
+            if (dirty) C[cci] = cc;
             for (int k = 0; k < nch; ++k) {   // mem_chain_weight, chn_beg / chn_end
                 DChainTmp c = C[k];
                 int w = 0;
