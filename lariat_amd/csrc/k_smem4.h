@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     // LCP shortcut of the backward sweep (pass 1): emin = end of the first entry pushed to the forward list (the shortest string),
     // tri = the unique run in progress stands for a list of several entries, tri_failed = it was tried for this SMEM and did not apply
     int emin = 0, tri = 0, tri_failed = 0;
+    uint32_t pbits = 0;   // pass 2, a call that passed the probe (S4_P2_PROBE): bit k = the LH_BLOOM_K-mer ending at read position x + 1 + k occurs again in the text
     // The blocks that several states lead to — the start of a bwt_smem1a call, the start of a backward row, the next step of a
     // forward walk — exist ONCE, between the transitions and the extensions of a turn; a state that needs one sets its bit in todo and
     // parks the lane (S4_PENDING) instead of carrying a copy of the block (the compiler pays for every copy, and for every level of
@@ -205,7 +206,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #define BLOOM_ISSUE()                                                                                        \
     {                                                                                                        \
         bword = 0; bmask = filt ? 1 : 0;   /* no filter: keep; window not all bases (or read start): drop */ \
-        if (filt && cinfo >= filt_from) {                                                                    \
+        if (pbits && cinfo - x <= LH_BLOOM_K) bword = (pbits >> (cinfo - x - 1)) & 1;   /* pass 2 after the probe: the text's own bit for this window (exact: no filter read) */ \
+        else if (filt && cinfo >= filt_from) {                                                               \
             uint32_t w_;                                                                                     \
             if (min_intv == 1) { dev_bloom_slot(wkey, ix.bloom1_words, &w_, &bmask); bword = ix.bloom1[w_]; } \
             else { dev_bloom_slot(wkey, ix.bloom2_words, &w_, &bmask); bword = ix.bloom2[w_]; }              \
@@ -247,7 +249,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             a_ &= 0x44444444u; b_ &= 0x44444444u;                                                            \
             int v_ = a_ ? (__ffs((int)a_) - 1) >> 2 : 8 + (b_ ? (__ffs((int)b_) - 1) >> 2 : 8);   /* valid bases from x on */ \
             J_ = ktl < v_ ? ktl : v_;                                                                        \
-            if (filt_from - x < J_) J_ = filt_from - x;                                                      \
+            const int lim_ = pbits ? __ffs((int)pbits) : filt_from - x;   /* the first level whose interval could be pushed */ \
+            if (lim_ < J_) J_ = lim_;                                                                        \
         }                                                                                                    \
         if (J_ >= 2) {                                                                                       \
             uint32_t cd_;                                                                                    \
@@ -429,7 +432,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             }
             else if (DO2 && st == S4_P2_PROBE3) {
                 const u64 bits = tw_sh ? (pn.lo >> tw_sh) | (pn.hi << (64 - tw_sh)) : pn.lo;
-                if (bits & ((1ull << LH_BLOOM_K) - 1)) { todo |= TD_SMEM; st = S4_PENDING; }
+                pbits = (uint32_t)(bits & ((1ull << LH_BLOOM_K) - 1));   // the walk's first LH_BLOOM_K filter decisions, and how far it may jump
+                if (pbits) { todo |= TD_SMEM; st = S4_PENDING; }
                 else st = S4_P2_NEXT;
             }
             else if (DO3 && st == S4_P3_JUMP) { pn = kt ? kt[ld64] : ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
@@ -545,7 +549,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             if (DO1 && st == S4_P1_SCAN) {   // first pass: all SMEMs
                 while (x < len && QB(x) > 3) ++x;
                 if (x >= len) { phase = 2; st = DO2 ? S4_P2_NEXT : S4_READ_DONE; }
-                else { min_intv = 1; todo |= TD_SMEM; st = S4_PENDING; }
+                else { min_intv = 1; pbits = 0; todo |= TD_SMEM; st = S4_PENDING; }
             }
             if (DO2 && st == S4_P2_NEXT) {   // second pass: re-seed inside long, rare SMEMs of the first pass
                 st = S4_P3_SCAN; x = 0;
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     if (filt && ix.rep_t && xm - (LH_BLOOM_K - 1) >= (int)(p.info >> 32) && xm + LH_BLOOM_K <= (int)(uint32_t)p.info) {
                         ld64 = p.x0; i = xm - (LH_BLOOM_K - 1) - (int)(p.info >> 32);
                         st = S4_P2_PROBE;
-                    } else { todo |= TD_SMEM; st = S4_PENDING; }
+                    } else { pbits = 0; todo |= TD_SMEM; st = S4_PENDING; }
                     break;
                 }
             }
