@@ -183,9 +183,9 @@ def main():
             "setup_s": {"genome": round(t_genome, 2), "index_build_device": round(t_index, 2), "reads_synth+upload(all steps)": round(t_reads_upload, 2)},
         }
         ctx.close()   # its pools and the resident batches (~70 GB next to the 131 GB index) make room for the informational runs
-        if not a.no_extras:
+        if not a.no_extras and world == 1:   # the informational legs and the CPU baseline: on the single-GPU run only
             out.update(extras(lib, idx, first[1], n_pairs, opts, elapsed / max(1, len(my_batches))))
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, idx, pac, first[0])
         print(json.dumps(out), flush=True)
     if dist is not None:
