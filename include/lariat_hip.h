@@ -327,6 +327,10 @@ int lh_synth_reads(const uint8_t* pac, int64_t l_pac, int32_t n_contigs, const i
 /* diagnostics: the device's restatement of Go's math/rand source (the jitter stream of tagBestAlignments, lariat.go:1486,
  * 1499,1510): n draws of rand.New(rand.NewSource(seed)) as Uint64 — out_fast from K8's state-free path (first min(n,273)
  * draws, the rest 0), out_ring from its state ring — and as Float64 (out_f64). */
+/* diagnostics: Go 1.9's sort.Sort as K8 restates it (lariat.go:1546 ByPosition; its order of equal keys is part of the result): n_sorts
+ * index spaces [first[k], first[k+1]) of keys[] (first[0] = 0) sorted by the serial restatement (one sort per lane) and by the wave-wide one;
+ * each returns the permutation of every index space (position -> original index inside its space) */
+int lh_diag_gosort(int device, int32_t n_sorts, const int32_t* first, const int64_t* keys, int32_t* perm_serial, int32_t* perm_wave);
 int lh_diag_go_rand(int device, int64_t seed, int32_t n, uint64_t* out_fast, uint64_t* out_ring, double* out_f64);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -82,3 +82,21 @@ __global__ void __launch_bounds__(256) k_diag_digest(const uint8_t* __restrict__
     if (a) atomicAdd(&out[0], a);
     if (b) atomicAdd(&out[1], b);
 }
+
+// Go's sort.Sort as K8 runs it (lh_sort.h): `n_sorts` index spaces of keys[] sorted (a) one sort per lane by the serial restatement,
+// into perm_serial, (b) all at once by the wave-wide one, into perm_wave.  Both must issue Go's Less / Swap sequence per range: equal
+// keys end up where Go leaves them.  q*: the wave-wide sort's queue of ranges (n ints each).
+__global__ void __launch_bounds__(64) k_diag_gosort(int n_sorts, const int32_t* __restrict__ first, i64* __restrict__ keys_a, int32_t* __restrict__ perm_serial,
+                                                    i64* __restrict__ keys_b, int32_t* __restrict__ perm_wave, int32_t* __restrict__ qa, int32_t* __restrict__ qb,
+                                                    int32_t* __restrict__ qd) {
+    const int lane = LANE();
+    for (int k = lane; k < n_sorts; k += 64) {
+        i64* kp = keys_a + first[k];
+        int32_t* ip = perm_serial + first[k];
+        dev_gosort(first[k + 1] - first[k], [&](int i, int j) { return kp[i] < kp[j]; },
+                   [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; });
+    }
+    WAVE_SYNC();
+    wave_gosort(n_sorts, first, [&](int i, int j) { return keys_b[i] < keys_b[j]; },
+                [&](int i, int j) { i64 t = keys_b[i]; keys_b[i] = keys_b[j]; keys_b[j] = t; int u = perm_wave[i]; perm_wave[i] = perm_wave[j]; perm_wave[j] = u; }, qa, qb, qd);
+}

@@ -12,6 +12,7 @@
 #include "../include/lariat_hip.h"
 #include "lariat_oracle.h"
 
+#include "gosort_impl.h"
 using namespace orc;
 
 namespace {
@@ -65,6 +66,17 @@ const char* lo_last_error() { return g_err.c_str(); }
 void lo_go_rand_stream(int64_t seed, int32_t n, int64_t* int63_out, double* float64_out) {
     if (int63_out) { orc::GoRand g(seed); for (int i = 0; i < n; ++i) int63_out[i] = g.int63(); }
     if (float64_out) { orc::GoRand g(seed); for (int i = 0; i < n; ++i) float64_out[i] = g.float64(); }
+}
+
+// Go 1.9's sort.Sort over `n_sorts` index spaces [first[k], first[k + 1]) of keys[]: perm[] starts as the identity and is swapped along
+// with the keys (tests/test_sort.py checks the device's serial and wave-wide restatements against it)
+void lo_gosort(int32_t n_sorts, const int32_t* first, int64_t* keys, int32_t* perm) {
+    for (int k = 0; k < n_sorts; ++k) {
+        int64_t* kp = keys + first[k];
+        int32_t* ip = perm + first[k];
+        orc::go19_sort(first[k + 1] - first[k], [&](int i, int j) { return kp[i] < kp[j]; },
+                       [&](int i, int j) { std::swap(kp[i], kp[j]); std::swap(ip[i], ip[j]); });
+    }
 }
 
 void lo_opts_init(lh_opts* o) {

@@ -63,3 +63,9 @@ def test_fuzz_regressions(lib, oracle):
     import fuzz_gpu
     for seed in (72337,):
         fuzz_gpu.run_case(lib, oracle, seed)
+
+
+def test_gosort_serial_and_wave(lib, oracle):
+    """K8's two restatements of Go's sort.Sort (equal keys end up where Go leaves them) against the oracle's, on the GPU"""
+    import test_sort
+    test_sort.check(lib, oracle)

@@ -1,0 +1,57 @@
+"""Go 1.9's sort.Sort (go/src/inference/lariat.go:1546 ByPosition, split.go:108): its order of EQUAL keys is part of lariat's result,
+so K8 restates the algorithm — serially (lh_sort.h dev_gosort) and, for large barcodes, with the ranges of its quickSort spread over
+the lanes of the wave (wave_gosort).  Both against the oracle's restatement (oracle/gosort_impl.h), on the kernel sources under the
+CPU emulator here and on the GPU in test_gpu_front.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from lariat_amd import capi
+
+EMU = os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "hipemu")])
+    return capi.Library(EMU)
+
+
+def oracle_perm(oracle, first, keys):
+    first = np.ascontiguousarray(first, dtype=np.int32)
+    k = np.ascontiguousarray(keys, dtype=np.int64).copy()
+    perm = np.concatenate([np.arange(first[i + 1] - first[i], dtype=np.int32) for i in range(len(first) - 1)])
+    oracle.L.lo_gosort.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    oracle.L.lo_gosort.restype = None
+    oracle.L.lo_gosort(len(first) - 1, first.ctypes.data_as(C.POINTER(C.c_int32)), k.ctypes.data_as(C.POINTER(C.c_int64)), perm.ctypes.data_as(C.POINTER(C.c_int32)))
+    return perm, k
+
+
+def cases():
+    rng = np.random.default_rng(12)
+    out = []
+    for sizes, hi in (([0, 1, 2, 5, 12, 13, 40, 41, 100], 6), ([700, 3, 1500], 40), ([2500], 3), ([300] * 70, 10), ([5000], 1 << 40)):
+        first = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        keys = rng.integers(0, hi, size=int(first[-1]))   # few distinct values: ties everywhere
+        out.append((first, keys))
+    n = 3000   # runs already sorted, reversed, and a sawtooth: the patterns that drive quickSort towards its depth limit
+    out.append((np.array([0, n, 2 * n, 3 * n], dtype=np.int32), np.concatenate([np.arange(n), np.arange(n)[::-1], np.arange(n) % 7])))
+    return out
+
+
+def check(lib, oracle):
+    for first, keys in cases():
+        want, sorted_keys = oracle_perm(oracle, first, keys)
+        ps, pw = lib.diag_gosort(first, keys)
+        assert np.array_equal(ps, want) and np.array_equal(pw, want)
+        for k in range(len(first) - 1):   # and it IS a sort
+            a, b = int(first[k]), int(first[k + 1])
+            assert np.array_equal(np.asarray(keys[a:b])[want[a:b]], sorted_keys[a:b]) and np.all(np.diff(sorted_keys[a:b]) >= 0)
+
+
+def test_emu_gosort_serial_and_wave(emu, oracle):
+    check(emu, oracle)
