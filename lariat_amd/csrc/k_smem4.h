@@ -76,6 +76,12 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_P2_PROBE2 31
 #define S4_P2_PROBE3 32
 #define S4_FETCH_SKIP 33
+#define S4_P3_PREP 35     // pass 3 by text (MODE 2, see P3TEXT): positions of the read's unique SMEMs, then one walk = three table reads
+#define S4_P3_PREP2 36
+#define S4_P3_PREP3 37
+#define S4_P3_T0 38
+#define S4_P3_T1 39
+#define S4_P3_T2 40
 #define S4_PENDING 34     // one of the shared blocks below runs for this lane before the turn's extensions (todo says which)
 #define TD_ROW 1          // BWD_ROW_BODY
 #define TD_SMEM 2         // START_SMEM1
@@ -114,6 +120,21 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                                                int32_t* __restrict__ next_read, DCounters* __restrict__ ctr, K1Split sp) {
     __shared__ uint32_t qn[32 * 64];
     constexpr bool FWD_ONLY = MODE == 5, BWD_ONLY = MODE == 6;
+    constexpr bool P3T = MODE == 2;
+    // PASS 3 BY TEXT (the pass-3 kernel, with a dense suffix array).  A walk of bwt_seed_strategy1 from x ends at the first length
+    // L >= min_seed_len + 1 where the match occurs fewer than max_mem_intv times.  If [x, x + Lw), Lw = min_seed_len + 1, lies inside a
+    // UNIQUE SMEM of the read (pass 1 left it in the read's interval array; its text position is one suffix-array read per SMEM), the
+    // read equals the text there: the Lw-mer's row is the inverse suffix array at that position, it is unique iff both LCP neighbours
+    // of the row share fewer than Lw bases, and then the walk's result is (that row, the row of the reverse strand's copy, 1) at
+    // length exactly Lw — three table reads instead of a tree read and six occurrence records.  Anything else: the walk as written.
+#ifdef LH_NO_P3TEXT   // A/B builds
+    const bool P3TEXT = false;
+#else
+    const bool P3TEXT = P3T && ix.isa != nullptr && ix.lcp != nullptr && o.max_mem_intv > 1;
+#endif
+    const int Lw = o.min_seed_len + 1;
+    int us0 = 0, ue0 = 0, us1 = 0, ue1 = 0, p3_notext = 0;   // the read's two longest unique SMEMs [us, ue), at text positions up0 / up1
+    u64 up0 = 0, up1 = 0;
     constexpr bool DO1 = MODE == 0 || MODE == 1 || MODE == 3 || MODE == 5 || MODE == 6, DO2 = MODE == 0 || MODE == 1 || MODE == 4, DO12 = DO1 || DO2, DO3 = MODE == 0 || MODE == 2;
     const int lane = LANE();
     const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)lane;
@@ -394,6 +415,17 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 if (!DO1) { on = n_intv[r]; rst |= status[r]; }   // continue behind the intervals of the earlier passes
                 if (len >= o.min_seed_len) { x = 0; phase = DO1 ? 1 : 2; st = DO1 ? S4_P1_SCAN : DO2 ? S4_P2_NEXT : S4_P3_SCAN; }
                 else st = S4_READ_DONE;
+                if (P3TEXT && st == S4_P3_SCAN) {   // the two longest unique SMEMs among the read's intervals
+                    us0 = ue0 = us1 = ue1 = 0; p3_notext = 0;
+                    for (int k = 0; k < on; ++k) {
+                        DIntv p = out[k];
+                        const int ps = (int)(p.info >> 32), pe = (int)(uint32_t)p.info;
+                        if (p.x2 != 1 || pe - ps < Lw) continue;
+                        if (pe - ps > ue0 - us0) { us1 = us0; ue1 = ue0; up1 = up0; us0 = ps; ue0 = pe; up0 = p.x0; }
+                        else if (pe - ps > ue1 - us1) { us1 = ps; ue1 = pe; up1 = p.x0; }
+                    }
+                    if (ue0 > us0) st = S4_P3_PREP;
+                }
                 if (!DO1 && DO2 && st == S4_P2_NEXT) {   // the long, rare SMEMs among pass 1's intervals (EMIT_MEM's test)
                     for (int k = 0; k < on; ++k) {
                         DIntv p = out[k];
@@ -435,6 +467,34 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 pbits = (uint32_t)(bits & ((1ull << LH_BLOOM_K) - 1));   // the walk's first LH_BLOOM_K filter decisions, and how far it may jump
                 if (pbits) { todo |= TD_SMEM; st = S4_PENDING; }
                 else st = S4_P2_NEXT;
+            }
+            else if (P3T && st == S4_P3_PREP) { ld64 = ix.sa[up0]; st = S4_P3_PREP2; }
+            else if (P3T && st == S4_P3_PREP2) {
+                up0 = ld64;
+                if (ue1 > us1) { ld64 = ix.sa[up1]; st = S4_P3_PREP3; }
+                else st = S4_P3_SCAN;
+            }
+            else if (P3T && st == S4_P3_PREP3) { up1 = ld64; st = S4_P3_SCAN; }
+            else if (P3T && st == S4_P3_T0) { ld64 = ix.isa[run_p]; st = S4_P3_T1; }
+            else if (P3T && st == S4_P3_T1) {
+                c0 = ld64;   // the row of the Lw-mer's occurrence
+                uint16_t v_;
+                __builtin_memcpy(&v_, ix.lcp + c0, 2);   // lcp[row], lcp[row + 1]
+                pn.lo = v_;
+                ld64 = ix.isa[(i64)ix.seq_len - (run_p + Lw)];   // the reverse strand's copy
+                st = S4_P3_T2;
+            }
+            else if (P3T && st == S4_P3_T2) {
+                const int l0_ = (int)(pn.lo & 0xff), l1_ = (int)((pn.lo >> 8) & 0xff);
+                if (l0_ < Lw && l1_ < Lw) {   // unique: the walk ends here with one occurrence
+                    if (on >= LH_MAX_INTV) ovf = 1;
+                    else { DIntv m; m.x0 = c0; m.x1 = ld64; m.x2 = 1; m.info = (u64)x << 32 | (u64)(x + Lw); out[on++] = m; }
+                    n_ext_total += (unsigned)(Lw - 1);
+                    x += Lw;
+                    st = S4_P3_SCAN;
+                    if (x >= us0 && x + Lw <= ue0) { run_p = (i64)up0 + (x - us0); st = S4_P3_T0; }        // the next walk lies in an SMEM as well (no
+                    else if (x >= us1 && x + Lw <= ue1) { run_p = (i64)up1 + (x - us1); st = S4_P3_T0; }   // non-base inside one): straight on
+                } else { p3_notext = 1; st = S4_P3_SCAN; }   // it occurs again: the walk as written, from x
             }
             else if (DO3 && st == S4_P3_JUMP) { pn = kt ? kt[ld64] : ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
             else if (DO3 && st == S4_P3_JUMP2) {   // as if the bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
@@ -576,7 +636,12 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             while (DO3 && st == S4_P3_SCAN) {   // third pass: LAST-like forward-only seeds (bwt_seed_strategy1)
                 while (x < len && QB(x) > 3) ++x;
                 if (x >= len) st = S4_READ_DONE;
+                else if (P3TEXT && !p3_notext && ((x >= us0 && x + Lw <= ue0) || (x >= us1 && x + Lw <= ue1))) {
+                    run_p = (x >= us0 && x + Lw <= ue0) ? (i64)up0 + (x - us0) : (i64)up1 + (x - us1);   // the text position the walk starts at
+                    st = S4_P3_T0;
+                }
                 else {
+                    p3_notext = 0;
                     int b = QB(x);
                     c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1;
                     i = x + 1;
