@@ -133,8 +133,13 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     const bool P3TEXT = P3T && ix.isa != nullptr && ix.lcp != nullptr && o.max_mem_intv > 1;
 #endif
     const int Lw = o.min_seed_len + 1;
-    int us0 = 0, ue0 = 0, us1 = 0, ue1 = 0, p3_notext = 0;   // the read's two longest unique SMEMs [us, ue), at text positions up0 / up1
+    uint32_t uspan = 0;   // the read's two longest unique SMEMs [us, ue) (reads have at most 250 bases: a byte each), at text positions up0 / up1
+#define P3_NOTEXT (1 << 30)   // kept in rst (the read's status bits), cleared before they are stored: "this walk start was tried by text and is not unique"
     u64 up0 = 0, up1 = 0;
+#define US0 ((int)(uspan & 0xff))
+#define UE0 ((int)((uspan >> 8) & 0xff))
+#define US1 ((int)((uspan >> 16) & 0xff))
+#define UE1 ((int)(uspan >> 24))
     constexpr bool DO1 = MODE == 0 || MODE == 1 || MODE == 3 || MODE == 5 || MODE == 6, DO2 = MODE == 0 || MODE == 1 || MODE == 4, DO12 = DO1 || DO2, DO3 = MODE == 0 || MODE == 2;
     const int lane = LANE();
     const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)lane;
@@ -416,15 +421,15 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 if (len >= o.min_seed_len) { x = 0; phase = DO1 ? 1 : 2; st = DO1 ? S4_P1_SCAN : DO2 ? S4_P2_NEXT : S4_P3_SCAN; }
                 else st = S4_READ_DONE;
                 if (P3TEXT && st == S4_P3_SCAN) {   // the two longest unique SMEMs among the read's intervals
-                    us0 = ue0 = us1 = ue1 = 0; p3_notext = 0;
+                    uspan = 0;
                     for (int k = 0; k < on; ++k) {
                         DIntv p = out[k];
                         const int ps = (int)(p.info >> 32), pe = (int)(uint32_t)p.info;
                         if (p.x2 != 1 || pe - ps < Lw) continue;
-                        if (pe - ps > ue0 - us0) { us1 = us0; ue1 = ue0; up1 = up0; us0 = ps; ue0 = pe; up0 = p.x0; }
-                        else if (pe - ps > ue1 - us1) { us1 = ps; ue1 = pe; up1 = p.x0; }
+                        if (pe - ps > UE0 - US0) { uspan = (uspan << 16) | (uint32_t)ps | (uint32_t)pe << 8; up1 = up0; up0 = p.x0; }
+                        else if (pe - ps > UE1 - US1) { uspan = (uspan & 0xffffu) | (uint32_t)ps << 16 | (uint32_t)pe << 24; up1 = p.x0; }
                     }
-                    if (ue0 > us0) st = S4_P3_PREP;
+                    if (UE0 > US0) st = S4_P3_PREP;
                 }
                 if (!DO1 && DO2 && st == S4_P2_NEXT) {   // the long, rare SMEMs among pass 1's intervals (EMIT_MEM's test)
                     for (int k = 0; k < on; ++k) {
@@ -471,7 +476,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             else if (P3T && st == S4_P3_PREP) { ld64 = ix.sa[up0]; st = S4_P3_PREP2; }
             else if (P3T && st == S4_P3_PREP2) {
                 up0 = ld64;
-                if (ue1 > us1) { ld64 = ix.sa[up1]; st = S4_P3_PREP3; }
+                if (UE1 > US1) { ld64 = ix.sa[up1]; st = S4_P3_PREP3; }
                 else st = S4_P3_SCAN;
             }
             else if (P3T && st == S4_P3_PREP3) { up1 = ld64; st = S4_P3_SCAN; }
@@ -492,9 +497,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     n_ext_total += (unsigned)(Lw - 1);
                     x += Lw;
                     st = S4_P3_SCAN;
-                    if (x >= us0 && x + Lw <= ue0) { run_p = (i64)up0 + (x - us0); st = S4_P3_T0; }        // the next walk lies in an SMEM as well (no
-                    else if (x >= us1 && x + Lw <= ue1) { run_p = (i64)up1 + (x - us1); st = S4_P3_T0; }   // non-base inside one): straight on
-                } else { p3_notext = 1; st = S4_P3_SCAN; }   // it occurs again: the walk as written, from x
+                    if (x >= US0 && x + Lw <= UE0) { run_p = (i64)up0 + (x - US0); st = S4_P3_T0; }        // the next walk lies in an SMEM as well (no
+                    else if (x >= US1 && x + Lw <= UE1) { run_p = (i64)up1 + (x - US1); st = S4_P3_T0; }   // non-base inside one): straight on
+                } else { rst |= P3_NOTEXT; st = S4_P3_SCAN; }   // it occurs again: the walk as written, from x
             }
             else if (DO3 && st == S4_P3_JUMP) { pn = kt ? kt[ld64] : ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
             else if (DO3 && st == S4_P3_JUMP2) {   // as if the bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
@@ -636,12 +641,12 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             while (DO3 && st == S4_P3_SCAN) {   // third pass: LAST-like forward-only seeds (bwt_seed_strategy1)
                 while (x < len && QB(x) > 3) ++x;
                 if (x >= len) st = S4_READ_DONE;
-                else if (P3TEXT && !p3_notext && ((x >= us0 && x + Lw <= ue0) || (x >= us1 && x + Lw <= ue1))) {
-                    run_p = (x >= us0 && x + Lw <= ue0) ? (i64)up0 + (x - us0) : (i64)up1 + (x - us1);   // the text position the walk starts at
+                else if (P3TEXT && !(rst & P3_NOTEXT) && ((x >= US0 && x + Lw <= UE0) || (x >= US1 && x + Lw <= UE1))) {
+                    run_p = (x >= US0 && x + Lw <= UE0) ? (i64)up0 + (x - US0) : (i64)up1 + (x - US1);   // the text position the walk starts at
                     st = S4_P3_T0;
                 }
                 else {
-                    p3_notext = 0;
+                    rst &= ~P3_NOTEXT;
                     int b = QB(x);
                     c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1;
                     i = x + 1;
@@ -680,6 +685,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 }
             }
             if (st == S4_READ_DONE) {
+                rst &= ~P3_NOTEXT;
                 if (ovf) rst |= LH_ST_INTV_OVERFLOW;
                 if (!FWD_ONLY) n_intv[r] = on;   // (MODE 5: the sweeps count the read's intervals)
                 status[r] = rst;
@@ -849,6 +855,11 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #undef CURR
 #undef PREV
 #undef PREV_AT
+#undef P3_NOTEXT
+#undef US0
+#undef UE0
+#undef US1
+#undef UE1
 #undef START_SMEM1
 #undef WKEY_AT
 #undef BLOOM_ISSUE
