@@ -90,7 +90,13 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define LH_KMER 12
 
 #ifndef LH_SLOW_BATCH
-#define LH_SLOW_BATCH 4
+#define LH_SLOW_BATCH 4       // pass 1 (and the kernels that carry it)
+#endif
+#ifndef LH_SLOW_BATCH_P2
+#define LH_SLOW_BATCH_P2 16   // the pass-2 and pass-3 kernels: their lanes spend a larger share of their turns in the batched states, and a batched
+#endif                        // state costs the wave a memory latency; measured at hg38 scale with 2 / 4 / 8 / 16 / 32 / 48 lanes:
+#ifndef LH_SLOW_BATCH_P3      // pass 1 6.61 / 6.68 / 6.67 / 7.07 ms, pass 2 2.87 / 2.84 / 2.75 / 2.66 / 2.74 / 3.09, pass 3 3.00 / 2.79 / 2.70 / 2.61 / 2.61 / 2.53
+#define LH_SLOW_BATCH_P3 48
 #endif
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
@@ -351,7 +357,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         // ---- A. lanes without a read take the next ones of the wave's chunk; the wave stages their bases in LDS ----
         // Lanes that left the extension loops wait until LH_SLOW_BATCH of them have gathered (or nothing else is in flight):
         // the divergent blocks of A and B then run for many lanes at once instead of for one or two in every turn.
-        const bool slow_turn = __popcll(__ballot(st == S4_FETCH || (st >= 8 && st < S4_FRUN_INIT))) >= LH_SLOW_BATCH ||
+        const bool slow_turn = __popcll(__ballot(st == S4_FETCH || (st >= 8 && st < S4_FRUN_INIT))) >= (MODE == 2 ? LH_SLOW_BATCH_P3 : MODE == 4 ? LH_SLOW_BATCH_P2 : LH_SLOW_BATCH) ||
                                !__any((st >= S4_REQ_FWD && st < 8) || st >= S4_FRUN_INIT);
         u64 need = slow_turn ? __ballot(st == S4_FETCH) : 0;
         if (need) {
