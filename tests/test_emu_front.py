@@ -9,7 +9,7 @@ import pytest
 import helpers
 from lariat_amd import capi
 
-EMU = os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu.so")
+EMU = os.environ.get("LH_EMU_LIB") or os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu.so")   # (LH_EMU_LIB: e.g. an AddressSanitizer build, tests/hipemu/Makefile asan)
 
 
 @pytest.fixture(scope="module")

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 import helpers
 
-EMU = os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu.so")
+EMU = os.environ.get("LH_EMU_LIB") or os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu.so")   # (LH_EMU_LIB: e.g. an AddressSanitizer build, tests/hipemu/Makefile asan)
 FIELDS = ["rid", "pos", "aend", "reversed", "score", "nm", "active", "is_proper", "mapq", "molecule_id", "duplicate"]
 
 
