@@ -24,7 +24,7 @@ def hostlib():
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
         ge.build()
-    return capi.Library(ge.LIB)
+    return capi.Library(os.environ.get("LH_HOST_LIB") or ge.LIB)   # (LH_HOST_LIB: the host code in another build, e.g. the emulator's AddressSanitizer one)
 
 
 def check_against_oracle(hostlib, path, trim, cap=0, chunk=0, max_pairs=1 << 20):

@@ -21,7 +21,7 @@ def hostlib():
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
         ge.build()
-    return capi.Library(ge.LIB)
+    return capi.Library(os.environ.get("LH_HOST_LIB") or ge.LIB)   # (LH_HOST_LIB: the host code in another build, e.g. the emulator's AddressSanitizer one)
 
 
 def write_fastq(tmp_path, rs, name="r.fastq"):
