@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
 #define LH_EXT_PRIMARY 35
 #define LH_EXT_HEAVY_COLS 32     // a full-band extension of this many query columns or more is "heavy" for the lane kernel
 #ifndef LH_NARROW_MAX_LOSS
-#define LH_NARROW_MAX_LOSS 26    // diagonal loss up to which k_extend_lane tries its narrow band (5 mismatches with the default scoring)
+#define LH_NARROW_MAX_LOSS 16    // diagonal loss up to which the lane DP runs in a narrow band (3 mismatches with the default scoring); a long side that loses more goes to the wave-per-read kernel: one such DP is ~2,500 cells = 0.2 ms on a single lane, the tail of a whole round
 #endif
 __device__ __forceinline__ int lh_ext_bucket(int nseeds, int longest, int cheap) {
     if (nseeds > LH_EXT_COMPLEX_SEEDS) return 0;

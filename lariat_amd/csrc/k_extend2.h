@@ -25,7 +25,7 @@
 #define LH_EXT_BINS (LH_EXT_PRIMARY * LH_EXT_SUB)
 struct DExtBins {
     int32_t count[LH_EXT_BINS], cursor[LH_EXT_BINS];
-    int32_t range[16];   // [first,last) pairs into the bucket-sorted order: complex, >= 128, 64..127, < 64 columns; [8..9] = the deferred list; [10..13] = the two no-DP buckets; [14..15] = their deferred list
+    int32_t range[20];   // [first,last) pairs into the bucket-sorted order: [0..1] complex (wave kernel); [8..9] = the deferred list; [16..17] = every other read (round 0 of k_ext_round); the rest: class boundaries (diagnostics)
 };
 
 // ---- pre-pass, one wave per read: per chain the reference window [rmax0,rmax1) and the seed order; per read the bucket ----
@@ -120,7 +120,8 @@ __global__ void __launch_bounds__(64) k_ext_offsets(DExtBins* __restrict__ bins)
             if (b == 34 * LH_EXT_SUB) { bins->range[7] = acc; bins->range[12] = acc; }
             bins->cursor[b] = acc; acc += bins->count[b];
         }
-        bins->range[13] = acc; bins->range[8] = 0; bins->range[9] = 0; bins->range[14] = 0; bins->range[15] = 0;   // [14..15]: the no-DP class's own deferred list
+        bins->range[13] = acc; bins->range[8] = 0; bins->range[9] = 0; bins->range[14] = 0; bins->range[15] = 0;
+        bins->range[16] = bins->range[1]; bins->range[17] = acc;
     }
 }
 __global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins, int32_t* __restrict__ order) {
@@ -188,7 +189,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
     u64 ncell = 0;
     for (int i = 0; i < tlen; ++i) {
         int f = 0, h1, m = 0, mj = -1;
-        int tb = tg.base(i);
+        const uint32_t tbs = (uint32_t)tg.base(i) << 29;
         if (circ_mask >= 0) EH_MATERIALIZE(i + w + 2)
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
@@ -197,10 +198,12 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
         else h1 = 0;
         int j;
         uint32_t p = EHW(beg);
+        // the cells of eh[beg .. end] that are not zero after this row (ksw_extend2 scans for them to shrink the interval): noted while they are written
+        int fnz = end, lnz = -1;
         for (j = beg; j < end; ++j) {
             uint32_t pnext = EHW(j + 1);   // j + 1 <= qlen: fetched while this cell is computed
-            int M = EH_H(p), e = EH_E(p), qv = EH_Q(p);
-            int sc = qv > 3 ? -1 : (tb == qv ? a_ : -b_);
+            int M = EH_H(p), e = EH_E(p);
+            int sc = (int32_t)p < 0 ? -1 : ((p ^ tbs) < 0x20000000u ? a_ : -b_);   // the column's base sits in the word's top three bits: compared in place
             M = M ? M + sc : 0;
             int h = M > e ? M : e;
             h = h > f ? h : f;
@@ -208,13 +211,14 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
             m = m > h ? m : h;
             int t = M - oe_del; t = t > 0 ? t : 0;
             e -= e_del; e = e > t ? e : t;
-            EHW(j) = EH_PACK(qv, e, h1);
+            EHW(j) = (p & 0xE0000000u) | (uint32_t)e << 16 | (uint32_t)h1;
+            if (e | h1) { fnz = fnz < j ? fnz : j; lnz = j; }
             h1 = h;
             t = M - oe_ins; t = t > 0 ? t : 0;
             f -= e_ins; f = f > t ? f : t;
             p = pnext;
         }
-        { uint32_t pe = EHW(end); EHW(end) = EH_PACK(EH_Q(pe), 0, h1); }
+        { uint32_t pe = EHW(end); EHW(end) = EH_PACK(EH_Q(pe), 0, h1); if (h1) lnz = end; }
         if (end > beg) ncell += (u64)(end - beg);
         if (j == qlen) {
             max_ie = gscore > h1 ? max_ie : i;
@@ -232,9 +236,8 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
                 if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
             }
         }
-        for (j = beg; j < end && (EHW(j) & 0x1fffffffu) == 0; ++j) {}
-        beg = j;
-        for (j = end; j >= beg && (EHW(j) & 0x1fffffffu) == 0; --j) {}
+        beg = fnz;                        // for (j = beg; j < end && eh[j] is zero; ++j); beg = j
+        j = lnz >= beg ? lnz : beg - 1;   // for (j = end; j >= beg && eh[j] is zero; --j)
         end = j + 2 < qlen ? j + 2 : qlen;
     }
 #undef EHW
@@ -284,7 +287,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
     int over = 0;
     for (int i = 0; i < tlen; ++i) {
         int f = 0, h1, m = 0, mj = -1;
-        int tb = tg.base(i);
+        const uint32_t tbs = (uint32_t)tg.base(i) << 29;
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
@@ -297,14 +300,15 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
             EH_MAT(end, 0)
         }
         uint32_t p = EHW(beg);
+        int fnz = end, lnz = -1;   // the cells of eh[beg .. end] that are not zero after this row, noted while they are written
         for (j = beg; j < end; ++j) {
             if (i == 0 && n_mat <= j + 1) {   // row 0 materialises its columns as it goes (j + 1 <= qlen)
                 if (j + 1 > 63) { over = 1; break; }
                 EH_MAT(j + 1, 1)
             }
             uint32_t pnext = EHW(j + 1);
-            int M = EH_H(p), e = EH_E(p), qv = EH_Q(p);
-            int sc = qv > 3 ? -1 : (tb == qv ? a_ : -b_);
+            int M = EH_H(p), e = EH_E(p);
+            int sc = (int32_t)p < 0 ? -1 : ((p ^ tbs) < 0x20000000u ? a_ : -b_);
             const int m_in = M;
             M = M ? M + sc : 0;
             int h = M > e ? M : e;
@@ -313,7 +317,8 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
             m = m > h ? m : h;
             int t = M - oe_del; t = t > 0 ? t : 0;
             e -= e_del; e = e > t ? e : t;
-            EHW(j) = EH_PACK(qv, e, h1);
+            EHW(j) = (p & 0xE0000000u) | (uint32_t)e << 16 | (uint32_t)h1;
+            if (e | h1) { fnz = fnz < j ? fnz : j; lnz = j; }
             h1 = h;
             t = M - oe_ins; t = t > 0 ? t : 0;
             f -= e_ins; f = f > t ? f : t;
@@ -325,7 +330,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
         if (cut) {
             // cells [j, end) and eh[end] are zero; stored slots among them (at most column j, just materialised with a zero first-row value) already are
             h1 = 0;
-        } else { uint32_t pe = EHW(end); EHW(end) = EH_PACK(EH_Q(pe), 0, h1); }
+        } else { uint32_t pe = EHW(end); EHW(end) = EH_PACK(EH_Q(pe), 0, h1); if (h1) lnz = end; }
         if (end == qlen) {
             max_ie = gscore > h1 ? max_ie : i;
             gscore = gscore > h1 ? gscore : h1;
@@ -342,10 +347,8 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
                 if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
             }
         }
-        for (j = beg; j < end && (j >= n_mat || (EHW(j) & 0x1fffffffu) == 0); ++j) {}
-        beg = j;
-        j = end < n_mat ? end : n_mat - 1;   // columns >= n_mat are zero
-        for (; j >= beg && (EHW(j) & 0x1fffffffu) == 0; --j) {}
+        beg = fnz;                        // the scans of ksw_extend2 (see lane_ksw_extend2); cells a cut row 0 left out are zero
+        j = lnz >= beg ? lnz : beg - 1;
         end = j + 2 < qlen ? j + 2 : qlen;
     }
 #undef EHW
@@ -360,151 +363,270 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
     return r;
 }
 
-// Reads order[range[0] .. range[1]).  EHW_ = LDS words per lane: a read that turns out to need an extension of EHW_ or more
-// columns (its bucket only bounds the FIRST extension) is left without output and appended to the deferred list, which the
-// wave-per-read kernel processes afterwards from scratch.
-template <int EHW_>
-__global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_reads, const int32_t* __restrict__ range, const int32_t* __restrict__ order,
-                                                     int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list,
-                                                     const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
-                                                     const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
-                                                     const int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, const i64* __restrict__ chain_rmax,
-                                                     const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs, DCounters* __restrict__ ctr) {
-    __shared__ uint32_t ehl[EHW_ ? EHW_ * 64 : 1];   // EHW_ = 0: no DP at all, a read that needs one is deferred
-    const int lane = LANE();
-    int first = range[0], last = range[1];
-    int g = first + blockIdx.x * 64 + lane;
-    if (first + blockIdx.x * 64 >= last) return;
-    int r = g < last ? order[g] : -1;
-    i64 off = 0;
-    int l_query = 0;
-    if (r >= 0) { off = seq_off[r]; l_query = (int)(seq_off[r + 1] - off); if (l_query > LH_MAXLEN) l_query = 0; }
-    const uint8_t* q = seq + off;
-    u64 cells = 0;
-#ifdef LH_K4_PROF
-    long long k4all_ = wall_clock64();
+// ---- K4 as ROUNDS over a job queue -----------------------------------------------------------------------------------------
+// Measured (profiles/r02_*): with one lane running a read's whole mem_chain2aln, the lanes of a wave sit in different DPs of
+// different widths — 14 of 64 lanes active, 74 % of the instructions in the DP cell loop.  The control flow of mem_chain2aln
+// (chains -> seeds by score -> left / right extension -> band retry) is cheap; the DPs are what has to run side by side with
+// DPs of the same shape.  So a read's program is RESUMABLE: it runs until it needs a ksw_extend2 call that is not provably the
+// diagonal, saves where it is (ExtSt, 16 B; the region under construction in its output slot), and queues the call as a JOB with
+// a key (kind of DP, band width, query columns).  The jobs of a round are counting-sorted by key; in the next round lane g runs
+// job g's DP — beside 63 DPs of the same kind, width and length — and then the read's control flow up to its next job.  A read
+// needs 0 .. 4 rounds on unique sequence; what is left after LH_EXT_ROUNDS, and live-interval windows that outgrow their 64
+// columns, goes to the wave-per-read kernel as before.  Same calls, same arguments, same order per read as mem_chain2aln.
+#ifndef LH_EXT_ROUNDS
+#define LH_EXT_ROUNDS 4   // every round ends with the latency of its slowest DP (~0.2 ms): what is left after four (1 % of the reads) is cheaper in the wave kernel (tests also build with 2)
 #endif
+#define LH_EXT_JOB_BINS 1536
+struct ExtSt { int32_t w0, narrow, sc0, pad; };   // w0: chain | seed rank << 8 | regions so far << 16 | side << 24 | band try << 25 | (left side used the doubled band) << 26
+struct DExtJobs {
+    int32_t hist[LH_EXT_JOB_BINS], cursor[LH_EXT_JOB_BINS];
+    int32_t count[LH_EXT_ROUNDS + 2];    // jobs queued for round k (k = 1 ..)
+    int32_t range[2 * (LH_EXT_ROUNDS + 2)];   // [2k, 2k+1] = the sorted order's slice round k runs
+    int32_t next[LH_EXT_ROUNDS + 2];          // round k's slice counter: its waves take slices of 64 jobs in the sorted order (heaviest bins first)
+    int32_t kinds[3 * (LH_EXT_ROUNDS + 2)];   // diagnostics: narrow / live-interval / short full-band jobs of round k
+};
+// job key: bins 0..959 = narrow band in the circular window (same w: same cells per row), 960..1215 = full band in the live-interval window, 1216..1471 = full band, fewer than 64 columns
+// bins in the order they should START (a round's tail is its last waves: the cheap ones): wide bands and long query sides first
+__device__ __forceinline__ int lh_ext_job_key(int narrow, int qlen, int h0) {
+    const int ql = 31 - (qlen >> 3 < 31 ? qlen >> 3 : 31), hh = 7 - (h0 < 16 ? 0 : h0 < 40 ? (h0 - 16) >> 2 : 6 + (h0 >= 80));   // h0 sets the width of a chance match's band: classes 16..19, 20..23, ..
+    if (narrow && narrow <= LH_EXT_CIRC_MAX_W) return (LH_EXT_CIRC_MAX_W - narrow) * 32 + ql;
+    if (qlen < 64) return 1216 + (31 - (qlen >> 1)) * 8 + hh;
+    return 960 + ql * 8 + hh;
+}
+__global__ void __launch_bounds__(256) k_extj_count(const int32_t* __restrict__ n_jobs, const int32_t* __restrict__ key, DExtJobs* __restrict__ jb) {
+    __shared__ int32_t hist[LH_EXT_JOB_BINS];
+    const int n = *n_jobs;
+    if ((int)blockIdx.x * 1024 >= n) return;
+    for (int b = threadIdx.x; b < LH_EXT_JOB_BINS; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (int blk = blockIdx.x; blk * 1024 < n; blk += gridDim.x)
+        for (int u = 0; u < 4; ++u) {
+            int i = (blk * 4 + u) * 256 + threadIdx.x;
+            if (i < n) atomicAdd(&hist[key[i]], 1);
+        }
+    __syncthreads();
+    for (int b = threadIdx.x; b < LH_EXT_JOB_BINS; b += 256) if (hist[b]) atomicAdd(&jb->hist[b], hist[b]);
+}
+__global__ void __launch_bounds__(256) k_extj_offsets(DExtJobs* __restrict__ jb, int round) {   // exclusive scan of the histogram; clears it for the next round
+    __shared__ int32_t part[256];
+    const int t = threadIdx.x, per = LH_EXT_JOB_BINS / 256;
+    int loc[per], s = 0;
+    for (int u = 0; u < per; ++u) { loc[u] = s; s += jb->hist[t * per + u]; }
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        int o = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += o;
+        __syncthreads();
+    }
+    const int excl = part[t] - s;
+    for (int u = 0; u < per; ++u) { const int b = t * per + u, c = jb->hist[b]; if (c) atomicAdd(&jb->kinds[3 * round + (b < 960 ? 0 : b < 1216 ? 1 : 2)], c); }
+    for (int u = 0; u < per; ++u) { jb->cursor[t * per + u] = excl + loc[u]; jb->hist[t * per + u] = 0; }
+    if (t == 255) { jb->range[2 * round] = 0; jb->range[2 * round + 1] = part[255]; }
+}
+__global__ void __launch_bounds__(256) k_extj_scatter(const int32_t* __restrict__ n_jobs, const int32_t* __restrict__ key, const int32_t* __restrict__ list,
+                                                       DExtJobs* __restrict__ jb, int32_t* __restrict__ order) {
+    __shared__ int32_t hist[LH_EXT_JOB_BINS], basep[LH_EXT_JOB_BINS];
+    const int n = *n_jobs;
+    for (int blk = blockIdx.x; blk * 1024 < n; blk += gridDim.x) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < LH_EXT_JOB_BINS; b += 256) hist[b] = 0;
+        __syncthreads();
+        int k[4], rank[4];
+        for (int u = 0; u < 4; ++u) {
+            int i = (blk * 4 + u) * 256 + threadIdx.x;
+            k[u] = i < n ? key[i] : -1;
+            rank[u] = k[u] >= 0 ? atomicAdd(&hist[k[u]], 1) : 0;
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < LH_EXT_JOB_BINS; b += 256) if (hist[b]) basep[b] = atomicAdd(&jb->cursor[b], hist[b]);
+        __syncthreads();
+        for (int u = 0; u < 4; ++u) {
+            int i = (blk * 4 + u) * 256 + threadIdx.x;
+            if (k[u] >= 0) order[basep[k[u]] + rank[u]] = list[i];
+        }
+    }
+}
+
+// One round.  DP = false: the first round — lane g starts read order[g] (the reads bucket-sorted by k_chain_lane's keys, minus the
+// complex ones) and runs it up to its first job.  DP = true: lane g runs the queued ksw_extend2 call of read order[g], then the
+// read's control flow up to its next job.  A read that finishes writes n_regs; one that queues a job appends itself to next_list
+// (key in next_key); a live-interval window that overflows, or a job queued in the last round (next_* = the deferred list),
+// leaves the read to the wave-per-read kernel, which redoes it from scratch.
+template <bool DP>
+__global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int32_t* __restrict__ range, int32_t* __restrict__ slice_ctr, const int32_t* __restrict__ order, ExtSt* __restrict__ est,
+                                                   int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key,
+                                                   int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list,
+                                                   const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
+                                                   const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
+                                                   const int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, const i64* __restrict__ chain_rmax,
+                                                   const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs, DCounters* __restrict__ ctr) {
+    __shared__ uint32_t ehl[DP ? 64 * 64 : 1];
+    const int lane = LANE();
+    const int first = range[0], last = range[1];
+    u64 cells = 0;
+    for (int blk = blockIdx.x;; blk += gridDim.x) {
+    if (DP) {   // persistent waves, slices handed out in order: the expensive bins start first, the cheap ones fill the tail
+        int nb = 0;
+        if (lane == 0) nb = atomicAdd(slice_ctr, 1);
+        blk = wave_readlane(nb, 0);
+    }
+    if (first + blk * 64 >= last) break;
+    const int g = first + blk * 64 + lane;
+    const int r = g < last ? order[g] : -1;
+    int out = 0, key = 0;   // out: 1 = a job was queued, 2 = the read is left to the wave kernel
     if (r >= 0) {
-        i64 base = seed_off[r];
+        const u64 cells0 = cells;
+        const i64 off = seq_off[r];
+        int l_query = (int)(seq_off[r + 1] - off);
+        if (l_query > LH_MAXLEN) l_query = 0;
+        const uint8_t* q = seq + off;
+        const i64 base = seed_off[r];
         DReg* av = regs + reg_off[r];
-        int n_av = 0, nch = n_chains[r], deferred = 0;
-        for (int ci = 0; ci < nch && !deferred; ++ci) {
-            DChain c = chains[base + ci];
+        const int nch = n_chains[r];
+        int ci = 0, k = 0, n_av = 0, side = 0, tri = 0, narrow = 0, sc0 = 0, aw0 = o.w;
+        bool resume = false;
+        DReg a;
+        a.rb = a.re = 0; a.qb = a.qe = 0; a.rid = 0; a.score = a.truesc = -1; a.sub = a.csub = 0; a.w = o.w; a.seedcov = 0; a.secondary = 0; a.seedlen0 = 0; a.n_comp = 0; a.is_alt = 0; a.frac_rep = 0;
+        if (DP) {
+            const ExtSt st = est[r];
+            ci = st.w0 & 0xff; k = (st.w0 >> 8) & 0xff; n_av = (st.w0 >> 16) & 0xff; side = (st.w0 >> 24) & 1; tri = (st.w0 >> 25) & 1; aw0 = o.w << ((st.w0 >> 26) & 1);
+            narrow = st.narrow; sc0 = st.sc0;
+            a = av[n_av];
+            resume = true;
+        }
+        while (ci < nch && !out) {
+            const DChain c = chains[base + ci];
             const DSeed* sd = cseeds + base + c.seed_start;
             const int32_t* srt = sorder + base + c.seed_start;
             int32_t* done = sdone + base + c.seed_start;
-            int n = c.n;
-            if (n == 0) continue;
-            i64 rmax0 = chain_rmax[2 * (base + ci)], rmax1 = chain_rmax[2 * (base + ci) + 1];
-            for (int k = n - 1; k >= 0 && !deferred; --k) {
-                int si = srt[k];
-                DSeed s = sd[si];
-                // test whether extension has been made before (any earlier region of this read "around" the seed)
-                int hit = 0;
-                for (int i = 0; i < n_av && !hit; ++i) {
-                    DReg p = av[i];
-                    if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;   // not fully contained
-                    if (s.len - p.seedlen0 > .1 * l_query) continue;   // this seed may give a better alignment
-                    int qd = s.qbeg - p.qb; i64 rd = s.rbeg - p.rb;
-                    int max_gap = dev_cal_max_gap(o, qd < rd ? qd : (int)rd);
-                    int w = max_gap < p.w ? max_gap : p.w;
-                    if (qd - rd < w && rd - qd < w) { hit = 1; break; }
-                    qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-                    max_gap = dev_cal_max_gap(o, qd < rd ? qd : (int)rd);
-                    w = max_gap < p.w ? max_gap : p.w;
-                    if (qd - rd < w && rd - qd < w) { hit = 1; break; }
-                }
-                if (hit) {   // (almost) contained: extend only if an overlapping, already-extended seed of the chain lies on another diagonal
-                    int other = 0;
-                    for (int i = k + 1; i < n && !other; ++i) {
-                        int ti = srt[i];
-                        if (!done[ti]) continue;
-                        DSeed t = sd[ti];
-                        if (t.len < s.len * .95) continue;
-                        if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) other = 1;
-                        if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) other = 1;
+            const int n = c.n;
+            if (n == 0) { ++ci; continue; }
+            const i64 rmax0 = chain_rmax[2 * (base + ci)], rmax1 = chain_rmax[2 * (base + ci) + 1];
+            if (!resume) k = n - 1;
+            while (k >= 0 && !out) {
+                const int si = srt[k];
+                const DSeed s = sd[si];
+                if (!resume) {
+                    // test whether extension has been made before (any earlier region of this read "around" the seed)
+                    int hit = 0;
+                    for (int i = 0; i < n_av && !hit; ++i) {
+                        DReg p = av[i];
+                        if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;   // not fully contained
+                        if (s.len - p.seedlen0 > .1 * l_query) continue;   // this seed may give a better alignment
+                        int qd = s.qbeg - p.qb; i64 rd = s.rbeg - p.rb;
+                        int max_gap = dev_cal_max_gap(o, qd < rd ? qd : (int)rd);
+                        int w = max_gap < p.w ? max_gap : p.w;
+                        if (qd - rd < w && rd - qd < w) { hit = 1; break; }
+                        qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+                        max_gap = dev_cal_max_gap(o, qd < rd ? qd : (int)rd);
+                        w = max_gap < p.w ? max_gap : p.w;
+                        if (qd - rd < w && rd - qd < w) { hit = 1; break; }
                     }
-                    if (!other) { done[si] = 0; continue; }
+                    if (hit) {   // (almost) contained: extend only if an overlapping, already-extended seed of the chain lies on another diagonal
+                        int other = 0;
+                        for (int i = k + 1; i < n && !other; ++i) {
+                            int ti = srt[i];
+                            if (!done[ti]) continue;
+                            DSeed t = sd[ti];
+                            if (t.len < s.len * .95) continue;
+                            if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) other = 1;
+                            if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) other = 1;
+                        }
+                        if (!other) { done[si] = 0; --k; continue; }
+                    }
+                    a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = 0; a.seedcov = 0; a.secondary = 0; a.n_comp = 0; a.is_alt = 0;
+                    a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid;
+                    aw0 = o.w; side = 0;
                 }
-                DReg a;
-                a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = 0; a.seedcov = 0; a.secondary = 0; a.n_comp = 0; a.is_alt = 0;
-                int aw0 = o.w, aw1 = o.w;
-                a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid;
-                for (int side = 0; side < 2; ++side) {   // 0 = left (reversed query prefix vs reversed reference prefix), 1 = right
-                    int qoff, qstep, qlen, tstep, tlen, bonus, h0, sc0 = a.score, qe = s.qbeg + s.len;
-                    i64 tc0, re = s.rbeg + s.len;
+                int aw1 = o.w;
+                while (side < 2 && !out) {   // 0 = left (reversed query prefix vs reversed reference prefix), 1 = right
+                    int qoff, qstep, qlen, tstep, tlen, bonus, h0;
+                    const int qe = s.qbeg + s.len;
+                    i64 tc0;
+                    const i64 re = s.rbeg + s.len;
+                    if (!resume) sc0 = a.score;
                     if (side == 0) {
-                        if (!s.qbeg) { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; continue; }
+                        if (!s.qbeg) { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; side = 1; continue; }
                         qoff = s.qbeg - 1; qstep = -1; qlen = s.qbeg; tc0 = s.rbeg - 1; tstep = -1; tlen = (int)(s.rbeg - rmax0); bonus = o.pen_clip5; h0 = s.len * o.a;
                     } else {
-                        if (qe == l_query) { a.qe = l_query; a.re = s.rbeg + s.len; continue; }
+                        if (qe == l_query) { a.qe = l_query; a.re = s.rbeg + s.len; side = 2; continue; }
                         qoff = qe; qstep = 1; qlen = l_query - qe; tc0 = re; tstep = 1; tlen = (int)(rmax1 - re); bonus = o.pen_clip3; h0 = sc0;
                     }
                     ExtRes e;
                     e.score = -1; e.qle = e.tle = e.gtle = 0; e.gscore = -1; e.max_off = 0;
                     int aw = o.w;
-                    // ksw_extend2 without the DP when it is provably the ungapped extension.  A cell off the diagonal is reached
-                    // through at least one gap and at most min(i,j)+1 aligned pairs: H(i,j) <= h0 + (min(i,j)+1)*a - min(oe_ins,
-                    // oe_del).  If the penalties lost along the diagonal (a+b per mismatch, a+1 per ambiguous base) stay below
-                    // that gap cost over the whole query, every row's maximum is its diagonal cell, strictly: max / qle / tle
-                    // come from the diagonal's running score (first maximum), max_off is 0, the band is not retried, and
-                    // gscore = the diagonal's last value at gtle = qlen (all other cells of the last column are smaller).
-                    // With the default scoring that is any extension with at most one mismatch: most of them.
-                    // When the diagonal loses more than that, the DP is still run, but in a band that is provably wide enough:
-                    // a cell more than B off the diagonal is reached through a gap of more than B bases, so it stays below
-                    // h0 + (min(i,j)+1)*a - gap_cost(B+1); a cell inside the band whose value depends on such a cell went
-                    // through a second gap as well.  If the whole diagonal loses less than gap_cost(B+1) and never drops to 0,
-                    // all those cells are strictly below their row's diagonal cell (and below the diagonal's end in the last
-                    // column): row maxima, their columns, gscore / gtle and max_off of ksw_extend2(w) and of ksw_extend2(B)
-                    // are the same, zdrop (> the loss) cannot fire, the band is not retried.  The region keeps w = opt->w.
-                    int proven = 0, narrow = 0;
-                    K4_T0()
-                    if (tlen >= qlen) {
-                        const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
-                        const int p_cap = o.zdrop > 0 && o.zdrop < LH_NARROW_MAX_LOSS ? o.zdrop : LH_NARROW_MAX_LOSS;
-                        LaneTgt tg;
-                        tg.init(ix, tc0, tstep);
-                        int P = 0, sc_run = h0, mx = h0, mxk = -1, k = 0;
-                        for (; k < qlen; ++k) {
-                            int qv = q[qoff + qstep * k], tb = tg.base(k);
-                            int sc = qv > 3 ? -1 : (tb == qv ? o.a : -o.b);
-                            P += o.a - sc;
-                            sc_run += sc;
-                            if (P >= p_cap || sc_run <= 0) break;
-                            if (sc_run > mx) { mx = sc_run; mxk = k; }
+                    if (!resume) {
+                        // ksw_extend2 without the DP when it is provably the ungapped extension.  A cell off the diagonal is reached
+                        // through at least one gap and at most min(i,j)+1 aligned pairs: H(i,j) <= h0 + (min(i,j)+1)*a - min(oe_ins,
+                        // oe_del).  If the penalties lost along the diagonal (a+b per mismatch, a+1 per ambiguous base) stay below
+                        // that gap cost over the whole query, every row's maximum is its diagonal cell, strictly: max / qle / tle
+                        // come from the diagonal's running score (first maximum), max_off is 0, the band is not retried, and
+                        // gscore = the diagonal's last value at gtle = qlen (all other cells of the last column are smaller).
+                        // With the default scoring that is any extension with at most one mismatch: most of them.
+                        // When the diagonal loses more than that, the DP is still run, but in a band that is provably wide enough:
+                        // a cell more than B off the diagonal is reached through a gap of more than B bases, so it stays below
+                        // h0 + (min(i,j)+1)*a - gap_cost(B+1); a cell inside the band whose value depends on such a cell went
+                        // through a second gap as well.  If the whole diagonal loses less than gap_cost(B+1) and never drops to 0,
+                        // all those cells are strictly below their row's diagonal cell (and below the diagonal's end in the last
+                        // column): row maxima, their columns, gscore / gtle and max_off of ksw_extend2(w) and of ksw_extend2(B)
+                        // are the same, zdrop (> the loss) cannot fire, the band is not retried.  The region keeps w = opt->w.
+                        int proven = 0;
+                        narrow = 0;
+                        if (tlen >= qlen) {
+                            const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
+                            const int p_cap = o.zdrop > 0 && o.zdrop < LH_NARROW_MAX_LOSS ? o.zdrop : LH_NARROW_MAX_LOSS;
+                            LaneTgt tg;
+                            tg.init(ix, tc0, tstep);
+                            int P = 0, sc_run = h0, mx = h0, mxk = -1, kk = 0;
+                            for (; kk < qlen; ++kk) {
+                                int qv = q[qoff + qstep * kk], tb = tg.base(kk);
+                                int sc = qv > 3 ? -1 : (tb == qv ? o.a : -o.b);
+                                P += o.a - sc;
+                                sc_run += sc;
+                                if (P >= p_cap || sc_run <= 0) break;
+                                if (sc_run > mx) { mx = sc_run; mxk = kk; }
+                            }
+                            if (kk == qlen && P < thr) {
+                                e.score = mx; e.qle = mxk + 1; e.tle = mxk + 1; e.gscore = sc_run; e.gtle = qlen; e.max_off = 0;
+                                a.score = e.score;
+                                proven = 1;
+                            } else if (kk == qlen) {
+                                narrow = 1;
+                                while (o.o_ins + o.e_ins * (narrow + 1) <= P || o.o_del + o.e_del * (narrow + 1) <= P) ++narrow;
+                            }
                         }
-                        if (k == qlen && P < thr) {
-                            e.score = mx; e.qle = mxk + 1; e.tle = mxk + 1; e.gscore = sc_run; e.gtle = qlen; e.max_off = 0;
+                        if (!proven) {   // queue the call: the first try of MAX_BAND_TRY
+                            tri = 0;
+                            key = lh_ext_job_key(narrow, qlen, h0);
+                            out = 1;
+                            break;
+                        }
+                    } else {
+                        resume = false;
+                        if (DP) {
+                            aw = o.w << tri;
+                            const int circ = narrow && narrow <= LH_EXT_CIRC_MAX_W;   // a narrow band needs 64 words whatever qlen is
+                            const int dyn = !circ && qlen >= 64;                       // full band, query side longer than the LDS window: live-interval window
+                            LaneTgt tg;
+                            tg.init(ix, tc0, tstep);
+                            if (dyn) {
+                                int over = 0;
+                                e = lane_ksw_extend2_dyn(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells, &over);
+                                if (over) { out = 2; break; }
+                            } else
+                                e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, narrow && narrow < aw ? narrow : aw, bonus, o.zdrop, h0, &cells, circ ? 63 : -1);
+                            const int prev = a.score;   // try 0: the score the side started from; try 1: the first try's
                             a.score = e.score;
-                            proven = 1;
-                        } else if (k == qlen) {
-                            narrow = 1;
-                            while (o.o_ins + o.e_ins * (narrow + 1) <= P || o.o_del + o.e_del * (narrow + 1) <= P) ++narrow;
+                            if (tri == 0 && !(a.score == prev || e.max_off < (aw >> 1) + (aw >> 2))) {   // MAX_BAND_TRY: once more with the doubled band
+                                tri = 1;
+                                key = lh_ext_job_key(0, qlen, h0);
+                                out = 1;
+                                break;
+                            }
                         }
                     }
-                    K4_T(3)
-                    const int circ = narrow && narrow <= LH_EXT_CIRC_MAX_W && EHW_ >= 64;   // a narrow band needs 64 words whatever qlen is
-                    const int dyn = !proven && !circ && qlen >= EHW_;   // full band, query side longer than the LDS window: live-interval window
-                    if (dyn && EHW_ < 64) { deferred = 1; break; }
-                    for (int i = 0; i < 2 && !proven; ++i) {   // MAX_BAND_TRY
-                        int prev = a.score;
-                        aw = o.w << i;
-                        LaneTgt tg;
-                        tg.init(ix, tc0, tstep);
-#if defined(LH_K4_HACK)   // timing experiments only: results are wrong
-                        if (dyn || LH_K4_HACK >= 2) { e.score = h0; e.qle = e.tle = e.gtle = 0; e.gscore = -1; e.max_off = 0; a.score = e.score; break; }
-#endif
-                        if (dyn) {
-                            int over = 0;
-                            e = lane_ksw_extend2_dyn(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells, &over);
-                            if (over) { deferred = 1; break; }
-                        } else
-                            e = lane_ksw_extend2(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, narrow && narrow < aw ? narrow : aw, bonus, o.zdrop, h0, &cells,
-                                                 circ ? 63 : -1);
-                        a.score = e.score;
-                        if (a.score == prev || e.max_off < (aw >> 1) + (aw >> 2)) break;
-                    }
-                    if (deferred) break;
                     if (side == 0) {
                         aw0 = aw;
                         if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip5) { a.qb = s.qbeg - e.qle; a.rb = s.rbeg - e.tle; a.truesc = a.score; }   // local extension
@@ -514,8 +636,9 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                         if (e.gscore <= 0 || e.gscore <= a.score - o.pen_clip3) { a.qe = qe + e.qle; a.re = re + e.tle; a.truesc += a.score - sc0; }
                         else { a.qe = l_query; a.re = re + e.gtle; a.truesc += e.gscore - sc0; }
                     }
+                    ++side;
                 }
-                if (deferred) break;
+                if (out) break;
                 int cov = 0;   // seedcov
                 for (int i = 0; i < n; ++i) {
                     DSeed t = sd[i];
@@ -526,15 +649,36 @@ __global__ void __launch_bounds__(64) k_extend_lane(DIndex ix, DOpts o, int n_re
                 a.seedlen0 = s.len;
                 a.frac_rep = c.frac_rep;
                 av[n_av++] = a;
+                --k;
             }
+            if (!out) ++ci;
         }
-        if (!deferred) n_regs[r] = n_av;
-        else { defer_list[atomicAdd(defer_count, 1)] = r; cells = 0; }   // the read is redone from scratch: its cells are counted there
+        if (!out) n_regs[r] = n_av;
+        else if (out == 1) {
+            ExtSt st;
+            st.w0 = ci | k << 8 | n_av << 16 | side << 24 | tri << 25 | (aw0 != o.w ? 1 : 0) << 26; st.narrow = narrow; st.sc0 = sc0; st.pad = 0;
+            est[r] = st;
+            av[n_av] = a;
+        } else cells = cells0;   // the read is redone from scratch: its cells are counted there
     }
-#ifdef LH_K4_PROF
-    if (r >= 0 && EHW_ == 128) atomicAdd(&lh_dbg[24], (int)((wall_clock64() - k4all_) >> 6));
-#endif
-    if (ctr) {
+    {
+        const u64 em = __ballot(out == 1);
+        if (em) {
+            int basep = 0;
+            if (lane == 0) basep = atomicAdd(next_count, (int32_t)__popcll(em));
+            basep = wave_readlane(basep, 0);
+            if (out == 1) { const int p = basep + lanes_below(em, lane); next_list[p] = r; if (next_key) next_key[p] = key; }
+        }
+        const u64 dm = __ballot(out == 2);
+        if (dm) {
+            int basep = 0;
+            if (lane == 0) basep = atomicAdd(defer_count, (int32_t)__popcll(dm));
+            basep = wave_readlane(basep, 0);
+            if (out == 2) defer_list[basep + lanes_below(dm, lane)] = r;
+        }
+    }
+    }
+    if (DP && ctr) {
         uint32_t lo = (uint32_t)cells;   // < 2^32 cells per read
         u64 tot = (u64)(uint32_t)wave_sum_i32((int)(lo >> 16)) << 16;
         tot += (u64)(uint32_t)wave_sum_i32((int)(lo & 0xffff));
