@@ -174,7 +174,7 @@ __device__ __forceinline__ ExtRes wave_ksw_extend2(const DIndex& ix, const DOpts
 // K4, one wavefront per read.  Without a list: grid = n_reads waves.  With a list (k_extend2.h hands over the reads that
 // do not suit its lane-per-read kernel): the waves stride over list[range[0] .. range[1]).
 __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, const int32_t* __restrict__ list, const int32_t* __restrict__ range,
-                                                const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+                                                const uint8_t* __restrict__ seq, const uint32_t* __restrict__ q4, const i64* __restrict__ seq_off,
                                                 const i64* __restrict__ seed_off, const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds,
                                                 const int32_t* __restrict__ n_chains, int32_t* __restrict__ sorder, int32_t* __restrict__ sdone,
                                                 const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs,
@@ -294,7 +294,19 @@ __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, 
                 ExtRes e;
                 e.score = -1; e.qle = e.tle = e.gtle = 0; e.gscore = -1; e.max_off = 0;
                 int aw = o.w;
-                for (int i = 0; i < 2; ++i) {   // MAX_BAND_TRY
+                // ksw_extend2 without the DP when it is provably the ungapped extension (the argument is in k_extend2.h, ext_control):
+                // every lane walks the diagonal (the same walk: no divergence), eight bases per step against the 4-bit text
+                int proven = 0;
+                if (tlen >= qlen) {
+                    const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
+                    const DiagScan ds = dev_diag_scan(ix, o, seq + off, q4, off, qoff, qstep, qlen, tc0, tstep, h0, thr);
+                    if (ds.done) {   // (the walk stops at a loss of thr: done means P < thr)
+                        e.score = ds.mx; e.qle = ds.mxk + 1; e.tle = ds.mxk + 1; e.gscore = ds.sc_run; e.gtle = qlen; e.max_off = 0;
+                        a.score = e.score;
+                        proven = 1;
+                    }
+                }
+                for (int i = 0; i < 2 && !proven; ++i) {   // MAX_BAND_TRY
                     int prev = a.score;
                     aw = o.w << i;
                     if (qlen <= 64) e = wave_ksw_extend2<1>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, aw, bonus, o.zdrop, h0, lane, &cells);
@@ -342,7 +354,7 @@ __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, 
         n_regs[r] = n_av;
         if (ctr) {
             atomicAdd(&LH_CTR(ctr)->ext_cells, cells);
-            if (count_chains) { atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }   // else counted by k_ext_prep
+            if (count_chains) { atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }   // else counted by k_chain_lane
         }
     }
     }

@@ -1,147 +1,17 @@
-// k_extend2.h — K4 v2: seed extension (BWA mem_chain2aln + ksw_extend2) with ONE LANE PER READ.
+// k_extend2.h — K4 v3: seed extension (BWA mem_chain2aln + ksw_extend2), a read's control flow on ONE LANE, its DPs in sorted rounds.
 // Reached in the reference through mem_align1_core (go/src/gobwa/gobwa.go:244,253).
 //
 // Measured on MI355X (profiles/r01_*): the wave-per-read kernel (k_extend.h: lanes = query columns, one DP row per step)
-// is VALU-issue bound at ~120 instructions per row for extensions that are ~35 columns wide: ~4.5 instructions per DP
-// cell.  ksw_extend2 is a short sequential program, so here every lane runs it for its own read exactly as written
-// (row-major cells, f/h1 carried in registers), 64 reads per wave:
+// is VALU-issue bound at ~120 instructions per row for extensions that are ~35 columns wide.  ksw_extend2 is a short sequential
+// program, so here every lane runs it for its own read exactly as written (row-major cells, f/h1 carried in registers):
 //   - eh[] lives in LDS, one 32-bit word per query column: h (16 bits) | e (13 bits) | the column's query base (3 bits),
 //     word j of lane L at ehl[j*64+L] (conflict-free for any per-lane j); one LDS read + one write per cell;
-//   - the reads are bucketed by the lengths of their first extension (the pre-pass inside k_chain_lane computes them from the
-//     chains), so the lanes of a wave sweep similar windows;
-//   - three exact shortcuts keep the DP small (see k_extend_lane): no DP for a provably ungapped extension, a provably
+//   - three exact shortcuts keep the DP small (see ext_control): no DP for a provably ungapped extension, a provably
 //     sufficient narrow band otherwise (in a circular 64-word window of eh[], whatever the query length), and the full band
-//     only in the wave-per-read kernel; one LDS footprint of 64 words per lane, plus an instance without LDS for the reads
-//     that are expected to need no DP at all.
+//     in a window that follows the live interval ksw_extend2 maintains;
+//   - the DPs of different reads run side by side only when they have the same shape: see "K4 as ROUNDS" below.
 #pragma once
 #include "k_extend.h"
-
-// Buckets (lh_ext_bucket in k_chain.h): 0 = reads with many chains / seeds (handed to the wave-per-read kernel, which is
-// parallel over seeds and columns) and reads with a long extension that needs the full band; then by the length of the LONGER
-// side of the first extension, longest first, in three ranges (>= 128, 64..127, < 64 columns: once LDS classes of their own,
-// now three launches of the 64-word instance); reads whose first extension is provably ungapped on both sides (no DP
-// expected) have their own buckets (25 and 34), run by the instance without LDS.  Each primary bucket has LH_EXT_SUB sub-buckets by the length
-// of the SHORTER side, so that the lanes of a wave sweep similar windows on both sides of the seed.
-#define LH_EXT_BINS (LH_EXT_PRIMARY * LH_EXT_SUB)
-struct DExtBins {
-    int32_t count[LH_EXT_BINS], cursor[LH_EXT_BINS];
-    int32_t range[20];   // [first,last) pairs into the bucket-sorted order: [0..1] complex (wave kernel); [8..9] = the deferred list; [16..17] = every other read (round 0 of k_ext_round); the rest: class boundaries (diagnostics)
-};
-
-// ---- pre-pass, one wave per read: per chain the reference window [rmax0,rmax1) and the seed order; per read the bucket ----
-__global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
-                                                  const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
-                                                  int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, i64* __restrict__ chain_rmax, int32_t* __restrict__ key,
-                                                  DCounters* __restrict__ ctr, const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
-    const int lane = LANE();
-    const int n_items = *list_count;   // the reads chained by the wave kernel; k_chain_lane prepares its own reads
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int r = list[item];
-    int l_query = (int)(seq_off[r + 1] - seq_off[r]);
-    if (l_query > LH_MAXLEN) l_query = 0;
-    i64 base = seed_off[r];
-    int nch = n_chains[r];
-    i64 l_pac = ix.l_pac;
-    u64 win = 0;
-    int longest = 0, shorter = 0, nseeds = 0;
-    for (int ci = 0; ci < nch; ++ci) {
-        DChain c = chains[base + ci];
-        nseeds += c.n;
-        const DSeed* sd = cseeds + base + c.seed_start;
-        int32_t* srt = sorder + base + c.seed_start;   // seed indices by (score, index) ascending
-        int32_t* done = sdone + base + c.seed_start;   // 1 = extension performed (upstream: srt[k] != 0)
-        int n = c.n;
-        if (n == 0) continue;
-        i64 r0 = l_pac << 1, r1 = 0;   // max possible span
-        for (int i = lane; i < n; i += 64) {
-            DSeed t = sd[i];
-            i64 b = t.rbeg - (t.qbeg + dev_cal_max_gap(o, t.qbeg));
-            i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_cal_max_gap(o, l_query - t.qbeg - t.len));
-            r0 = r0 < b ? r0 : b;
-            r1 = r1 > e ? r1 : e;
-        }
-        i64 rmax0 = wave_min_i64(r0), rmax1 = wave_max_i64(r1);
-        rmax0 = rmax0 > 0 ? rmax0 : 0;
-        rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
-        DSeed s0 = sd[0];
-        if (rmax0 < l_pac && l_pac < rmax1) {   // crossing the forward-reverse boundary; then choose one side
-            if (s0.rbeg < l_pac) rmax1 = l_pac;
-            else rmax0 = l_pac;
-        }
-        dev_fetch_clamp(ix, &rmax0, s0.rbeg, &rmax1);   // bns_fetch_seq clamps the window to the contig
-        win += (u64)(rmax1 - rmax0);
-        if (lane == 0) { chain_rmax[2 * (base + ci)] = rmax0; chain_rmax[2 * (base + ci) + 1] = rmax1; }
-        // order of extension: by seed score (= len) then index, descending (upstream sorts score<<32|i ascending and walks down)
-        for (int i = lane; i < n; i += 64) {
-            DSeed t = sd[i];
-            int rank = 0;
-            for (int u = 0; u < n; ++u) { DSeed x = sd[u]; rank += (x.len < t.len) || (x.len == t.len && u < i); }
-            srt[rank] = i;
-            done[i] = 1;
-            if (ci == 0 && rank == n - 1) {   // the seed extended first
-                int lt = t.qbeg, rt = l_query - t.qbeg - t.len;
-                longest = lt > rt ? lt : rt; shorter = lt > rt ? rt : lt;
-            }
-        }
-    }
-    longest = wave_max_i32(longest); shorter = wave_max_i32(shorter);
-    if (lane == 0) {
-        int prim = lh_ext_bucket(nseeds, longest, 0);   // longest extensions first
-        int sub = shorter >> 4 < LH_EXT_SUB - 1 ? shorter >> 4 : LH_EXT_SUB - 1;
-        key[r] = prim * LH_EXT_SUB + sub;
-        if (ctr) { atomicAdd(&LH_CTR(ctr)->win_bases, win); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)nch); }
-    }
-    }
-}
-
-// ---- counting sort of the reads by bucket (order inside a bucket is irrelevant: every read writes its own output slots) ----
-#define LH_EXT_SORT_PER_THREAD 4   // 1024 reads per block: device-scope atomics on 32 shared addresses are slow (~0.25 us each across the XCDs)
-__global__ void __launch_bounds__(256) k_ext_count(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins) {
-    __shared__ int32_t hist[LH_EXT_BINS];
-    for (int b = threadIdx.x; b < LH_EXT_BINS; b += 256) hist[b] = 0;
-    __syncthreads();
-    for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
-        int r = (blockIdx.x * LH_EXT_SORT_PER_THREAD + u) * 256 + threadIdx.x;
-        if (r < n_reads) atomicAdd(&hist[key[r]], 1);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < LH_EXT_BINS; b += 256) if (hist[b]) atomicAdd(&bins->count[b], hist[b]);
-}
-__global__ void __launch_bounds__(64) k_ext_offsets(DExtBins* __restrict__ bins) {
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < LH_EXT_BINS; ++b) {
-            if (b == 0) bins->range[0] = acc;
-            if (b == 1 * LH_EXT_SUB) { bins->range[1] = acc; bins->range[2] = acc; }
-            if (b == 17 * LH_EXT_SUB) { bins->range[3] = acc; bins->range[4] = acc; }
-            // class 128 runs buckets 17..24, class 64 buckets 26..33; buckets 25 and 34 (no DP expected) run without LDS: range[10..13]
-            if (b == 25 * LH_EXT_SUB) { bins->range[5] = acc; bins->range[10] = acc; }
-            if (b == 26 * LH_EXT_SUB) { bins->range[11] = acc; bins->range[6] = acc; }
-            if (b == 34 * LH_EXT_SUB) { bins->range[7] = acc; bins->range[12] = acc; }
-            bins->cursor[b] = acc; acc += bins->count[b];
-        }
-        bins->range[13] = acc; bins->range[8] = 0; bins->range[9] = 0; bins->range[14] = 0; bins->range[15] = 0;
-        bins->range[16] = bins->range[1]; bins->range[17] = acc;
-    }
-}
-__global__ void __launch_bounds__(256) k_ext_scatter(int n_reads, const int32_t* __restrict__ key, DExtBins* __restrict__ bins, int32_t* __restrict__ order) {
-    __shared__ int32_t hist[LH_EXT_BINS], basep[LH_EXT_BINS];
-    for (int b = threadIdx.x; b < LH_EXT_BINS; b += 256) hist[b] = 0;
-    __syncthreads();
-    int k[LH_EXT_SORT_PER_THREAD], rank[LH_EXT_SORT_PER_THREAD];
-    for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
-        int r = (blockIdx.x * LH_EXT_SORT_PER_THREAD + u) * 256 + threadIdx.x;
-        k[u] = r < n_reads ? key[r] : -1;
-        rank[u] = k[u] >= 0 ? atomicAdd(&hist[k[u]], 1) : 0;   // position inside the block's share of the bucket
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < LH_EXT_BINS; b += 256) if (hist[b]) basep[b] = atomicAdd(&bins->cursor[b], hist[b]);
-    __syncthreads();
-    for (int u = 0; u < LH_EXT_SORT_PER_THREAD; ++u) {
-        int r = (blockIdx.x * LH_EXT_SORT_PER_THREAD + u) * 256 + threadIdx.x;
-        if (k[u] >= 0) order[basep[k[u]] + rank[u]] = r;
-    }
-}
 
 #define EH_H(v) ((int)((v) & 0xffffu))
 #define EH_E(v) ((int)(((v) >> 16) & 0x1fffu))
@@ -374,7 +244,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
 // needs 0 .. 4 rounds on unique sequence; what is left after LH_EXT_ROUNDS, and live-interval windows that outgrow their 64
 // columns, goes to the wave-per-read kernel as before.  Same calls, same arguments, same order per read as mem_chain2aln.
 #ifndef LH_EXT_ROUNDS
-#define LH_EXT_ROUNDS 4   // every round ends with the latency of its slowest DP (~0.2 ms): what is left after four (1 % of the reads) is cheaper in the wave kernel (tests also build with 2)
+#define LH_EXT_ROUNDS 6   // every round ends with the latency of its slowest DP (~0.2 ms): what is left after six goes to the wave kernel (tests also build with 2)
 #endif
 #define LH_EXT_JOB_BINS 1536
 struct ExtSt { int32_t w0, narrow, sc0, pad; };   // w0: chain | seed rank << 8 | regions so far << 16 | side << 24 | band try << 25 | (left side used the doubled band) << 26
@@ -384,6 +254,7 @@ struct DExtJobs {
     int32_t range[2 * (LH_EXT_ROUNDS + 2)];   // [2k, 2k+1] = the sorted order's slice round k runs
     int32_t next[LH_EXT_ROUNDS + 2];          // round k's slice counter: its waves take slices of 64 jobs in the sorted order (heaviest bins first)
     int32_t kinds[3 * (LH_EXT_ROUNDS + 2)];   // diagnostics: narrow / live-interval / short full-band jobs of round k
+    int32_t wave_range[2], heavy_range[2], defer_range[2];   // [0, n): the reads the wave kernels chain and extend (k_chain_lane's list); the reads round 0 / the later rounds left to the wave extension kernel
 };
 // job key: bins 0..959 = narrow band in the circular window (same w: same cells per row), 960..1215 = full band in the live-interval window, 1216..1471 = full band, fewer than 64 columns
 // bins in the order they should START (a round's tail is its last waves: the cheap ones): wide bands and long query sides first
@@ -449,35 +320,23 @@ __global__ void __launch_bounds__(256) k_extj_scatter(const int32_t* __restrict_
     }
 }
 
-// One round.  DP = false: the first round — lane g starts read order[g] (the reads bucket-sorted by k_chain_lane's keys, minus the
-// complex ones) and runs it up to its first job.  DP = true: lane g runs the queued ksw_extend2 call of read order[g], then the
-// read's control flow up to its next job.  A read that finishes writes n_regs; one that queues a job appends itself to next_list
-// (key in next_key); a live-interval window that overflows, or a job queued in the last round (next_* = the deferred list),
-// leaves the read to the wave-per-read kernel, which redoes it from scratch.
+struct ExtArgs {   // what a read's control flow reads and writes
+    const uint8_t* seq; const uint32_t* q4; const i64* seq_off; const i64* seed_off; const DChain* chains; const DSeed* cseeds; const int32_t* n_chains;
+    const int32_t* sorder; int32_t* sdone; const i64* chain_rmax; const i64* reg_off; DReg* regs; int32_t* n_regs; ExtSt* est;
+};
+// mem_chain2aln for read r, from the start (DP = false) or from its queued ksw_extend2 call (DP = true: the call is made here, in
+// the lane's LDS window ehl), up to the next call that needs a DP.  Returns 0: the read is finished (n_regs written); 1: a call was
+// queued (state saved, *key = its bin); 2: the read is left to the wave-per-read kernel (a live-interval window outgrew its 64 columns,
+// or — first seed of the read only, as before — a long side whose diagonal loses LH_NARROW_MAX_LOSS or more, e.g. behind an indel:
+// one full-band DP of that size keeps a lane busy for most of a millisecond).
 template <bool DP>
-__global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int32_t* __restrict__ range, int32_t* __restrict__ slice_ctr, const int32_t* __restrict__ order, ExtSt* __restrict__ est,
-                                                   int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key,
-                                                   int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list,
-                                                   const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off,
-                                                   const DChain* __restrict__ chains, const DSeed* __restrict__ cseeds, const int32_t* __restrict__ n_chains,
-                                                   const int32_t* __restrict__ sorder, int32_t* __restrict__ sdone, const i64* __restrict__ chain_rmax,
-                                                   const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs, DCounters* __restrict__ ctr) {
-    __shared__ uint32_t ehl[DP ? 64 * 64 : 1];
-    const int lane = LANE();
-    const int first = range[0], last = range[1];
+__device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, const ExtArgs& A, const int r, uint32_t* ehl, const int lane, int* key_out, u64* cells_out) {
+    const uint8_t* seq = A.seq; const uint32_t* q4 = A.q4; const i64* seq_off = A.seq_off; const i64* seed_off = A.seed_off; const DChain* chains = A.chains;
+    const DSeed* cseeds = A.cseeds; const int32_t* n_chains = A.n_chains; const int32_t* sorder = A.sorder; int32_t* sdone = A.sdone; const i64* chain_rmax = A.chain_rmax;
+    const i64* reg_off = A.reg_off; DReg* regs = A.regs; int32_t* n_regs = A.n_regs; ExtSt* est = A.est;
+    int out = 0, key = 0;
     u64 cells = 0;
-    for (int blk = blockIdx.x;; blk += gridDim.x) {
-    if (DP) {   // persistent waves, slices handed out in order: the expensive bins start first, the cheap ones fill the tail
-        int nb = 0;
-        if (lane == 0) nb = atomicAdd(slice_ctr, 1);
-        blk = wave_readlane(nb, 0);
-    }
-    if (first + blk * 64 >= last) break;
-    const int g = first + blk * 64 + lane;
-    const int r = g < last ? order[g] : -1;
-    int out = 0, key = 0;   // out: 1 = a job was queued, 2 = the read is left to the wave kernel
-    if (r >= 0) {
-        const u64 cells0 = cells;
+    {
         const i64 off = seq_off[r];
         int l_query = (int)(seq_off[r + 1] - off);
         if (l_query > LH_MAXLEN) l_query = 0;
@@ -540,6 +399,7 @@ __global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int3
                     a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid;
                     aw0 = o.w; side = 0;
                 }
+                const bool first_seed = !DP && ci == 0 && n_av == 0 && k == n - 1;
                 int aw1 = o.w;
                 while (side < 2 && !out) {   // 0 = left (reversed query prefix vs reversed reference prefix), 1 = right
                     int qoff, qstep, qlen, tstep, tlen, bonus, h0;
@@ -577,26 +437,16 @@ __global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int3
                         if (tlen >= qlen) {
                             const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
                             const int p_cap = o.zdrop > 0 && o.zdrop < LH_NARROW_MAX_LOSS ? o.zdrop : LH_NARROW_MAX_LOSS;
-                            LaneTgt tg;
-                            tg.init(ix, tc0, tstep);
-                            int P = 0, sc_run = h0, mx = h0, mxk = -1, kk = 0;
-                            for (; kk < qlen; ++kk) {
-                                int qv = q[qoff + qstep * kk], tb = tg.base(kk);
-                                int sc = qv > 3 ? -1 : (tb == qv ? o.a : -o.b);
-                                P += o.a - sc;
-                                sc_run += sc;
-                                if (P >= p_cap || sc_run <= 0) break;
-                                if (sc_run > mx) { mx = sc_run; mxk = kk; }
-                            }
-                            if (kk == qlen && P < thr) {
-                                e.score = mx; e.qle = mxk + 1; e.tle = mxk + 1; e.gscore = sc_run; e.gtle = qlen; e.max_off = 0;
+                            const DiagScan ds = dev_diag_scan(ix, o, q, q4, off, qoff, qstep, qlen, tc0, tstep, h0, p_cap);
+                            if (ds.done && ds.P < thr) {
+                                e.score = ds.mx; e.qle = ds.mxk + 1; e.tle = ds.mxk + 1; e.gscore = ds.sc_run; e.gtle = qlen; e.max_off = 0;
                                 a.score = e.score;
                                 proven = 1;
-                            } else if (kk == qlen) {
+                            } else if (ds.done) {
                                 narrow = 1;
-                                while (o.o_ins + o.e_ins * (narrow + 1) <= P || o.o_del + o.e_del * (narrow + 1) <= P) ++narrow;
-                            }
-                        }
+                                while (o.o_ins + o.e_ins * (narrow + 1) <= ds.P || o.o_del + o.e_del * (narrow + 1) <= ds.P) ++narrow;
+                            } else if (first_seed && qlen >= LH_EXT_HEAVY_COLS) { out = 2; break; }
+                        } else if (first_seed && qlen >= LH_EXT_HEAVY_COLS) { out = 2; break; }
                         if (!proven) {   // queue the call: the first try of MAX_BAND_TRY
                             tri = 0;
                             key = lh_ext_job_key(narrow, qlen, h0);
@@ -659,27 +509,54 @@ __global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int3
             st.w0 = ci | k << 8 | n_av << 16 | side << 24 | tri << 25 | (aw0 != o.w ? 1 : 0) << 26; st.narrow = narrow; st.sc0 = sc0; st.pad = 0;
             est[r] = st;
             av[n_av] = a;
-        } else cells = cells0;   // the read is redone from scratch: its cells are counted there
+        } else cells = 0;   // the read is redone from scratch: its cells are counted there
     }
-    {
-        const u64 em = __ballot(out == 1);
-        if (em) {
-            int basep = 0;
-            if (lane == 0) basep = atomicAdd(next_count, (int32_t)__popcll(em));
-            basep = wave_readlane(basep, 0);
-            if (out == 1) { const int p = basep + lanes_below(em, lane); next_list[p] = r; if (next_key) next_key[p] = key; }
-        }
-        const u64 dm = __ballot(out == 2);
-        if (dm) {
-            int basep = 0;
-            if (lane == 0) basep = atomicAdd(defer_count, (int32_t)__popcll(dm));
-            basep = wave_readlane(basep, 0);
-            if (out == 2) defer_list[basep + lanes_below(dm, lane)] = r;
-        }
+    *key_out = key;
+    *cells_out += cells;
+    return out;
+}
+
+// wave-wide: the lanes whose read queued a call (out == 1) / is left to the wave kernel (out == 2) append it to the lists
+__device__ __forceinline__ void ext_append(int out, int r, int key, int lane, int32_t* next_count, int32_t* next_list, int32_t* next_key, int32_t* defer_count, int32_t* defer_list) {
+    const u64 em = __ballot(out == 1);
+    if (em) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(next_count, (int32_t)__popcll(em));
+        basep = wave_readlane(basep, 0);
+        if (out == 1) { const int p = basep + lanes_below(em, lane); next_list[p] = r; if (next_key) next_key[p] = key; }
     }
+    const u64 dm = __ballot(out == 2);
+    if (dm) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(defer_count, (int32_t)__popcll(dm));
+        basep = wave_readlane(basep, 0);
+        if (out == 2) defer_list[basep + lanes_below(dm, lane)] = r;
     }
-    if (DP && ctr) {
-        uint32_t lo = (uint32_t)cells;   // < 2^32 cells per read
+}
+// One round.  Lane g runs the queued ksw_extend2 call of read order[g], then the read's control flow up to its next call (ext_control).
+// A read that queues a call appends itself to next_list (its bin in next_key); one that is left to the wave kernel, or queues a call
+// in the last round (next_* = the deferred list), appends itself to the deferred list.  (Round 0 — every read up to its first call —
+// runs at the end of k_chain_lane, k_chain.h.)
+__global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int32_t* __restrict__ range, int32_t* __restrict__ slice_ctr, const int32_t* __restrict__ order, ExtArgs A,
+                                                   int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key,
+                                                   int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list, DCounters* __restrict__ ctr) {
+    __shared__ uint32_t ehl[64 * 64];
+    const int lane = LANE();
+    const int first = range[0], last = range[1];
+    u64 cells = 0;
+    for (;;) {   // persistent waves, slices handed out in order: the expensive bins start first, the cheap ones fill the tail
+        int nb = 0;
+        if (lane == 0) nb = atomicAdd(slice_ctr, 1);
+        const int blk = wave_readlane(nb, 0);
+        if (first + blk * 64 >= last) break;
+        const int g = first + blk * 64 + lane;
+        const int r = g < last ? order[g] : -1;
+        int out = 0, key = 0;
+        if (r >= 0) out = ext_control<true>(ix, o, A, r, ehl, lane, &key, &cells);
+        ext_append(out, r, key, lane, next_count, next_list, next_key, defer_count, defer_list);
+    }
+    if (ctr) {
+        uint32_t lo = (uint32_t)cells;   // < 2^32 cells per lane
         u64 tot = (u64)(uint32_t)wave_sum_i32((int)(lo >> 16)) << 16;
         tot += (u64)(uint32_t)wave_sum_i32((int)(lo & 0xffff));
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->ext_cells, tot);

@@ -118,6 +118,7 @@ struct DIndex {
     const uint8_t* pac;      // 2-bit forward reference, MSB first
     const i64* contig_off;   // [n_contigs]
     const int32_t* contig_len;
+    const uint8_t* contig_alt;   // [n_contigs] bntann1_t.is_alt (the .alt file, bwa_idx_load BWA_IDX_ALL: gobwa.go:130); null: no ALT contigs
     const int32_t* rid_bins; // contig holding forward position (b << rid_bin_shift), b = 0 .. l_pac >> shift: bns_pos2rid in one read + a short walk
     int32_t rid_bin_shift;
     u64 primary, L2[5], seq_len;
@@ -374,6 +375,86 @@ struct LaneTgt {
         return (int)((w >> (8 * (int)((ii >> 2) & 3) + (int)((~ii & 3) << 1))) & 3) ^ comp;
     }
 };
+
+// ------------------------------------------------------------------ ungapped extension profile (K3's routing, K4's shortcuts)
+// eight 4-bit symbols from position p of a packed stream (symbol i at bits 4*(i&7) of word i>>3; p >= -16: the streams are padded)
+__device__ __forceinline__ uint32_t dev_nib8(const uint32_t* __restrict__ a, i64 p) {
+    const i64 w = p >> 3;
+    const int sh = (int)(p & 7) * 4;
+    const uint32_t lo = a[w], hi = a[w + 1];
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+}
+// The diagonal of a ksw_extend2 call: query base k = q[qoff + qstep * k] against the text at tc0 + tstep * k (fwd||rev coordinates),
+// k = 0 .. qlen - 1, scored like the DP scores a diagonal step.  P = score lost against all-matches, sc_run = h0 + the diagonal's
+// score, mx / mxk = the first maximum of the running score over k (mx = h0, mxk = -1: never above h0).  The walk stops when P reaches
+// p_cap or the running score drops to zero (done = 0).  With the 4-bit text (DIndex::tn) and the batch's 4-bit reads (q4; q4pos = the
+// stream position of q[0]) eight bases are one XOR; otherwise base by base from the 2-bit reference.
+struct DiagScan { int done, P, sc_run, mx, mxk; };
+__device__ __forceinline__ DiagScan dev_diag_scan(const DIndex& ix, const DOpts& o, const uint8_t* __restrict__ q, const uint32_t* __restrict__ q4, i64 q4pos, int qoff, int qstep,
+                                                  int qlen, i64 tc0, int tstep, int h0, int p_cap) {
+    DiagScan d;
+    d.P = 0; d.sc_run = h0; d.mx = h0; d.mxk = -1; d.done = 0;
+    int k = 0;
+    if (ix.tn && q4) {
+        const i64 qp = q4pos + qoff;
+        for (; k < qlen; k += 8) {
+            const int nb = qlen - k < 8 ? qlen - k : 8;
+            uint32_t qw, tw, x;
+            if (qstep > 0) {   // symbol j of the words = step k + j
+                qw = dev_nib8(q4, qp + k); tw = dev_nib8(ix.tn, tc0 + k);
+                x = (qw ^ tw) & (nb < 8 ? (1u << (4 * nb)) - 1u : 0xffffffffu);
+            } else {           // symbol j = step k + 7 - j
+                qw = dev_nib8(q4, qp - k - 7); tw = dev_nib8(ix.tn, tc0 - k - 7);
+                x = (qw ^ tw) & (nb < 8 ? ~((1u << (4 * (8 - nb))) - 1u) : 0xffffffffu);
+            }
+            if (x == 0) {   // nb matches: the running score rises with every step
+                d.sc_run += nb * o.a;
+                if (d.sc_run > d.mx) { d.mx = d.sc_run; d.mxk = k + nb - 1; }
+                continue;
+            }
+            int stop = 0;
+            for (int u = 0; u < nb; ++u) {
+                const int j = qstep > 0 ? u : 7 - u;
+                const int qv = (int)((qw >> (4 * j)) & 0xf), ne = (int)((x >> (4 * j)) & 0xf);
+                const int sc = qv > 3 ? -1 : (ne ? -o.b : o.a);
+                d.P += o.a - sc;
+                d.sc_run += sc;
+                if (d.P >= p_cap || d.sc_run <= 0) { stop = 1; break; }
+                if (d.sc_run > d.mx) { d.mx = d.sc_run; d.mxk = k + u; }
+            }
+            if (stop) return d;
+        }
+        d.done = 1;
+        return d;
+    }
+    LaneTgt tg;
+    tg.init(ix, tc0, tstep);
+    for (; k < qlen; ++k) {
+        int qv = q[qoff + qstep * k], tb = tg.base(k);
+        int sc = qv > 3 ? -1 : (tb == qv ? o.a : -o.b);
+        d.P += o.a - sc;
+        d.sc_run += sc;
+        if (d.P >= p_cap || d.sc_run <= 0) return d;
+        if (d.sc_run > d.mx) { d.mx = d.sc_run; d.mxk = k; }
+    }
+    d.done = 1;
+    return d;
+}
+// the batch's reads as a 4-bit stream (base i of the batch buffer at symbol i; non-bases = 4), two words of padding in front
+__global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ seq, i64 n_bases, uint32_t* __restrict__ q4) {
+    const i64 nw = (n_bases + 7) / 8;   // (the batch buffer is 8-aligned and padded past n_bases)
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < nw + 2; w += (i64)gridDim.x * blockDim.x) {
+        u64 v8 = 0x0404040404040404ull;
+        if (w < nw) __builtin_memcpy(&v8, __builtin_assume_aligned(seq + w * 8, 8), 8);
+        uint32_t v = 0;
+        for (int b = 0; b < 8; ++b) {
+            const i64 i = w * 8 + b;
+            uint32_t c = i < n_bases ? (uint32_t)((v8 >> (8 * b)) & 0xff) : 4;
+            v |= (c > 4 ? 4u : c) << (4 * b);
+        }
+        q4[w] = v;
+    }
+}
 
 __device__ __forceinline__ int dev_pos2rid(const DIndex& ix, i64 pos_f) {
     int left, mid, right;
