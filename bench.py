@@ -208,8 +208,8 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
     # (K4's lane kernels take as long per step, but they are integer DP out of LDS: neither an HBM nor an MFMA roofline applies to them)
     dom = "k_smem4" if "k_smem4" in avg else max(avg, key=avg.get)
     share = 1.0 / a.lanes   # a launch of the timed lane covers this share of the step's pairs (uniform barcodes: the cut is at the middle)
-    k1 = {"k_smem4": ("k_smem4_t<3>", "n_ext_exec_p1", "n_ktree_p1"), "k_smem4_p2": ("k_smem4_t<4>", "n_ext_exec_p2", "n_ktree_p2"),
-          "k_smem4_p3": ("k_smem4_t<2>", "n_ext_exec_p3", "n_ktree_p3")}
+    k1 = {"k_smem4": ("k_smem_pass<1>", "n_ext_exec_p1", "n_ktree_p1"), "k_smem4_p2": ("k_smem_pass<2>", "n_ext_exec_p2", "n_ktree_p2"),
+          "k_smem4_p3": ("k_smem_pass<3>", "n_ext_exec_p3", "n_ktree_p3")}
     n_bases = int(reads["seq_off"][-1])
     pmc = None
     if os.path.exists(PMC_FILE):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 2
+#define LH_ABI_VERSION 3
 
 /* status codes */
 #define LH_OK 0
@@ -73,12 +73,12 @@ typedef struct lh_opts {
 
 /* lh_opts.flags (development / measurement; the defaults are the measured best) */
 #define LH_F_NO_SWEEP_FILTER 1u  /* K1 sweeps every interval like bwt_smem1a does (n_ext then counts every bwt_extend of the reference) */
-#define LH_F_SMEM_FUSED 2u       /* K1's three passes in one launch */
-#define LH_F_SMEM_P12 4u         /* K1's passes 1+2 in one launch, pass 3 in another */
-#define LH_F_SMEM_LANE 8u        /* K1 as BWA's loop nest, one lane per read (k_smem3.h) */
+#define LH_F_SMEM_FUSED 2u       /* (reserved: accepted and ignored since r03 — K1 is always one launch per pass) */
+#define LH_F_SMEM_P12 4u         /* (reserved, ignored) */
+#define LH_F_SMEM_LANE 8u        /* (reserved, ignored) */
 #define LH_F_EXT_WAVE 16u        /* K4 wave-per-read only */
-#define LH_F_EXT_SERIAL 32u      /* K4's classes one after the other on one stream (per-class timings) */
-#define LH_F_SMEM_SPLIT 64u      /* K1 pass 1 as two kernels: the forward walks of every read, then the backward sweeps as independent work items */
+#define LH_F_EXT_SERIAL 32u      /* K4's rounds and wave-kernel launches one after the other on one stream (per-round timings) */
+#define LH_F_SMEM_SPLIT 64u      /* (reserved, ignored) */
 
 /* how an index is made resident (lh_index_load / lh_index_from_arrays / lh_index_build_device); NULL = defaults */
 typedef struct lh_index_opts {
@@ -181,6 +181,8 @@ typedef struct lh_result {
     uint64_t n_ext_exec_p1, n_ext_exec_p2, n_ext_exec_p3;
     /* bwt_extend results K1 read from its k-mer tree table instead (one 16-B entry each), per pass */
     uint64_t n_ktree_p1, n_ktree_p2, n_ktree_p3;
+    /* bwt_smem1a calls of pass 1 that K1 decided from the text at the read's known locus (two PLCP bytes + the comparison; their bwt_extend calls are in neither count) */
+    uint64_t n_calls_by_text;
     void* arena_; /* private */
 } lh_result;
 

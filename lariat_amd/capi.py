@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LARIAT_HIP_LIB") or os.path.join(_HERE, "_build", "liblariat_hip.so")
 
 LH_OK = 0
-LH_ABI_VERSION = 2
+LH_ABI_VERSION = 3
 LH_E_ARG, LH_E_IO, LH_E_HIP, LH_E_CAPACITY, LH_E_NODEVICE, LH_E_LIMIT = 1, 2, 3, 4, 5, 6
 # lh_opts.flags
 LH_REC_DEBUG_TAGS = 1
@@ -83,7 +83,7 @@ _RESULT_READ_FIELDS = [
     ("as_score", c_f64p, np.float64), ("split_idx", c_i64p, np.int64), ("split_mapq", c_i32p, np.int32),
     ("split_second_best", c_f64p, np.float64), ("split_score", c_f64p, np.float64),
 ]
-_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3", "n_ktree_p1", "n_ktree_p2", "n_ktree_p3"]
+_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3", "n_ktree_p1", "n_ktree_p2", "n_ktree_p3", "n_calls_by_text"]
 
 
 class LhResult(C.Structure):

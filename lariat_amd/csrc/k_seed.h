@@ -106,8 +106,10 @@ __global__ void __launch_bounds__(256) k_seed(DIndex ix, DOpts o, int n_reads, c
                 if ((u64)u < c) { x0 = iv[t].x0; step = st; info = iv[t].info; break; }
                 u -= (i64)c;
             }
-            i64 rbeg = (i64)dev_sa(ix, x0 + (u64)u * step, &nlf);
-            nsa = 1;
+            i64 rbeg;
+            if (x0 >> 62 & 1) rbeg = (i64)(x0 & ~(1ull << 62));   // K1 stored the interval's one occurrence by its text position (LH_POSF, k_smem4.h)
+            else rbeg = (i64)dev_sa(ix, x0 + (u64)u * step, &nlf);
+            nsa = 1;   // (n_sa counts the reference's bwt_sa calls: one per seed)
             int qbeg = (int)(info >> 32), slen = (int)(uint32_t)info - qbeg;
             DSeed sd;
             sd.rbeg = rbeg; sd.qbeg = qbeg; sd.len = slen;

@@ -1,34 +1,34 @@
-// k_smem4.h — K1 v4: SMEM seeding with PERSISTENT lanes (one read per lane, every lane always busy).
+// k_smem4.h — K1: SMEM seeding with PERSISTENT lanes (one read per lane, every lane always busy), one launch per pass.
+// mem_collect_intv (bwt_smem1a passes 1 + 2 and bwt_seed_strategy1), reached from go/src/gobwa/gobwa.go:244,253.
 //
-// Measured on MI355X (profiles/r01_*): with one lane per read but BWA's loop nest kept as written (k_smem3.h), the lanes of
-// a wave drift into different loops and the hardware serialises them: 13 of 64 lanes are active on average, so the wave
-// has ~13 x 2 occurrence-block reads in flight instead of 128 and issues 5x more instructions than needed.
+// Measured on MI355X (profiles/r01_*): with one lane per read but BWA's loop nest kept as written, the lanes of a wave drift
+// into different loops and the hardware serialises them: 13 of 64 lanes are active on average.  Here a pass is a per-lane STATE
+// MACHINE around one shared program point: in every turn of the main loop each lane that has a bwt_extend pending performs it (all
+// lanes together: their table reads in flight at the same time), then each lane does the bookkeeping of the loop it is in (forward
+// extension / backward sweep / pass 3) and prepares its next request.  A lane that finishes its read takes the next one from the
+// wave's chunk (chunks of 64 reads come from one device counter), so no lane waits for the slowest read of a batch.  The arithmetic
+// and the order of list operations per read are exactly those of bwt_smem1a / bwt_seed_strategy1: only the interleaving across reads
+// differs — and work of the reference that is PROVABLY without effect is left out:
 //
-// Here mem_collect_intv (bwt_smem1a passes 1+2 and bwt_seed_strategy1; reached from go/src/gobwa/gobwa.go:244,253) is a
-// per-lane STATE MACHINE around one shared program point: in every turn of the main loop each lane that has a
-// bwt_extend pending performs it (all lanes together: 2 x 64-B block reads per lane in flight), then each lane does the
-// bookkeeping of the loop it is in (forward extension / backward sweep / pass 3) and prepares its next request.  A lane
-// that finishes its read takes the next one from the wave's chunk (chunks of 64 reads come from one device counter), so
-// no lane waits for the slowest read of a batch.  The arithmetic and the order of list operations per read are exactly
-// those of bwt_smem1a / bwt_seed_strategy1: only the interleaving across reads differs.
+//  - UNIQUE RUNS: once a match has a single occurrence (interval size 1), extending it is comparing the read with the text at that
+//    occurrence.  With a fully resident suffix array the lane looks the position up once (sa[x0]) and then advances sixteen bases per
+//    turn by XOR-ing 4-bit packed read and text words, instead of one base per turn through two occurrence records.
+//  - POSITIONS INSTEAD OF ROWS (new in r03): an interval that a run produced has one occurrence, and everything downstream (pass 2's
+//    probe, pass 3's text walks, K2's seeds) wants that occurrence's text position — which the run knows — not its suffix-array row,
+//    which used to cost an inverse-suffix-array read per run end (and K2 a suffix-array read to undo it).  Such an interval is stored
+//    as x0 = LH_POSF | position of its first base, x1 = 0, x2 = 1; k_intv_rows turns it back into rows for the stage dump.  What the
+//    sweep needs to know about a unique match's neighbourhood comes from the PLCP array (DIndex::plcp, indexed by text position).
+//  - CALLS BY TEXT (new in r03): after a read's first unique run the lane knows a locus P where the read (mostly) lies.  A later
+//    bwt_smem1a call from x is decided from the text at P alone when that is provable (see START_SMEM1): two PLCP bytes and the
+//    comparison with the text replace the ~18 tree / occurrence steps of the forward walk, their filter reads and the sweep.
+//  - SWEEP FILTER, K-MER TREE TABLE, COLLAPSED SWEEPS, FORWARD JUMP, PASS-2 PROBE, PASS 3 BY TEXT: see the blocks below.
 //
-//  - UNIQUE RUNS: once a match has a single occurrence (interval size 1), extending it is comparing the read with the text at
-//    that occurrence.  With a fully resident suffix array the lane looks the position up once (sa[x0]) and then advances
-//    sixteen bases per turn by XOR-ing 4-bit packed read and text words, instead of one base per turn through two
-//    occurrence records; the interval bound that changes meanwhile (x1 forward, x0 backward) is read back once from the
-//    inverse suffix array when the run ends (the other bound provably stays put while the size is 1).  Used for the
-//    forward extension of bwt_smem1a and for backward rows with one surviving interval: most of a read's steps.
-//  - SWEEP FILTER: intervals of the forward list that provably cannot yield a seed are left out of the backward sweep (two Bloom
-//    filters over the text's 19-mers, see BLOOM_ISSUE below): 41 % of the reference's bwt_extend calls disappear.
-//  - PASS-SPECIFIC INSTANCES: the kernel is a template over the passes it carries (k_smem4_t<MODE>); the host launches pass 1,
-//    pass 2 and pass 3 one after the other, each with only its own states (fewer instructions per turn, fewer registers).
-//  - pass 3 starts its walks from the bi-interval of the first 12 bases (a table built on load).
 //  - query: 4-bit packed in LDS (8 bases per word, word w of lane L at qn[w*64+L]), staged by the whole wave
-//  - prev/curr interval lists: 16-B packed entries in an HBM slab interleaved by thread; the entry the next row starts
-//    with stays in registers (and is never written to the slab: most backward rows have a single survivor) and the
-//    following one is prefetched while the current extension is in flight
+//  - prev/curr interval lists: 16-B packed entries in an HBM slab interleaved by thread; the entry the next row starts with stays in
+//    registers (and is never written to the slab: most backward rows have a single survivor) and the following one is prefetched
+//    while the current extension is in flight
 #pragma once
-#include "k_smem3.h"
+#include "lh_dev.h"
 
 struct __attribute__((aligned(16))) PEnt { u64 lo, hi; };   // x0:40 | x2[0..23]  /  x1:40 | x2[24..32] | info:15
 #define LH_M40 0xffffffffffull
@@ -42,6 +42,7 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define PE_X1(e) ((e).hi & LH_M40)
 #define PE_X2(e) (((e).lo >> 40) | ((((e).hi >> 40) & 0x1ffull) << 24))
 #define PE_INFO(e) ((int)((e).hi >> 49))
+#define LH_POSF (1ull << 62)   // DIntv::x0 of an interval with ONE occurrence, stored by text position: x0 = LH_POSF | position of its first base
 
 #define S4_FETCH 0
 #define S4_DONE 1
@@ -65,24 +66,24 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define S4_BRUN_INIT 20
 #define S4_BRUN_INIT2 21
 #define S4_BRUN_END 22
-#define S4_BRUN_END2 23
-#define S4_P3_JUMP 24    // pass 3: the walk's first 12 bases come from the 12-mer table
+#define S4_TRI_C1 23     // the collapsed sweep did not apply: the longest entry's second row bound (not kept by a run) is read back before the sweep as written
+#define S4_P3_JUMP 24    // pass 3: the walk's first bases come from the k-mer tree table
 #define S4_P3_JUMP2 25
-#define S4_TRI_LCP 26    // the sweep of a forward list whose longest entry is unique, decided from the LCP array (see BWD_ROW_BODY)
-#define S4_TRI_LCP2 27
+#define S4_TRI_C1B 26
+#define S4_TRI_LCP2 27   // the sweep of a forward list whose longest entry is unique, decided from the PLCP array (see BWD_ROW_BODY)
 #define S4_FJUMP 28      // forward extension: the first levels of the walk in one read of the k-mer tree (see START_SMEM1)
 #define S4_FJUMP2 29
 #define S4_P2_PROBE 30   // pass 2: can the re-seeding inside this SMEM yield a seed at all? (DIndex::rep_t, see S4_P2_NEXT)
 #define S4_P2_PROBE2 31
 #define S4_P2_PROBE3 32
-#define S4_FETCH_SKIP 33
-#define S4_P3_PREP 35     // pass 3 by text (MODE 2, see P3TEXT): positions of the read's unique SMEMs, then one walk = three table reads
+#define S4_P3_PREP 35    // pass 3 by text (see P3TEXT): positions of the read's unique SMEMs, then a batch of walks = one PLCP byte each
 #define S4_P3_PREP2 36
 #define S4_P3_PREP3 37
 #define S4_P3_T0 38
 #define S4_P3_T1 39
-#define S4_P3_T2 40
-#define S4_PENDING 34     // one of the shared blocks below runs for this lane before the turn's extensions (todo says which)
+#define S4_BT_INIT 40    // pass 1, a bwt_smem1a call decided from the text at the read's known locus (see START_SMEM1)
+#define S4_BT_B 41
+#define S4_PENDING 34    // one of the shared blocks below runs for this lane before the turn's extensions (todo says which)
 #define TD_ROW 1          // BWD_ROW_BODY
 #define TD_SMEM 2         // START_SMEM1
 #define TD_FADV 4         // BLOOM_ISSUE + FWD_ADVANCE
@@ -90,7 +91,7 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #define LH_KMER 12
 
 #ifndef LH_SLOW_BATCH
-#define LH_SLOW_BATCH 4       // pass 1 (and the kernels that carry it)
+#define LH_SLOW_BATCH 4       // pass 1
 #endif
 #ifndef LH_SLOW_BATCH_P2
 #define LH_SLOW_BATCH_P2 16   // the pass-2 and pass-3 kernels: their lanes spend a larger share of their turns in the batched states, and a batched
@@ -101,43 +102,23 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
 #endif
-// MODE 0: the three passes of mem_collect_intv in one kernel; 1: passes 1 and 2; 3: pass 1; 4: pass 2 (re-seeding inside the
-// long SMEMs pass 1 left, recognised from the stored intervals); 2: pass 3 only, appended to the
-// intervals the earlier launches left (pass 3 depends on the read alone, and the intervals are sorted afterwards: running it as
-// its own small kernel — a quarter of the instructions per turn, twice the waves — gives the same interval array).
-// MODE 5 / 6: pass 1 as TWO kernels.  A bwt_smem1a call is a forward walk (which alone decides where the next call starts: its
-// return value is the end of the longest forward match) and a backward sweep over the list the walk leaves.  MODE 5 makes the
-// forward walks of a read one after the other and hands every list to MODE 6 as an ITEM (start, end, the list's entries copied to a
-// pool, its last entry, emin); MODE 6 sweeps items, one per lane, whatever read they belong to, and appends the MEMs to the read's
-// interval array through its counter (their order does not matter: k_smem_fin sorts by `info`, and equal keys are equal intervals).
-// Each kernel carries half of the states — fewer instructions per turn, so the memory system rather than instruction issue sets the
-// pace — and the unit of work in the second one is a sweep, not a read (short tails).  Same Less / extend sequence per call.
-struct __attribute__((aligned(16))) K1Item { int32_t r, x, ret, nlist; PEnt ce; int32_t emin, list_off, pad0, pad1; };
-struct K1Split {
-    K1Item* items; PEnt* pool;
-    int32_t* ctr;          // [0] item slots handed out, [1] pool entries handed out, [2] set when either ran out, [3] MODE 6's fetch cursor
-    int32_t item_cap, pool_cap;
-};
-#define LH_K1_ITEM_CHUNK 256
-#define LH_K1_POOL_CHUNK 1024
-template <int MODE>
-__global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+// PASS 1: all SMEMs of the read (bwt_smem1a with min_intv 1 from every position the previous call returned).  PASS 2: re-seeding inside
+// the long SMEMs pass 1 left (recognised from the stored intervals).  PASS 3: bwt_seed_strategy1, appended to the intervals the earlier
+// launches left (it depends on the read alone, and the intervals are sorted afterwards).  Each launch carries only its own states:
+// fewer instructions per turn, fewer registers.
+template <int PASS>
+__global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pass(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
-                                               int32_t* __restrict__ next_read, DCounters* __restrict__ ctr, K1Split sp) {
+                                               int32_t* __restrict__ next_read, DCounters* __restrict__ ctr) {
     __shared__ uint32_t qn[32 * 64];
-    constexpr bool FWD_ONLY = MODE == 5, BWD_ONLY = MODE == 6;
-    constexpr bool P3T = MODE == 2;
-    // PASS 3 BY TEXT (the pass-3 kernel, with a dense suffix array).  A walk of bwt_seed_strategy1 from x ends at the first length
-    // L >= min_seed_len + 1 where the match occurs fewer than max_mem_intv times.  If [x, x + Lw), Lw = min_seed_len + 1, lies inside a
-    // UNIQUE SMEM of the read (pass 1 left it in the read's interval array; its text position is one suffix-array read per SMEM), the
-    // read equals the text there: the Lw-mer's row is the inverse suffix array at that position, it is unique iff both LCP neighbours
-    // of the row share fewer than Lw bases, and then the walk's result is (that row, the row of the reverse strand's copy, 1) at
-    // length exactly Lw — three table reads instead of a tree read and six occurrence records.  Anything else: the walk as written.
-#ifdef LH_NO_P3TEXT   // A/B builds
-    const bool P3TEXT = false;
-#else
-    const bool P3TEXT = P3T && ix.isa != nullptr && ix.lcp != nullptr && o.max_mem_intv > 1;
-#endif
+    constexpr bool DO1 = PASS == 1, DO2 = PASS == 2, DO12 = DO1 || DO2, DO3 = PASS == 3, P3T = PASS == 3;
+    // PASS 3 BY TEXT (with a dense suffix array).  A walk of bwt_seed_strategy1 from x ends at the first length L >= min_seed_len + 1
+    // where the match occurs fewer than max_mem_intv times.  If [x, x + Lw), Lw = min_seed_len + 1, lies inside a UNIQUE SMEM of the read
+    // (pass 1 left it in the read's interval array, usually with its text position), the read equals the text there: the Lw-mer is unique
+    // iff the suffix at its position shares fewer than Lw bases with every other suffix (one PLCP byte), and then the walk's result is
+    // that one occurrence at length exactly Lw.  Consecutive walks of an SMEM start Lw apart: their bytes are read together.  Anything
+    // else: the walk as written.
+    const bool P3TEXT = P3T && ix.isa != nullptr && ix.plcp != nullptr && o.max_mem_intv > 1;
     const int Lw = o.min_seed_len + 1;
     uint32_t uspan = 0;   // the read's two longest unique SMEMs [us, ue) (reads have at most 250 bases: a byte each), at text positions up0 / up1
 #define P3_NOTEXT (1 << 30)   // kept in rst (the read's status bits), cleared before they are stored: "this walk start was tried by text and is not unique"
@@ -146,25 +127,21 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #define UE0 ((int)((uspan >> 8) & 0xff))
 #define US1 ((int)((uspan >> 16) & 0xff))
 #define UE1 ((int)(uspan >> 24))
-    constexpr bool DO1 = MODE == 0 || MODE == 1 || MODE == 3 || MODE == 5 || MODE == 6, DO2 = MODE == 0 || MODE == 1 || MODE == 4, DO12 = DO1 || DO2, DO3 = MODE == 0 || MODE == 2;
     const int lane = LANE();
     const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)lane;
     PEnt* const LA = slab + t;                                    // entry e of list A at LA[e * T]
     PEnt* const LB = slab + (size_t)(LH_MAXLEN + 2) * T + t;
     const int split_len = (int)(o.min_seed_len * o.split_factor + .499);
-    int chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of reads (MODE 6: of items)
-    int it_next = 0, it_end = 0, pl_next = 0, pl_end = 0;   // MODE 5, wave-uniform: the wave's chunks of item slots and pool entries
-    int list_off = 0;                    // MODE 6: the item's forward list in the pool
-    const int n_work = BWD_ONLY ? (sp.ctr[0] < sp.item_cap ? sp.ctr[0] : sp.item_cap) : n_reads;
+    int chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of reads
     int st = S4_FETCH;
     int r = -1, len = 0, rst = 0, on = 0, ovf = 0;
     DIntv* out = intv_out;
-    u64 c0 = 0, c1 = 0, c2 = 0, last_size = 0, p2mask = 0;   // c*: ik (forward, pass 3) or the prev entry p (backward)
-    int cinfo = 0, ec = 0, i = 0, x = 0, j = 0, ncurr = 0, nprev = 0, rev = 0, min_intv = 1, have_mem = 0, last_mem_start = 0, ret = 0, phase = 0, curA = 1;
+    u64 c0 = 0, c1 = 0, c2 = 0, last_size = 0, p2mask = 0;   // c*: ik (forward, pass 3) or the prev entry p (backward); p2mask (pass 2): the read's long, rare SMEMs still to be re-seeded
+    int cinfo = 0, ec = 0, i = 0, x = 0, j = 0, ncurr = 0, nprev = 0, min_intv = 1, last_mem_start = -1, ret = 0;
     PEnt ce, pn;
     ce.lo = ce.hi = pn.lo = pn.hi = 0;
     i64 run_p = 0;            // unique run: text position of the match's first base
-    u64 ld64 = 0;             // a suffix-array / inverse-array value in flight
+    u64 ld64 = 0;             // a table value in flight
     uint32_t tw0 = 0, tw1 = 0, tw2 = 0, tw_sh = 0;   // the text words of the run's current 16-base window
     const bool runs = DO1 && ix.isa != nullptr;   // unique runs need min_intv == 1: pass 1 only
     // sweep filter (see FWD_PUSH_OK): the key of the LH_BLOOM_K read bases that end where the current forward interval ends,
@@ -172,17 +149,36 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     const bool filt = DO12 && ix.bloom1 != nullptr && o.min_seed_len >= LH_BLOOM_K;
     u64 wkey = 0, bword = 0, bmask = 0;
     int filt_from = 0;
-    unsigned n_ext_total = 0, n_exec_total = 0, n_ktree_total = 0;   // bwt_extend calls of the reference accounted for / really executed on the occurrence table / read from the k-mer tree
+    unsigned n_ext_total = 0, n_exec_total = 0, n_ktree_total = 0, n_bt_total = 0;   // bwt_extend calls of the reference accounted for / really executed on the occurrence table / read from the k-mer tree
     // k-mer tree table (DIndex::ktree): a bwt_extend whose result is a match of at most ktl bases is ONE 16-B table read (the result
     // is a function of the matched string alone).  fcode = the bases of the current forward / pass-3 walk from x on (base t at
     // bits 2t), kept while the walk is that short; rcode = the 16 read bases from the current backward row's position i on.
     const PEnt* const kt = (const PEnt*)ix.ktree;
     const int ktl = kt ? ix.ktree_levels : 0;
     uint32_t fcode = 0, rcode = 0;
-    // LCP shortcut of the backward sweep (pass 1): emin = end of the first entry pushed to the forward list (the shortest string),
-    // tri = the unique run in progress stands for a list of several entries, tri_failed = it was tried for this SMEM and did not apply
-    int emin = 0, tri = 0, tri_failed = 0;
+    // collapsed sweeps (pass 1): emin = end of the first entry pushed to the forward list (the shortest string), tri = the unique run in
+    // progress stands for a list of several entries, tri_failed = it was tried for this SMEM and did not apply
+    int emin = 0;
     uint32_t pbits = 0;   // pass 2, a call that passed the probe (S4_P2_PROBE): bit k = the LH_BLOOM_K-mer ending at read position x + 1 + k occurs again in the text
+    // runs and calls by text (pass 1).  rflags: RF_RUNP = run_p is the text position of read base x in this call (a forward run or a call
+    // by text set it: the backward run needs no suffix-array read), RF_BT = this call is being decided by text, RF_C1UNK = the current
+    // entry's second row bound c1 is not known (a run made it), RF_PK = the read has a known locus (bits 8.. = the length of the unique
+    // match that named it: a longer one replaces it — chance matches have short runs).  Pk = text position of read base 0 at that locus; bt_skip = a start position at which a call by text is known to fail (the base there differs from the text, or it was tried).
+    const bool by_text = runs && filt && ix.plcp != nullptr;   // (like the sweep filter this leaves bwt_extend calls of the reference out of n_ext: off when the filter is off)
+    int rflags = 0;   // + bits 16..23: bt_skip + 1, bits 24..31: x_prev + 2 = where the read's previous bwt_smem1a call started (see (B'))
+#define BT_SKIP() (((rflags >> 16) & 0xff) - 1)
+#define SET_BT_SKIP(v_) (rflags = (rflags & ~0xff0000) | (((v_) + 1) & 0xff) << 16)
+#define X_PREV() ((int)((uint32_t)rflags >> 24) - 2)
+#define SET_X_PREV(v_) (rflags = (rflags & 0xffffff) | (int)((uint32_t)((v_) + 2) << 24))
+    i64 Pk = 0;
+#define RF_RUNP 1
+#define RF_BT 2
+#define RF_C1UNK 4
+#define RF_PK 8
+#define RF_CURA 16     // the list being filled is list A
+#define RF_REV 32      // prev is a forward list: walked from its end (longest match first)
+#define RF_TRI 64      // the unique run in progress stands for a list of several entries (collapsed sweep)
+#define RF_TRIF 128    // ... it was tried for this call and did not apply
     // The blocks that several states lead to — the start of a bwt_smem1a call, the start of a backward row, the next step of a
     // forward walk — exist ONCE, between the transitions and the extensions of a turn; a state that needs one sets its bit in todo and
     // parks the lane (S4_PENDING) instead of carrying a copy of the block (the compiler pays for every copy, and for every level of
@@ -212,10 +208,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #define T16_LOAD(p_) { i64 w_ = (p_) >> 3; tw_sh = (uint32_t)((p_) & 7) * 4; tw0 = ix.tn[w_]; tw1 = ix.tn[w_ + 1]; tw2 = ix.tn[w_ + 2]; }
 #define T16_A() (tw_sh ? (tw0 >> tw_sh) | (tw1 << (32 - tw_sh)) : tw0)
 #define T16_B() (tw_sh ? (tw1 >> tw_sh) | (tw2 << (32 - tw_sh)) : tw1)
-#define CURR (curA ? LA : LB)
-#define PREV (curA ? LB : LA)
-    // entry e_ of the list being swept; MODE 6 reads an item's forward list (rev: the first row's) from the pool
-#define PREV_AT(e_) ((BWD_ONLY && rev) ? sp.pool[list_off + (e_)] : PREV[(uint32_t)(e_) * T])
+#define CURR ((rflags & RF_CURA) ? LA : LB)
+#define PREV ((rflags & RF_CURA) ? LB : LA)
+#define PREV_AT(e_) PREV[(uint32_t)(e_) * T]
     // forward extension: the next base decides between another bwt_extend and the end of the forward list
 #define FWD_ADVANCE()                                                                                        \
     {                                                                                                        \
@@ -262,6 +257,21 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         t2_ = (t2_ | t2_ >> 2) & 0x0f0fu; t2_ = (t2_ | t2_ >> 4) & 0x3fu;                                    \
         wkey = (u64)t0_ | (u64)t1_ << 16 | (u64)t2_ << 32;                                                   \
     }
+    // START OF A bwt_smem1a CALL.
+    // CALL BY TEXT (pass 1, with the read's locus P known from an earlier unique run of this read).  Let b be the end of the match of
+    // read[x ..] with the text at P + x (found by comparing: the forward run), u the start of the match of read[.. x) with the text at
+    // P going left (the backward run).  (A) If the suffix of the text at P + x shares fewer than b - x bases with every other suffix
+    // (one PLCP byte), read[x, b) occurs only at P and read[x, b] nowhere: the forward walk of bwt_smem1a runs to b exactly (its return
+    // value), and the forward list is [x, e) for some ends e < b plus the unique [x, b).  In the sweep, every row down to u leaves the
+    // longest entry alive (it occurs at P), so nothing is emitted there; at row u - 1 it dies and becomes the MEM [u, b).  The other
+    // entries [u, e) can only emit something more if one of them survives row u - 1, i.e. if read[u - 1, e) occurs in the text — not at
+    // P (the base before u differs there), so read[u, e) would have to occur somewhere else as well.  (B) If the suffix at P + u shares at
+    // most x - u bases with every other suffix, no [u, e) with e > x does: the call yields exactly [u, b) at one occurrence, whose text
+    // position is P + u.  When the left comparison stops at the start of the read or at a non-base, bwt_smem1a emits only the longest
+    // entry anyway (its c < 0 rule) and (B) is not needed.  (B') Nor is it when u - 1 is where the read's PREVIOUS call started: that call
+    // returned the end of the longest match of read[u - 1 ..] anywhere in the text, which is <= x (this call starts where it returned), so
+    // read[u - 1, e) with e > x occurs nowhere — the usual case: a substitution at u - 1, the call from there runs into a chance match, the
+    // next one is this.  If (A) or (B) does not hold, the call is made as written, from x.
     // FORWARD JUMP.  While the walk's interval ends before filt_from nothing can be pushed to the forward list (the window of the
     // sweep filter is not all bases: the start of the read, usually), so the steps up to level J = min(tree depth, filt_from - x,
     // valid bases from x) only matter through the interval they arrive at: the tree's entry for the J bases, one read.  Sizes do
@@ -272,7 +282,10 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
     {                                                                                                        \
         int s_ = QB(x);                                                                                      \
         c0 = ix.L2[s_] + 1; c2 = ix.L2[s_ + 1] - ix.L2[s_]; c1 = ix.L2[3 - s_] + 1; cinfo = x + 1;          \
-        ncurr = 0; i = x + 1; curA = 1; fcode = (uint32_t)s_; tri = 0; tri_failed = 0;                       \
+        ncurr = 0; i = x + 1; fcode = (uint32_t)s_;                                                          \
+        rflags = (rflags & ~(RF_RUNP | RF_BT | RF_C1UNK | RF_TRI | RF_TRIF)) | RF_CURA;                      \
+        if (DO1 && by_text && (rflags & RF_PK) && x != BT_SKIP() && Pk + x >= 0 && (u64)(Pk + x) < ix.seq_len) st = S4_BT_INIT; \
+        else {                                                                                               \
         if (filt) { int last_; WKEY_AT(x, last_) filt_from = last_ + 1 + LH_BLOOM_K; }                       \
         int J_ = 0;                                                                                          \
         if (filt && ktl > 1) {                                                                               \
@@ -291,6 +304,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             ld64 = (((1ull << (2 * J_)) - 4) / 3) + cd_; j = J_; rcode = cd_;                                \
             st = S4_FJUMP;                                                                                   \
         } else todo |= TD_FADV;                                                                              \
+        }                                                                                                    \
     }
     // pass 3: next base of the forward-only walk
 #define P3_ADVANCE()                                                                                         \
@@ -308,19 +322,23 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         int c_ = i < 0 ? 4 : QB(i);                                                                          \
         ncurr = 0; last_size = 0; j = 0;                                                                     \
         c0 = PE_X0(ce); c1 = PE_X1(ce); c2 = PE_X2(ce); cinfo = PE_INFO(ce);                                 \
-        if (c_ > 3) st = S4_BWD_EMIT0;   /* nothing extends: only the first (longest) entry can be a new MEM */ \
-        else if (runs && nprev == 1 && c2 == 1 && min_intv == 1) { tri = 0; st = S4_BRUN_INIT; }   /* one unique match left */ \
+        if (c_ > 3) {   /* nothing extends: only the first (longest) entry can be a new MEM */               \
+            if ((rflags & (RF_C1UNK | RF_RUNP)) == (RF_C1UNK | RF_RUNP)) { c0 = LH_POSF | (u64)run_p; c1 = 0; }   /* a run's entry, first row of the sweep: by its position */ \
+            st = S4_BWD_EMIT0;                                                                               \
+        }                                                                                                    \
+        else if (runs && nprev == 1 && c2 == 1 && min_intv == 1) { rflags &= ~RF_TRI; st = S4_BRUN_INIT; }   /* one unique match left */ \
         /* Several entries, the longest of them unique (the usual forward list: [x, e) for growing e until one occurrence is  \
            left).  Rows down to u, the position where the unique match ends on the left, cannot emit anything: every entry     \
-           still matches at that occurrence.  If the SHORTEST entry's string [u, emin) is unique as well — both neighbours of   \
-           its suffix-array row share fewer than emin - u bases with it (LCP array) — every entry has shrunk to that one        \
-           occurrence by row u: equal sizes of nested occurrence sets are equal sets, bwt_smem1a keeps one interval per size,  \
-           so the list has collapsed into its longest entry, whose failure at u - 1 is the only thing the sweep reports.       \
-           That is the unique run below; otherwise the sweep is done row by row as written (tri_failed).  Like the sweep filter, this leaves bwt_extend calls of the reference out (no n_ext for them): off when the filter is off. */ \
-        else if (runs && filt && ix.lcp && rev && nprev > 1 && c2 == 1 && min_intv == 1 && !tri_failed) { tri = 1; st = S4_BRUN_INIT; } \
+           still matches at that occurrence.  If the SHORTEST entry's string [u, emin) is unique as well — the suffix of the    \
+           text at u's position shares fewer than emin - u bases with every other suffix (PLCP array) — every entry has shrunk  \
+           to that one occurrence by row u: equal sizes of nested occurrence sets are equal sets, bwt_smem1a keeps one interval \
+           per size, so the list has collapsed into its longest entry, whose failure at u - 1 is the only thing the sweep       \
+           reports.  That is the unique run below; otherwise the sweep is done row by row as written (tri_failed).  Like the    \
+           sweep filter, this leaves bwt_extend calls of the reference out (no n_ext for them): off when the filter is off. */  \
+        else if (by_text && (rflags & (RF_REV | RF_TRIF)) == RF_REV && nprev > 1 && c2 == 1 && min_intv == 1) { rflags |= RF_TRI; st = S4_BRUN_INIT; } \
         else {                                                                                               \
             ec = c_; st = S4_REQ_BWD;                                                                        \
-            if (nprev > 1) pn = PREV_AT(rev ? nprev - 2 : 1);                                                \
+            if (nprev > 1) pn = PREV_AT((rflags & RF_REV) ? nprev - 2 : 1);                                                \
             if (ktl) CODE16(i, rcode)                                                                        \
         }                                                                                                    \
     }
@@ -331,10 +349,11 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         if (j < nprev) {                                                                                     \
             c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn); cinfo = PE_INFO(pn);                             \
             st = S4_REQ_BWD;                                                                                 \
-            if (j + 1 < nprev) pn = PREV_AT(rev ? nprev - 2 - j : j + 1);                                    \
+            if (j + 1 < nprev) pn = PREV_AT((rflags & RF_REV) ? nprev - 2 - j : j + 1);                                    \
         } else if (ncurr == 0) st = S4_SMEM_DONE;                                                            \
         else {                                                                                               \
-            curA ^= 1; nprev = ncurr; rev = 0; --i;                                                          \
+            nprev = ncurr; --i;                                                                              \
+            rflags = (rflags ^ RF_CURA) & ~(RF_RUNP | RF_C1UNK | RF_REV);   /* (rows made by bwt_extend carry both bounds; run_p no longer belongs to them) */ \
             if (i < -1) st = S4_SMEM_DONE;                                                                   \
             else { todo |= TD_ROW; st = S4_PENDING; }                                                        \
         }                                                                                                    \
@@ -343,28 +362,26 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #define EMIT_MEM()                                                                                           \
     {                                                                                                        \
         if (cinfo - (i + 1) >= o.min_seed_len) {                                                             \
-            if (BWD_ONLY) on = atomicAdd(&n_intv[r], 1);   /* sweeps of one read run in different lanes */    \
-            if (on >= LH_MAX_INTV) { ovf = 1; if (BWD_ONLY) atomicOr(&status[r], LH_ST_INTV_OVERFLOW); }     \
+            if (on >= LH_MAX_INTV) ovf = 1;                                                                  \
             else {                                                                                           \
                 DIntv m_; m_.x0 = c0; m_.x1 = c1; m_.x2 = c2; m_.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32; \
-                if (phase == 1 && cinfo - (i + 1) >= split_len && c2 <= (u64)o.split_width) p2mask |= 1ull << on; \
-                out[on] = m_; if (!BWD_ONLY) on++;                                                           \
+                out[on] = m_; on++;                                                                          \
             }                                                                                                \
         }                                                                                                    \
-        have_mem = 1; last_mem_start = i + 1;                                                                \
+        last_mem_start = i + 1;                                                                              \
     }
     for (;;) {
         // ---- A. lanes without a read take the next ones of the wave's chunk; the wave stages their bases in LDS ----
         // Lanes that left the extension loops wait until LH_SLOW_BATCH of them have gathered (or nothing else is in flight):
         // the divergent blocks of A and B then run for many lanes at once instead of for one or two in every turn.
-        const bool slow_turn = __popcll(__ballot(st == S4_FETCH || (st >= 8 && st < S4_FRUN_INIT))) >= (MODE == 2 ? LH_SLOW_BATCH_P3 : MODE == 4 ? LH_SLOW_BATCH_P2 : LH_SLOW_BATCH) ||
+        const bool slow_turn = __popcll(__ballot(st == S4_FETCH || (st >= 8 && st < S4_FRUN_INIT))) >= (PASS == 3 ? LH_SLOW_BATCH_P3 : PASS == 2 ? LH_SLOW_BATCH_P2 : LH_SLOW_BATCH) ||
                                !__any((st >= S4_REQ_FWD && st < 8) || st >= S4_FRUN_INIT);
         u64 need = slow_turn ? __ballot(st == S4_FETCH) : 0;
         if (need) {
             int cnt = __popcll(need), newbase = 0;
             if (chunk_next + cnt > chunk_end) {
                 int nb = 0;
-                if (lane == 0) nb = atomicAdd(BWD_ONLY ? sp.ctr + 3 : next_read, 64);
+                if (lane == 0) nb = atomicAdd(next_read, 64);
                 newbase = wave_readlane(nb, 0);
             }
             i64 off = 0;
@@ -372,16 +389,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             if (st == S4_FETCH) {
                 int idx = chunk_next + lanes_below(need, lane);
                 rr = idx < chunk_end ? idx : newbase + (idx - chunk_end);
-                if (rr >= n_work) st = S4_DONE;
-                else {
-                    if (BWD_ONLY) {   // rr is an item: its read is staged like any other
-                        const K1Item it = sp.items[rr];
-                        x = it.x; ret = it.ret; ncurr = it.nlist; ce = it.ce; emin = it.emin; list_off = it.list_off;
-                        rr = it.r;   // -1: a slot its wave did not use
-                    }
-                    if (rr >= 0) { off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
-                    else st = S4_FETCH_SKIP;
-                }
+                if (rr >= n_reads) st = S4_DONE;
+                else { off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
             }
             if (chunk_next + cnt > chunk_end) { chunk_next = newbase + (chunk_next + cnt - chunk_end); chunk_end = newbase + 64; }
             else chunk_next += cnt;
@@ -412,19 +421,12 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     if (!(lane & 1)) qn[(lane >> 1) * 64 + Lk[k]] = nb16 | other << 16;
                 }
             }
-            if (st == S4_FETCH_SKIP) st = S4_FETCH;   // (staged nothing; takes another item in the next slow turn)
-            else if (BWD_ONLY && st == S4_FETCH) {
-                r = rr; len = ln; if (len > LH_MAXLEN) len = 0;
-                out = intv_out + (size_t)r * LH_MAX_INTV;
-                phase = 1; min_intv = 1; cinfo = ret; curA = 1; tri = 0; tri_failed = 0;
-                st = S4_BWD_INIT;
-            }
-            else if (st == S4_FETCH) {
-                r = rr; len = ln; rst = 0; on = 0; ovf = 0; p2mask = 0;
+            if (st == S4_FETCH) {
+                r = rr; len = ln; rst = 0; on = 0; ovf = 0; p2mask = 0; rflags = 0;
                 if (len > LH_MAXLEN) { rst |= LH_ST_TOO_LONG; len = 0; }
                 out = intv_out + (size_t)r * LH_MAX_INTV;
                 if (!DO1) { on = n_intv[r]; rst |= status[r]; }   // continue behind the intervals of the earlier passes
-                if (len >= o.min_seed_len) { x = 0; phase = DO1 ? 1 : 2; st = DO1 ? S4_P1_SCAN : DO2 ? S4_P2_NEXT : S4_P3_SCAN; }
+                if (len >= o.min_seed_len) { x = 0; st = DO1 ? S4_P1_SCAN : DO2 ? S4_P2_NEXT : S4_P3_SCAN; }
                 else st = S4_READ_DONE;
                 if (P3TEXT && st == S4_P3_SCAN) {   // the two longest unique SMEMs among the read's intervals
                     uspan = 0;
@@ -437,7 +439,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     }
                     if (UE0 > US0) st = S4_P3_PREP;
                 }
-                if (!DO1 && DO2 && st == S4_P2_NEXT) {   // the long, rare SMEMs among pass 1's intervals (EMIT_MEM's test)
+                if (DO2 && st == S4_P2_NEXT) {   // the long, rare SMEMs among pass 1's intervals (EMIT_MEM's test)
                     for (int k = 0; k < on; ++k) {
                         DIntv p = out[k];
                         if ((int)(uint32_t)p.info - (int)(p.info >> 32) >= split_len && p.x2 <= (u64)o.split_width) p2mask |= 1ull << k;
@@ -447,15 +449,41 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         }
         // ---- B. transitions between the loops of mem_collect_intv (rare per lane; the blocks are ordered so that the
         //         usual chains finish in one pass) ----
-    if (st >= S4_FRUN_INIT) {   // unique runs: ONE step of their load / use chains per turn: a value read here is used in the next turn
+        if (st >= S4_FRUN_INIT) {   // ONE step of the load / use chains per turn: a value read here is used in the next turn
             if (DO1 && st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; st = S4_FRUN_INIT2; }
-            else if (DO1 && st == S4_FRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p + (i - x)) st = S4_REQ_FRUN; }
-            else if (DO1 && st == S4_FRUN_END) { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }   // the reverse strand's copy of the match
-            else if (DO1 && st == S4_FRUN_END2) {   // the unique interval closes the forward list (it is the list's last entry: kept in ce only)
+            else if (DO1 && st == S4_FRUN_INIT2) {
+                run_p = (i64)ld64; T16_LOAD(run_p + (i - x))
+                rflags |= RF_RUNP;
+                st = S4_REQ_FRUN;
+            }
+            else if (DO1 && st == S4_FRUN_END) {
+                // The unique interval closes the forward list (it is the list's last entry: kept in ce only).  Its second row bound is the
+                // row of the reverse strand's copy of the match: only a sweep made by bwt_extend needs it — never when the run's interval
+                // is the whole list or the list can collapse (BWD_ROW_BODY); it is read back if that does not work out (S4_TRI_C1).  Without the
+                // PLCP array the sweep reports rows: both bounds, as before.
+                if (by_text) {
+                    rflags |= RF_C1UNK;
+                    ce = pe_pack(c0, 0, c2, cinfo);
+                    ncurr++;
+                    st = S4_BWD_INIT;
+                } else { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }
+            }
+            else if (DO1 && st == S4_FRUN_END2) {
                 c1 = ld64;
                 ce = pe_pack(c0, c1, c2, cinfo);
                 ncurr++;
                 st = S4_BWD_INIT;
+            }
+            else if (DO1 && st == S4_BT_INIT) {   // a call by text: the comparison starts at x, the PLCP byte of (A) is read beside the first text words
+                run_p = Pk + x;
+                T16_LOAD(run_p)
+                ec = ix.plcp[run_p];
+                i = x; last_mem_start = -1; rflags |= RF_BT | RF_RUNP;
+                st = S4_REQ_FRUN;
+            }
+            else if (DO1 && st == S4_BT_B) {   // (B): ec = the PLCP byte at u's position; i + 1 = u
+                if (ec <= x - (i + 1)) { c0 = LH_POSF | (u64)run_p; c1 = 0; c2 = 1; rflags &= ~RF_BT; n_bt_total++; st = S4_BWD_EMIT0; }
+                else { rflags &= ~(RF_RUNP | RF_BT | RF_C1UNK); SET_BT_SKIP(x); todo |= TD_SMEM; st = S4_PENDING; }   // not provable: the call as written
             }
             else if (DO12 && st == S4_FJUMP) { pn = kt[ld64]; st = S4_FJUMP2; }
             else if (DO12 && st == S4_FJUMP2) {
@@ -467,7 +495,11 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     else { todo |= TD_FADV | TD_KEY; st = S4_PENDING; }
                 } else { todo |= TD_FADV; st = S4_PENDING; }   // the walk ends inside the skipped levels: step by step from level 1
             }
-            else if (DO2 && st == S4_P2_PROBE) { ld64 = ix.sa[ld64]; st = S4_P2_PROBE2; }
+            else if (DO2 && st == S4_P2_PROBE) {
+                if (ld64 & LH_POSF) ld64 &= ~LH_POSF;   // pass 1 stored the SMEM by its position
+                else ld64 = ix.sa[ld64];
+                st = S4_P2_PROBE2;
+            }
             else if (DO2 && st == S4_P2_PROBE2) {   // the bits of the K windows' first positions: text position of the SMEM's start + i on
                 const u64 t0 = ld64 + (u64)i;
                 pn.lo = ix.rep_t[t0 >> 6]; pn.hi = ix.rep_t[(t0 >> 6) + 1]; tw_sh = (uint32_t)(t0 & 63);
@@ -479,33 +511,49 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 if (pbits) { todo |= TD_SMEM; st = S4_PENDING; }
                 else st = S4_P2_NEXT;
             }
-            else if (P3T && st == S4_P3_PREP) { ld64 = ix.sa[up0]; st = S4_P3_PREP2; }
+            else if (P3T && st == S4_P3_PREP) {
+                if (up0 & LH_POSF) ld64 = up0 & ~LH_POSF;
+                else ld64 = ix.sa[up0];
+                st = S4_P3_PREP2;
+            }
             else if (P3T && st == S4_P3_PREP2) {
                 up0 = ld64;
-                if (UE1 > US1) { ld64 = ix.sa[up1]; st = S4_P3_PREP3; }
+                if (UE1 > US1) {
+                    if (up1 & LH_POSF) ld64 = up1 & ~LH_POSF;
+                    else ld64 = ix.sa[up1];
+                    st = S4_P3_PREP3;
+                }
                 else st = S4_P3_SCAN;
             }
             else if (P3T && st == S4_P3_PREP3) { up1 = ld64; st = S4_P3_SCAN; }
-            else if (P3T && st == S4_P3_T0) { ld64 = ix.isa[run_p]; st = S4_P3_T1; }
-            else if (P3T && st == S4_P3_T1) {
-                c0 = ld64;   // the row of the Lw-mer's occurrence
-                uint16_t v_;
-                __builtin_memcpy(&v_, ix.lcp + c0, 2);   // lcp[row], lcp[row + 1]
-                pn.lo = v_;
-                ld64 = ix.isa[(i64)ix.seq_len - (run_p + Lw)];   // the reverse strand's copy
-                st = S4_P3_T2;
+            else if (P3T && st == S4_P3_T0) {   // up to four walks from run_p on, Lw apart, as long as they lie inside the SMEM (j of them): their PLCP bytes
+                const uint8_t* pl = ix.plcp + run_p;
+                uint32_t v = pl[0];
+                if (j > 1) v |= (uint32_t)pl[Lw] << 8;
+                if (j > 2) v |= (uint32_t)pl[2 * Lw] << 16;
+                if (j > 3) v |= (uint32_t)pl[3 * Lw] << 24;
+                tw0 = v;
+                st = S4_P3_T1;
             }
-            else if (P3T && st == S4_P3_T2) {
-                const int l0_ = (int)(pn.lo & 0xff), l1_ = (int)((pn.lo >> 8) & 0xff);
-                if (l0_ < Lw && l1_ < Lw) {   // unique: the walk ends here with one occurrence
-                    if (on >= LH_MAX_INTV) ovf = 1;
-                    else { DIntv m; m.x0 = c0; m.x1 = ld64; m.x2 = 1; m.info = (u64)x << 32 | (u64)(x + Lw); out[on++] = m; }
-                    n_ext_total += (unsigned)(Lw - 1);
-                    x += Lw;
-                    st = S4_P3_SCAN;
-                    if (x >= US0 && x + Lw <= UE0) { run_p = (i64)up0 + (x - US0); st = S4_P3_T0; }        // the next walk lies in an SMEM as well (no
-                    else if (x >= US1 && x + Lw <= UE1) { run_p = (i64)up1 + (x - US1); st = S4_P3_T0; }   // non-base inside one): straight on
-                } else { rst |= P3_NOTEXT; st = S4_P3_SCAN; }   // it occurs again: the walk as written, from x
+            else if (P3T && st == S4_P3_T1) {
+                st = S4_P3_SCAN;
+                for (int k = 0; k < j; ++k) {
+                    if ((int)((tw0 >> (8 * k)) & 0xff) < Lw) {   // unique: the walk ends here with one occurrence
+                        if (on >= LH_MAX_INTV) ovf = 1;
+                        else { DIntv m; m.x0 = LH_POSF | (u64)(run_p + (i64)k * Lw); m.x1 = 0; m.x2 = 1; m.info = (u64)x << 32 | (u64)(x + Lw); out[on++] = m; }
+                        n_ext_total += (unsigned)(Lw - 1);
+                        x += Lw;
+                    } else { rst |= P3_NOTEXT; break; }   // it occurs again: the walk as written, from x
+                }
+                if (!(rst & P3_NOTEXT)) {   // the next walks of the SMEM (no non-base inside one): straight on
+                    const int in0 = x >= US0 && x + Lw <= UE0, in1 = x >= US1 && x + Lw <= UE1;
+                    if (in0 || in1) {
+                        run_p = in0 ? (i64)up0 + (x - US0) : (i64)up1 + (x - US1);
+                        const int room = ((in0 ? UE0 : UE1) - x) / Lw;
+                        j = room < 4 ? room : 4;
+                        st = S4_P3_T0;
+                    }
+                }
             }
             else if (DO3 && st == S4_P3_JUMP) { pn = kt ? kt[ld64] : ((const PEnt*)ix.kmer12)[ld64]; st = S4_P3_JUMP2; }
             else if (DO3 && st == S4_P3_JUMP2) {   // as if the bwt_extend steps after the first base had been made (none of them can end the walk: i - x < min_seed_len)
@@ -515,21 +563,23 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 i = x + jl;
                 P3_ADVANCE()
             }
-            else if (DO1 && !FWD_ONLY && st == S4_BRUN_INIT) { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
-            else if (DO1 && !FWD_ONLY && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }
-            else if (DO1 && !FWD_ONLY && st == S4_BRUN_END) { ld64 = ix.isa[run_p]; st = S4_BRUN_END2; }
-            else if (DO1 && !FWD_ONLY && st == S4_TRI_LCP) {   // ld64 = the row of the suffix that starts where the unique match ends on the left
-                const uint8_t* lp = ix.lcp + ld64;
-                int l0 = lp[0], l1 = lp[1];
-                ec = l0 > l1 ? l0 : l1;   // (ec is free outside the extension states)
-                st = S4_TRI_LCP2;
+            else if (DO1 && st == S4_BRUN_INIT) {
+                if (rflags & RF_RUNP) { T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }   // the forward run (or the call by text) left the position of read base x
+                else { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
             }
-            else if (DO1 && !FWD_ONLY && st == S4_TRI_LCP2) {
-#ifdef LH_SMEM_TURNS
-                atomicAdd(&lh_dbg[ec < emin - (i + 1) ? 22 : 23], 1);
-#endif
-                if (ec < emin - (i + 1)) {   // the shortest entry is unique from u = i + 1 on: the list is its longest entry
-                    c0 = ld64;
+            else if (DO1 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }
+            else if (DO1 && st == S4_BRUN_END) {   // the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
+                const bool edge = i < 0 || QB(i) > 3;   // stopped by the start of the read or a non-base: bwt_smem1a emits the longest entry only
+                if (rflags & RF_BT) {
+                    if (edge || i == X_PREV()) { c0 = LH_POSF | (u64)run_p; c1 = 0; c2 = 1; rflags &= ~RF_BT; n_bt_total++; st = S4_BWD_EMIT0; }   // (B') see START_SMEM1
+                    else { ec = ix.plcp[run_p]; st = S4_BT_B; }
+                } else if ((rflags & RF_TRI) && !edge) { ec = ix.plcp[run_p]; st = S4_TRI_LCP2; }
+                else if (by_text) { c0 = LH_POSF | (u64)run_p; c1 = 0; st = S4_BWD_EMIT0; }   // one occurrence, at run_p
+                else { ld64 = ix.isa[run_p]; st = S4_TRI_C1B; }   // (no PLCP array: the row, as before)
+            }
+            else if (DO1 && st == S4_TRI_LCP2) {   // ec = bases the suffix at u's position shares with another suffix (u = i + 1)
+                if (ec < emin - (i + 1)) {   // the shortest entry is unique from u on: the list is its longest entry
+                    c0 = LH_POSF | (u64)run_p; c1 = 0;
                     st = S4_BWD_EMIT0;   // a MEM unless contained in the previous one, then the call is over
                 } else {
                     // Not the whole list, but its tail: an entry [x, e) with e - u > ec is unique from row u on, so by then it has merged
@@ -537,94 +587,46 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                     // entry that is NOT unique at row u was never merged into one that is.  Down to row u nothing is emitted, so the
                     // sweep over the longest entry and the entries that may still be distinct at row u leaves the same list there as
                     // the sweep over all of them.  The list's ends are distinct and ascending from emin: at most u + ec - emin + 1 of
-                    // them are <= u + ec, the first ones of the forward list.  The sweep as written over those, from its first row.
+                    // them are <= u + ec, the first ones of the forward list.  The sweep as written over those, from its first row —
+                    // with the longest entry's second row bound, which the run did not keep: the row of the reverse strand's copy.
                     const int m_ = i + 1 + ec - emin + 1;
                     if (m_ < nprev - 1) nprev = m_ + 1;
-                    tri_failed = 1; tri = 0;
-                    i = x - 1;
-                    todo |= TD_ROW; st = S4_PENDING;
+                    ld64 = ix.isa[(i64)ix.seq_len - (run_p + (PE_INFO(ce) - (i + 1)))];
+                    st = S4_TRI_C1;
                 }
             }
-            else if (DO1 && !FWD_ONLY && st == S4_BRUN_END2) {   // the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
-                if (tri) st = S4_TRI_LCP;
-                else { c0 = ld64; st = S4_BWD_EMIT0; }
+            else if (DO1 && st == S4_TRI_C1) {
+                ce = pe_pack(PE_X0(ce), ld64, PE_X2(ce), PE_INFO(ce));
+                rflags = (rflags | RF_TRIF) & ~(RF_TRI | RF_RUNP | RF_C1UNK);
+                i = x - 1;
+                todo |= TD_ROW; st = S4_PENDING;
             }
+            else if (DO1 && st == S4_TRI_C1B) { c0 = ld64; st = S4_BWD_EMIT0; }
         }
         while (slow_turn && __any(st >= 8 && st < S4_FRUN_INIT)) {
-            if (DO12 && !FWD_ONLY && st == S4_BWD_EMIT) {
+            if (DO12 && st == S4_BWD_EMIT) {
                 EMIT_MEM()
                 BWD_ADVANCE()
             }
-            if (FWD_ONLY) {   // the forward list is complete: hand it to the sweep kernel, go on with the read where the next call starts
-                // a list whose sweep cannot start (nothing before x, or a non-base there) yields its longest entry at once (S4_BWD_EMIT0 of a
-                // sweep's first row: have_mem is 0): no item for those — the first call of every read is one
-                if (st == S4_BWD_INIT && (x == 0 || QB(x - 1) > 3)) {
-                    if (cinfo - x >= o.min_seed_len) {
-                        const int slot = atomicAdd(&n_intv[r], 1);
-                        if (slot >= LH_MAX_INTV) rst |= LH_ST_INTV_OVERFLOW;
-                        else { DIntv m_; m_.x0 = PE_X0(ce); m_.x1 = PE_X1(ce); m_.x2 = PE_X2(ce); m_.info = (u64)(uint32_t)cinfo | (u64)x << 32; intv_out[(size_t)r * LH_MAX_INTV + slot] = m_; }
-                    }
-                    x = cinfo; st = S4_P1_SCAN;
-                }
-                const bool give = st == S4_BWD_INIT;
-                const u64 gm = __ballot(give);
-                if (gm) {   // wave-wide: item slots and pool entries come from the wave's chunks (one device atomic per chunk)
-                    const int ng = __popcll(gm), mine = lanes_below(gm, lane);
-                    const int nl = give ? ncurr - 1 : 0;   // entries before the last one (which travels in the item)
-                    const int pl_pre = wave_scan_add_i32(nl) - nl, pl_tot = wave_sum_i32(nl);
-                    if (it_next + ng > it_end) {   // the rest of the old chunk stays unused: marked empty
-                        for (int e = it_next + lane; e < it_end; e += 64) sp.items[e].r = -1;
-                        int nb = 0;
-                        if (lane == 0) nb = atomicAdd(sp.ctr, LH_K1_ITEM_CHUNK);
-                        it_next = wave_readlane(nb, 0); it_end = it_next + LH_K1_ITEM_CHUNK;
-                        if (it_end > sp.item_cap) { if (lane == 0) sp.ctr[2] = 1; it_end = it_next < sp.item_cap ? sp.item_cap : it_next; }
-                    }
-                    if (pl_next + pl_tot > pl_end) {
-                        const int want = pl_tot > LH_K1_POOL_CHUNK ? pl_tot : LH_K1_POOL_CHUNK;
-                        int nb = 0;
-                        if (lane == 0) nb = atomicAdd(sp.ctr + 1, want);
-                        pl_next = wave_readlane(nb, 0); pl_end = pl_next + want;
-                        if (pl_end > sp.pool_cap) { if (lane == 0) sp.ctr[2] = 1; pl_end = pl_next; }
-                    }
-                    const bool fits = it_next + ng <= it_end && pl_next + pl_tot <= pl_end;   // else the overflow flag is up: the host redoes pass 1 in one kernel
-                    if (give && fits) {
-                        K1Item it;
-                        it.r = r; it.x = x; it.ret = cinfo; it.nlist = ncurr; it.ce = ce; it.emin = emin; it.list_off = pl_next + pl_pre; it.pad0 = it.pad1 = 0;
-                        sp.items[it_next + mine] = it;
-                        for (int e = 0; e < nl; ++e) sp.pool[it.list_off + e] = CURR[(uint32_t)e * T];
-                    }
-                    if (fits) { it_next += ng; pl_next += pl_tot; }
-                    if (give) { x = cinfo; st = S4_P1_SCAN; }
-                }
-            }
-            if (!FWD_ONLY && DO12 && st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
-                ret = cinfo; curA ^= 1; nprev = ncurr; rev = 1; have_mem = 0; last_mem_start = 0; i = x - 1;
-#ifdef LH_SMEM_TURNS
-                if (MODE == 3) {
-                    if (nprev == 1) atomicAdd(&lh_dbg[24], 1);
-                    else if (PE_X2(ce) == 1) { atomicAdd(&lh_dbg[25], 1); atomicAdd(&lh_dbg[26], nprev); }
-                    else { atomicAdd(&lh_dbg[27], 1); atomicAdd(&lh_dbg[28], nprev); if (x == 0) atomicAdd(&lh_dbg[29], 1); }
-                }
-#endif
+            if (DO12 && st == S4_BWD_INIT) {   // the forward list becomes prev and is walked from its end (longest match first)
+                ret = cinfo; rflags = (rflags ^ RF_CURA) | RF_REV; nprev = ncurr; last_mem_start = -1; i = x - 1;
                 todo |= TD_ROW; st = S4_PENDING;
             }
-            if (DO12 && !FWD_ONLY && st == S4_BWD_EMIT0) {
-                if (!have_mem || i + 1 < last_mem_start) EMIT_MEM()
+            if (DO12 && st == S4_BWD_EMIT0) {
+                if (last_mem_start < 0 || i + 1 < last_mem_start) EMIT_MEM()
                 st = S4_SMEM_DONE;
             }
-            if (DO12 && !FWD_ONLY && st == S4_SMEM_DONE) {
-                if (BWD_ONLY) st = S4_FETCH;
-                else if (phase == 1) { x = ret; st = S4_P1_SCAN; }
+            if (DO12 && st == S4_SMEM_DONE) {
+                if (DO1) { SET_X_PREV(x); x = ret; st = S4_P1_SCAN; }
                 else st = S4_P2_NEXT;
             }
             if (DO1 && st == S4_P1_SCAN) {   // first pass: all SMEMs
                 while (x < len && QB(x) > 3) ++x;
-                if (x >= len) { phase = 2; st = DO2 ? S4_P2_NEXT : S4_READ_DONE; }
+                if (x >= len) st = S4_READ_DONE;
                 else { min_intv = 1; pbits = 0; todo |= TD_SMEM; st = S4_PENDING; }
             }
             if (DO2 && st == S4_P2_NEXT) {   // second pass: re-seed inside long, rare SMEMs of the first pass
-                st = S4_P3_SCAN; x = 0;
-                if (!DO3 || o.max_mem_intv <= 0) st = S4_READ_DONE;
+                st = S4_READ_DONE; x = 0;
                 while (p2mask) {
                     int k = __ffsll((unsigned long long)p2mask) - 1;
                     p2mask &= p2mask - 1;
@@ -646,9 +648,12 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             }
             while (DO3 && st == S4_P3_SCAN) {   // third pass: LAST-like forward-only seeds (bwt_seed_strategy1)
                 while (x < len && QB(x) > 3) ++x;
-                if (x >= len) st = S4_READ_DONE;
+                if (x >= len || o.max_mem_intv <= 0) st = S4_READ_DONE;
                 else if (P3TEXT && !(rst & P3_NOTEXT) && ((x >= US0 && x + Lw <= UE0) || (x >= US1 && x + Lw <= UE1))) {
-                    run_p = (x >= US0 && x + Lw <= UE0) ? (i64)up0 + (x - US0) : (i64)up1 + (x - US1);   // the text position the walk starts at
+                    const int in0 = x >= US0 && x + Lw <= UE0;
+                    run_p = in0 ? (i64)up0 + (x - US0) : (i64)up1 + (x - US1);   // the text position the walk starts at
+                    const int room = ((in0 ? UE0 : UE1) - x) / Lw;                // walks that fit into the SMEM from here
+                    j = room < 4 ? room : 4;
                     st = S4_P3_T0;
                 }
                 else {
@@ -693,14 +698,14 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             if (st == S4_READ_DONE) {
                 rst &= ~P3_NOTEXT;
                 if (ovf) rst |= LH_ST_INTV_OVERFLOW;
-                if (!FWD_ONLY) n_intv[r] = on;   // (MODE 5: the sweeps count the read's intervals)
+                n_intv[r] = on;
                 status[r] = rst;
                 st = S4_FETCH;
             }
         }
         // ---- B'. the shared blocks (see todo) ----
         if (DO12 && (todo & TD_SMEM)) START_SMEM1()
-        if (DO12 && !FWD_ONLY && (todo & TD_ROW)) BWD_ROW_BODY()
+        if (DO12 && (todo & TD_ROW)) BWD_ROW_BODY()
         if (DO12 && (todo & TD_FADV)) {
             if (todo & TD_KEY) { int last_; WKEY_AT(i - 1, last_) (void)last_; }
             BLOOM_ISSUE()
@@ -715,26 +720,6 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         // ---- D. the shared program point: one bwt_extend per requesting lane ----
         DIntv ok;
         ok.x0 = ok.x1 = ok.x2 = ok.info = 0;
-#ifdef LH_SMEM_TURNS   // development aid: lanes per state class over all turns of the pass-1 instance (lh_dbg[8..15])
-        if (MODE == 3) {
-            int cls_ = st == S4_REQ_FWD ? 0 : st == S4_REQ_BWD ? 1 : st == S4_REQ_FRUN ? 2 : st == S4_REQ_BRUN ? 3 : st >= S4_FRUN_INIT ? 4 : st >= 8 ? 5 : 6;
-            for (int kk_ = 0; kk_ < 7; ++kk_) { int n_ = (int)__popcll(__ballot(cls_ == kk_)); if (lane == 0 && n_) atomicAdd(&lh_dbg[8 + kk_], n_); }
-            if (lane == 0) atomicAdd(&lh_dbg[15], 1);
-        }
-#endif
-#ifdef LH_SMEM_PROF   // development aid: FM-index extensions actually performed, by loop (lh_dbg[16..19] in units of 1024)
-        { int k_ = st == S4_REQ_FWD ? (phase == 1 ? 16 : 18) : st == S4_REQ_BWD ? (phase == 1 ? 17 : 18) : st == S4_REQ_P3 ? 19 : -1;
-          for (int kk_ = 16; kk_ < 20; ++kk_) { int n_ = (int)__popcll(__ballot(k_ == kk_)); if (lane == 0 && n_) atomicAdd(&lh_dbg[kk_ + 4], n_); } }
-#endif
-#ifdef LH_KTREE_STATS   // development aid: how many executed extensions produce a match of at most 14 bases (lh_dbg[8..13])
-        {
-            int any_ = st >= S4_REQ_FWD && st <= S4_REQ_P3;
-            int L_ = st == S4_REQ_BWD ? cinfo - i : i + 1 - x;
-            int b_ = MODE == 3 ? 8 : MODE == 4 ? 10 : 12;
-            int ns_ = (int)__popcll(__ballot(any_ && L_ <= 14)), na_ = (int)__popcll(__ballot(any_));
-            if (lane == 0) { atomicAdd(&lh_dbg[b_], ns_); atomicAdd(&lh_dbg[b_ + 1], na_); }
-        }
-#endif
         // Both kinds of lanes ISSUE their reads before either kind uses them: as an if / else the tree lanes' read would have to land
         // before the occurrence records of the other lanes are even requested (two memory latencies per turn instead of one).
         const bool req = st >= S4_REQ_FWD && st <= S4_REQ_P3;
@@ -744,12 +729,6 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
         uint4 hk = {0, 0, 0, 0}, dk = hk, hl = hk, dl = hk;
         u64 k2 = 0, l2 = 0;
         const u64 xa = st == S4_REQ_BWD ? c0 : c1;   // x[!is_back]
-#ifdef LH_SMEM_TURNS   // which extensions pass 1 still makes (lh_dbg[16..21])
-        if (MODE == 3) {
-            int cls_ = !req ? -1 : st == S4_REQ_FWD ? (by_tree ? 0 : 1) : (by_tree ? 2 : 4) + (nprev > 1 ? 1 : 0);
-            for (int kk_ = 0; kk_ < 6; ++kk_) { int n_ = (int)__popcll(__ballot(cls_ == kk_)); if (lane == 0 && n_) atomicAdd(&lh_dbg[16 + kk_], n_); }
-        }
-#endif
         if (by_tree) {
             uint32_t code;
             if (st == S4_REQ_BWD) code = rcode & ((1u << (2 * lnew)) - 1u);
@@ -801,9 +780,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
                 if (runs && c2 == 1 && min_intv == 1) st = S4_FRUN_INIT;   // a single occurrence: follow it through the text (it ends the list: no filter)
                 else { todo |= TD_FADV; st = S4_PENDING; }
             }
-        } else if (DO12 && !FWD_ONLY && st == S4_REQ_BWD) {
+        } else if (DO12 && st == S4_REQ_BWD) {
             if (ok.x2 < (u64)min_intv) {
-                if (ncurr == 0 && (!have_mem || i + 1 < last_mem_start)) st = S4_BWD_EMIT;   // no longer match survived, not contained in the previous MEM
+                if (ncurr == 0 && (last_mem_start < 0 || i + 1 < last_mem_start)) st = S4_BWD_EMIT;   // no longer match survived, not contained in the previous MEM
             } else if (ncurr == 0 || ok.x2 != last_size) {
                 PEnt e = pe_pack(ok.x0, ok.x1, ok.x2, cinfo);
                 if (ncurr == 0) ce = e;   // a row's first entry is only ever read through ce
@@ -818,25 +797,37 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
             Q8(i + 8, qb)
             uint32_t xa = qa ^ T16_A(), xb = qb ^ T16_B();
             int n = xa ? (__ffs((int)xa) - 1) >> 2 : 8 + (xb ? (__ffs((int)xb) - 1) >> 2 : 8);
-            n_ext_total += (unsigned)n;
+            if (!(rflags & RF_BT)) n_ext_total += (unsigned)n;
             i += n;
             if (n == 16) T16_LOAD(run_p + (i - x))
+            else if (rflags & RF_BT) {   // the call by text: i = b, ec = the PLCP byte at x's position
+                if (ec < i - x) {   // (A): read[x, b) occurs only here: the forward walk returns b, its last entry is this one occurrence
+                    cinfo = i; ret = i; c2 = 1; SET_BT_SKIP(i);
+                    if (x == 0 || QB(x - 1) > 3) { i = x - 1; c0 = LH_POSF | (u64)run_p; c1 = 0; rflags &= ~RF_BT; n_bt_total++; st = S4_BWD_EMIT0; }   // nothing before x: bwt_smem1a emits the longest entry
+                    else { i = x - 1; T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }
+                } else { rflags &= ~(RF_RUNP | RF_BT | RF_C1UNK); SET_BT_SKIP(x); todo |= TD_SMEM; st = S4_PENDING; }   // not provable (or the read leaves the locus at x): the call as written
+            }
             else {   // read exhausted, ambiguous base, text exhausted or a mismatch: the run's interval is the forward list's last entry
                 if (i < len && QB(i) <= 3) n_ext_total++;   // the bwt_extend that returned an empty interval
                 cinfo = i;
+                if (by_text && i - x > ((rflags >> 8) & 0xff)) {   // the longest unique match so far names the read's locus: later calls may be decided by text there
+                    Pk = run_p - x; rflags = (rflags & ~0xff00) | RF_PK | (i - x) << 8;
+                    SET_BT_SKIP(i);   // (a call from there finds the base that ended this run)
+                } else if ((rflags & RF_PK) && run_p - x == Pk) SET_BT_SKIP(i);
                 st = S4_FRUN_END;
             }
-        } else if (DO1 && !FWD_ONLY && st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
+        } else if (DO1 && st == S4_REQ_BRUN) {   // backward unique run: rows in which the one interval left survives
             uint32_t qa, qb;
             Q8(i - 15, qa)
             Q8(i - 7, qb)
             uint32_t xa = qa ^ T16_A(), xb = qb ^ T16_B();
             int n = xb ? __clz((int)xb) >> 2 : 8 + (xa ? __clz((int)xa) >> 2 : 8);
-            n_ext_total += (unsigned)n;
+            if (!(rflags & RF_BT)) n_ext_total += (unsigned)n;
             i -= n; run_p -= n;
             if (n == 16) T16_LOAD(run_p - 16)
             else {
-                if (i >= 0 && QB(i) <= 3) n_ext_total++;   // the bwt_extend that returned an empty interval
+                if (!(rflags & RF_BT) && i >= 0 && QB(i) <= 3) n_ext_total++;   // the bwt_extend that returned an empty interval
+                rflags &= ~RF_RUNP;   // (run_p now names the start of the extended match)
                 st = S4_BRUN_END;
             }
         } else if (DO3 && st == S4_REQ_P3) {
@@ -875,19 +866,91 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 8 : LH_SMEM4_WAVES) k_smem4_t(
 #undef BWD_ROW_BODY
 #undef BWD_ADVANCE
 #undef EMIT_MEM
-    if (FWD_ONLY) for (int e = it_next + lane; e < it_end; e += 64) sp.items[e].r = -1;
+#undef RF_RUNP
+#undef RF_BT
+#undef RF_C1UNK
+#undef RF_PK
+#undef RF_CURA
+#undef RF_REV
+#undef RF_TRI
+#undef RF_TRIF
+#undef BT_SKIP
+#undef SET_BT_SKIP
+#undef X_PREV
+#undef SET_X_PREV
     if (ctr) {
         unsigned tot = (unsigned)wave_sum_i32((int)n_ext_total);
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->n_ext, (u64)tot);
         unsigned ex = (unsigned)wave_sum_i32((int)n_exec_total);
-        if (lane == 0 && ex) atomicAdd(&LH_CTR(ctr)->n_ext_exec[MODE == 3 || MODE == 1 || MODE == 0 || MODE == 5 || MODE == 6 ? 0 : MODE == 4 ? 1 : 2], (u64)ex);
+        if (lane == 0 && ex) atomicAdd(&LH_CTR(ctr)->n_ext_exec[PASS - 1], (u64)ex);
         unsigned kx = (unsigned)wave_sum_i32((int)n_ktree_total);
-        if (lane == 0 && kx) atomicAdd(&LH_CTR(ctr)->n_ktree[MODE == 3 || MODE == 1 || MODE == 0 || MODE == 5 || MODE == 6 ? 0 : MODE == 4 ? 1 : 2], (u64)kx);
+        if (lane == 0 && kx) atomicAdd(&LH_CTR(ctr)->n_ktree[PASS - 1], (u64)kx);
+        unsigned bx = (unsigned)wave_sum_i32((int)n_bt_total);
+        if (lane == 0 && bx) atomicAdd(&LH_CTR(ctr)->n_bt, (u64)bx);
     }
 }
 
-// after the sweeps of the split pass 1: a read's counter may have run past its array (the read is flagged; the one-kernel pass stops at the limit)
-__global__ void __launch_bounds__(256) k_clamp_intv(int n_reads, int32_t* __restrict__ n_intv) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_reads && n_intv[r] > LH_MAX_INTV) n_intv[r] = LH_MAX_INTV;
+// sort each read's intervals by info (rank sort; equal keys are identical intervals), seed counts, l_rep.  16 lanes per read.
+__global__ void __launch_bounds__(256) k_smem_fin(DOpts o, int n_reads, DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv, int32_t* __restrict__ seed_cnt,
+                                                   int32_t* __restrict__ l_rep_out) {
+    int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    int r = gid < n_reads ? gid : n_reads - 1;
+    int live = gid < n_reads;
+    DIntv* a = intv + (size_t)r * LH_MAX_INTV;
+    int n = n_intv[r];
+    DIntv mine[4];
+    int rank[4];
+    for (int t = 0; t < 4; ++t) {
+        int e = sub + 16 * t;
+        mine[t].x0 = mine[t].x1 = mine[t].x2 = 0; mine[t].info = ~0ull;
+        if (e < n) mine[t] = a[e];
+        rank[t] = 0;
+    }
+    for (int u = 0; u < n; ++u) {
+        u64 oi = a[u].info;
+        for (int t = 0; t < 4; ++t) { int e = sub + 16 * t; rank[t] += (oi < mine[t].info) || (oi == mine[t].info && u < e); }
+    }
+    __syncthreads();   // every lane holds its entries before any is overwritten
+    int cnt = 0;
+    for (int t = 0; t < 4; ++t) {
+        int e = sub + 16 * t;
+        if (e < n && live) {
+            a[rank[t]] = mine[t];
+            u64 s = mine[t].x2;
+            u64 step = s > (u64)o.max_occ ? s / (u64)o.max_occ : 1;
+            u64 c = (s + step - 1) / step;
+            cnt += (int)(c < (u64)o.max_occ ? c : (u64)o.max_occ);
+        }
+    }
+    cnt += (int)dpp_xor1((uint32_t)cnt); cnt += (int)dpp_xor2((uint32_t)cnt); cnt += (int)dpp_half_mirror((uint32_t)cnt); cnt += (int)dpp_ror8((uint32_t)cnt);
+    __syncthreads();
+    if (sub == 0 && live) {
+        int b = 0, e = 0, l_rep = 0;
+        for (int u = 0; u < n; ++u) {
+            DIntv p = a[u];
+            if (p.x2 <= (u64)o.max_occ) continue;
+            int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
+            if (sb > e) { l_rep += e - b; b = sb; e = se; }
+            else e = e > se ? e : se;
+        }
+        l_rep += e - b;
+        seed_cnt[r] = cnt; l_rep_out[r] = l_rep;
+    }
+}
+
+// intervals stored by text position (LH_POSF) -> suffix-array rows, as bwt_smem1a reports them: x0 = the row of the match, x1 = the row of
+// its reverse complement (the stage dump, which the tests compare with the oracle's intervals)
+__global__ void __launch_bounds__(256) k_intv_rows(DIndex ix, int n_reads, DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || !ix.isa) return;
+    DIntv* a = intv + (size_t)r * LH_MAX_INTV;
+    const int n = n_intv[r];
+    for (int k = 0; k < n; ++k) {
+        DIntv p = a[k];
+        if (!(p.x0 & LH_POSF)) continue;
+        const u64 pos = p.x0 & ~LH_POSF;
+        const int l = (int)(uint32_t)p.info - (int)(p.info >> 32);
+        p.x0 = ix.isa[pos]; p.x1 = ix.isa[ix.seq_len - (pos + (u64)l)];
+        a[k] = p;
+    }
 }

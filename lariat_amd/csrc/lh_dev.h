@@ -97,6 +97,9 @@ struct DIndex {
     // lcp[r] = bases shared by the suffixes of rows r - 1 and r, capped at 255 (rows 0, 1 and n + 1: 0); next to isa / tn, else null.
     // K1 (pass 1) reads from it whether every entry of a forward list is unique at the point where its longest one ends (k_smem4.h).
     const uint8_t* lcp;
+    // plcp[p] = the most bases the suffix of the text (fwd||rev) at position p shares with any OTHER suffix, capped at 255: max(lcp[r], lcp[r + 1]) at
+    // r = isa[p].  Next to isa / tn / lcp, else null.  K1 decides from it — by text position, without a row — whether a match is unique (k_smem4.h).
+    const uint8_t* plcp;
     // rep_t: one bit per position of the text fwd||rev, next to lcp, else null: the LH_BLOOM_K-mer that starts there occurs again elsewhere
     // (its row shares LH_BLOOM_K bases with a neighbouring row).  K1's pass 2 reads from it that a re-seeding inside a unique SMEM
     // cannot yield a seed (k_smem4.h, S4_P2_PROBE).
@@ -146,7 +149,7 @@ struct DReg {   // mem_alnreg_t
 // telemetry counters: LH_CTR_SLOTS copies on separate 128-B lines, indexed by blockIdx, summed by the host
 // (same-address atomics serialize at ~12 ns each: one shared copy cost k_extend ~70 ms per 2M waves)
 #define LH_CTR_SLOTS 64
-struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells, n_ext_exec[3], n_ktree[3], pad[1]; };   // n_ext_exec: bwt_extend calls K1 really executed on the occurrence table, per pass; n_ktree: those it read from the k-mer tree table
+struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells, n_ext_exec[3], n_ktree[3], n_bt; };   // n_ext_exec: bwt_extend calls K1 really executed on the occurrence table, per pass; n_ktree: those it read from the k-mer tree table
 #define LH_CTR(ctr) ((ctr) + (blockIdx.x & (LH_CTR_SLOTS - 1)))
 
 // ------------------------------------------------------------------ lane helpers

@@ -86,26 +86,26 @@ def test_emu_long_noisy_reads(emu, oracle):
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
 
 
-def test_emu_k1_launch_variants_and_sweep_filter(emu, oracle):
-    """K1 as three launches (default), two (LH_F_SMEM_P12) or one (LH_F_SMEM_FUSED), with and without the sweep filter: the same
-    intervals / seeds / chains as the oracle every time; the filter executes fewer bwt_extend calls, without it the count is
-    the reference's"""
+def test_emu_k1_sweep_filter_and_text_shortcuts(emu, oracle):
+    """K1 with and without its exact shortcuts (sweep filter, collapsed sweeps, calls by text): the same intervals / seeds / chains as
+    the oracle both ways; with them fewer bwt_extend calls are accounted for, without them (LH_F_NO_SWEEP_FILTER) the count is the
+    reference's"""
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
     idx = emu.index_from_arrays(oidx.arrays())
     rs = helpers.small_reads(names, contigs, n_barcodes=2, pairs=25, junk=0.05, seed=41)
-    rs.seq[np.arange(7, len(rs.seq), 211)] = 4   # ambiguous bases: the filter's window logic
+    rs.seq[np.arange(7, len(rs.seq), 211)] = 4   # ambiguous bases: the filter's window logic, runs that stop at a non-base
     b = helpers.batch_of(rs)
     want = oidx.stage_dump(b)
     want_ext = oidx.align_barcodes(b, oracle.opts(run_inference=0)).counters["n_ext"]
     ctx = idx.context(rs.n_pairs)
     seen = {}
-    P12, FUSED, NOF, SPLIT = capi.LH_F_SMEM_P12, capi.LH_F_SMEM_FUSED, capi.LH_F_NO_SWEEP_FILTER, capi.LH_F_SMEM_SPLIT
-    for flags in (0, SPLIT, P12, FUSED, NOF, NOF | FUSED, NOF | SPLIT):
+    NOF = capi.LH_F_NO_SWEEP_FILTER
+    for flags in (0, NOF):
         helpers.assert_same_dump(ctx.stage_dump(b, emu.opts(flags=flags)), want, helpers.DUMP_FRONT)
         seen[flags] = ctx.align_barcodes(b, emu.opts(run_inference=0, flags=flags)).counters["n_ext"]
-    assert seen[NOF] == want_ext == seen[NOF | FUSED] == seen[NOF | SPLIT]
-    assert seen[0] == seen[P12] == seen[FUSED] == seen[SPLIT] < want_ext
+    assert seen[NOF] == want_ext
+    assert seen[0] < want_ext
 
 
 def test_emu_many_candidate_pairs_go_rng_ring(emu, oracle):
