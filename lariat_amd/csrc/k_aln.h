@@ -13,6 +13,7 @@
 
 #define LH_MAXT 704                       // reference bases staged per candidate (re - rb)
 #define LH_ZSLAB (LH_MAXT * 256)          // direction bytes per resident wave
+#define LH_ZLDS 8192                      // ... kept in LDS when the band is narrow enough (150 rows x 54 columns)
 
 struct DCand {   // device-side result arrays (one entry per candidate unless noted)
     i64* cand_off;   // [n_reads+1] (input)
@@ -57,8 +58,9 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
     __shared__ uint32_t cg[LH_MAX_CIGAR + 4];
     __shared__ uint32_t cgo[LH_MAX_CIGAR + 4];
     __shared__ int32_t sh[8];
+    __shared__ uint8_t zl[LH_ZLDS];   // the direction bytes of a narrow band: lane 0's traceback is a chain of dependent reads (from the HBM slab: ~1 us each)
     int lane = LANE();
-    uint8_t* z = zpool + (size_t)blockIdx.x * LH_ZSLAB;
+    uint8_t* const zg = zpool + (size_t)blockIdx.x * LH_ZSLAB;
     u64 cells = 0;
     const int n_items = *slow_count;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -123,10 +125,12 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
                         w = w < w2 ? w : w2;
                         int min_w = dl + 3;
                         w = w > min_w ? w : min_w;
+                        const int n_col_ = lq < 2 * w + 1 ? lq : 2 * w + 1;
+                        uint8_t* const z = rlen * n_col_ <= LH_ZLDS ? zl : zg;
                         score = wave_ksw_global2(ix, o, q, qoff, qstep, lq, t0, tstep, rlen, w, z, lane, &cells);
                         WAVE_SYNC();
                         if (lane == 0) {   // backtrack
-                            int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
+                            const int n_col = n_col_;
                             int which = 0, nc = 0, ovf = 0;
                             int i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
                             // ops are produced last-to-first; push_cigar merges equal neighbours
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
 __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                    const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, i64 cand_cap,
                                                    int32_t* __restrict__ status, int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count,
-                                                   DCounters* __restrict__ ctr) {
+                                                   DCounters* __restrict__ ctr, const uint32_t* __restrict__ q4) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     const int live = r < n_reads;
     unsigned proven_cells = 0;   // cells of global DPs whose outcome is known without running them (see below)
@@ -328,30 +332,51 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                 if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
                 int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
                 int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
-                LaneTgt tg;
-                tg.init(ix, rb, 1);
                 int nmm = 0, n_amb = 0, xo = -2;   // n_amb: mismatching pairs with an ambiguous base (scored -1, not -b)
-                for (int t0 = 0; t0 < lq; t0 += 16) {   // 16 query bases per round trip (the batch buffer is padded past the last read)
-                    uint32_t qw[4];
-                    __builtin_memcpy(qw, q + qb + t0, 16);
+                // 32 pairs per round trip, eight per XOR: the batch's 4-bit reads against the 4-bit text (both strands: rb + t is a text position);
+                // without those tables the same words are put together from the bytes and the 2-bit reference
+                LaneTgt tg;
+                const bool packed = ix.tn && q4;
+                tg.init(ix, rb, 1);
+                for (int t0 = 0; t0 < lq; t0 += 32) {
+                    uint32_t qx[4], tx[4];
+                    if (packed) {
+                        const i64 qp = off + qb + t0, tp = rb + t0;
+                        const uint32_t* qa = q4 + (qp >> 3);
+                        const uint32_t* ta = ix.tn + (tp >> 3);
+                        uint32_t qr[5], tr[5];
+                        for (int k = 0; k < 5; ++k) { qr[k] = qa[k]; tr[k] = ta[k]; }   // (both streams are padded past their ends)
+                        const int qs = (int)(qp & 7) * 4, ts = (int)(tp & 7) * 4;
+                        for (int k = 0; k < 4; ++k) {
+                            qx[k] = qs ? (qr[k] >> qs) | (qr[k + 1] << (32 - qs)) : qr[k];
+                            tx[k] = ts ? (tr[k] >> ts) | (tr[k + 1] << (32 - ts)) : tr[k];
+                        }
+                    } else {
+                        for (int k = 0; k < 4; ++k) {
+                            qx[k] = 0; tx[k] = 0;
+                            for (int u = 0; u < 8 && t0 + 8 * k + u < lq; ++u) { qx[k] |= (uint32_t)(q[qb + t0 + 8 * k + u] & 0xf) << (4 * u); tx[k] |= (uint32_t)tg.base(t0 + 8 * k + u) << (4 * u); }
+                        }
+                    }
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        int t = t0 + u;
-                        if (t < lq) {
-                            int rbase = tg.base(t), qv = (int)((qw[u >> 2] >> ((u & 3) * 8)) & 0xff);
-                            if (rbase != qv) {
-                                if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
-                                else {   // (rare: the pool, see DCand)
-                                    if (xo == -2) {
-                                        xo = atomicAdd(R.mm_xctr, l_query - LH_MAX_MM);
-                                        if (xo + l_query - LH_MAX_MM > R.mm_xcap) xo = -1;
-                                        R.mm_xoff[c] = xo;
-                                    }
-                                    if (xo >= 0) { R.mm_xref[xo + nmm - LH_MAX_MM] = is_rev ? (int)refEnd - t : t + (int)refStart; R.mm_xread[xo + nmm - LH_MAX_MM] = qb + t; }
+                    for (int k = 0; k < 4; ++k) {
+                        const int tb = t0 + 8 * k;
+                        if (tb >= lq) break;
+                        const uint32_t qw = qx[k];
+                        uint32_t xw = (qw ^ tx[k]) & (lq - tb < 8 ? (1u << (4 * (lq - tb))) - 1u : 0xffffffffu);
+                        while (xw) {
+                            const int u = (__ffs((int)xw) - 1) >> 2, t = tb + u;
+                            xw &= ~(0xfu << (4 * u));
+                            if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
+                            else {   // (rare: the pool, see DCand)
+                                if (xo == -2) {
+                                    xo = atomicAdd(R.mm_xctr, l_query - LH_MAX_MM);
+                                    if (xo + l_query - LH_MAX_MM > R.mm_xcap) xo = -1;
+                                    R.mm_xoff[c] = xo;
                                 }
-                                nmm++;
-                                n_amb += qv > 3;
+                                if (xo >= 0) { R.mm_xref[xo + nmm - LH_MAX_MM] = is_rev ? (int)refEnd - t : t + (int)refStart; R.mm_xread[xo + nmm - LH_MAX_MM] = qb + t; }
                             }
+                            nmm++;
+                            n_amb += ((qw >> (4 * u)) & 0xf) > 3;
                         }
                     }
                 }
@@ -371,9 +396,9 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                         int w = (max_gap + 1) >> 1;
                         w = w < wq ? w : wq;
                         w = w > 3 ? w : 3;
-                        for (int i = 0; i < rlen; ++i) {
-                            int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
-                            if (end > beg) proven_cells += (unsigned)(end - beg);
+                        {   // sum over rows i of min(i + w + 1, lq) - max(i - w, 0)   (rlen == lq here)
+                            const int n1 = lq - w > 0 ? lq - w : 0, m = lq - 1 - w > 0 ? lq - 1 - w : 0;
+                            proven_cells += (unsigned)(n1 * (w + 1) + n1 * (n1 - 1) / 2 + (lq - n1) * lq - m * (m + 1) / 2);
                         }
                         if (S0 == last_sc || wq == o.w << 2) break;
                         last_sc = S0;
