@@ -235,6 +235,14 @@ int lh_index_from_arrays(int device, uint64_t primary, const uint64_t L2[5], con
                          int32_t n_contigs, const int64_t* contig_off, const int32_t* contig_len, const char* const* contig_name,
                          const lh_index_opts* io, lh_index** out);
 /* GetReferenceContigsInfo (gobwa.go:26) */
+/* ALT contigs — bntann1_t.is_alt, which bwa_idx_load(path, BWA_IDX_ALL) (gobwa/gobwa.go:130) restores from <prefix>.alt (bntseq.c
+ * bns_restore: per line the first token up to a tab / newline is a contig name, lines starting with '@' are skipped, a name that
+ * matches a contig of .ann marks it; a last line without a newline is not seen).  mem_chain_flt does not let an ALT chain shadow a
+ * primary one, and every region on an ALT contig carries is_alt.  lh_index_load reads the file when it exists; lh_index_set_alt does
+ * the same from an array of n_contigs flags (indexes built from arrays or on the device); lh_index_alt returns the resident flags
+ * (NULL: none); lh_index_save writes <prefix>.alt when any contig is ALT. */
+int lh_index_set_alt(lh_index* idx, const uint8_t* is_alt);
+const uint8_t* lh_index_alt(const lh_index* idx);
 int lh_index_contigs(const lh_index* idx, int32_t* n, const char* const** names, const int64_t** lens, const int64_t** offsets);
 int64_t lh_index_l_pac(const lh_index* idx);
 /* The .sa file holds every 32nd suffix-array row (bwa index default); bwt_sa (reached from mem_chain via gobwa.go:244,253)

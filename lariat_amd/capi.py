@@ -582,6 +582,20 @@ class Index:
         self.lib.check(self.lib.L.lh_diag_index_digest(self.h, C.byref(a), C.byref(b), C.byref(l)))
         return a.value, b.value, l.value
 
+    def set_alt(self, flags):
+        """bntann1_t.is_alt per contig (what <prefix>.alt sets when lh_index_load finds it)"""
+        f = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert len(f) == len(self.contigs())
+        self.lib.L.lh_index_set_alt.argtypes = [C.c_void_p, c_u8p]
+        self.lib.check(self.lib.L.lh_index_set_alt(self.h, f.ctypes.data_as(c_u8p)))
+
+    def alt(self):
+        self.lib.L.lh_index_alt.argtypes = [C.c_void_p]
+        self.lib.L.lh_index_alt.restype = c_u8p
+        p = self.lib.L.lh_index_alt(self.h)
+        n = len(self.contigs())
+        return [0] * n if not p else [int(p[i]) for i in range(n)]
+
     def set_holes(self, holes):
         n = len(holes)
         ho = np.array([h[0] for h in holes], dtype=np.int64)
@@ -791,5 +805,5 @@ EXPORTED_SYMBOLS = [
     "lh_records_text", "lh_records_text_ex", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_set_flags", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_random_read", "lh_diag_go_rand",
-    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest",
+    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt",
 ]

@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, 
             a.w = aw0 > aw1 ? aw0 : aw1;
             a.seedlen0 = s.len;
             a.frac_rep = c.frac_rep;
+            a.is_alt = c.is_alt;
             if (lane == 0) av[n_av] = a;
             n_av++;
             WAVE_SYNC();

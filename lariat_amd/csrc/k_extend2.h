@@ -498,6 +498,7 @@ __device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, con
                 a.w = aw0 > aw1 ? aw0 : aw1;
                 a.seedlen0 = s.len;
                 a.frac_rep = c.frac_rep;
+                a.is_alt = c.is_alt;   // (mem_align1_core sets it from the contig after the dedup: the same flag)
                 av[n_av++] = a;
                 --k;
             }

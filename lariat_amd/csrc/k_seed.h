@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(256) k_seed_owner(int n_reads, const i64* __re
 // K2.  one lane per seed; grid-stride over the pool.
 __global__ void __launch_bounds__(256) k_seed(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ seed_off, i64 pool_cap,
                                               const DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv, DSeed* __restrict__ seeds,
-                                              int32_t* __restrict__ s_rid, DCounters* __restrict__ ctr, const int32_t* __restrict__ owner) {
+                                              int32_t* __restrict__ s_rid, DCounters* __restrict__ ctr, const int32_t* __restrict__ owner,
+                                              const int32_t* __restrict__ big_slot, const DIntv* __restrict__ big_slab) {
     i64 total = seed_off[n_reads];
     if (total > pool_cap) total = pool_cap;
     i64 stride = (i64)gridDim.x * blockDim.x;
@@ -95,7 +96,8 @@ __global__ void __launch_bounds__(256) k_seed(DIndex ix, DOpts o, int n_reads, c
         if (g < total) {
             int r = owner[g];
             i64 u = g - seed_off[r];
-            const DIntv* iv = intv + (size_t)r * LH_MAX_INTV;
+            const int bs = big_slot ? big_slot[r] : -1;   // (a read with more than LH_MAX_INTV intervals: the sorted half of its big-slab slot, k_smem4.h)
+            const DIntv* iv = bs < 0 ? intv + (size_t)r * LH_MAX_INTV : big_slab + ((size_t)bs * 2 + 1) * LH_BIG_INTV;
             int n = n_intv[r];
             u64 x0 = 0, step = 1, info = 0;
             for (int t = 0; t < n; ++t) {

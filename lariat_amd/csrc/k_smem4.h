@@ -106,10 +106,15 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 // the long SMEMs pass 1 left (recognised from the stored intervals).  PASS 3: bwt_seed_strategy1, appended to the intervals the earlier
 // launches left (it depends on the read alone, and the intervals are sorted afterwards).  Each launch carries only its own states:
 // fewer instructions per turn, fewer registers.
-template <int PASS>
-__global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pass(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
+// BIG: the second chance of the reads whose intervals outgrew their LH_MAX_INTV regular slots (listed by k_big_collect): the same
+// passes again, over the list, into slab slots of LH_BIG_INTV intervals (BWA's interval vector grows; no read is refused for it).
+struct K1Big { const int32_t* list; const int32_t* count; const int32_t* slot; DIntv* slab; };   // slot[r]: the read's big-slab slot, -1: none; slab: 2 x LH_BIG_INTV per slot (unsorted | sorted)
+template <int PASS, bool BIG>
+__global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pass(DIndex ix, DOpts o, int n_reads_all, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
-                                               int32_t* __restrict__ next_read, DCounters* __restrict__ ctr) {
+                                               int32_t* __restrict__ next_read, DCounters* __restrict__ ctr, K1Big big) {
+    const int n_reads = BIG ? *big.count : n_reads_all;
+    constexpr int ICAP = BIG ? LH_BIG_INTV : LH_MAX_INTV;
     __shared__ uint32_t qn[32 * 64];
     constexpr bool DO1 = PASS == 1, DO2 = PASS == 2, DO12 = DO1 || DO2, DO3 = PASS == 3, P3T = PASS == 3;
     // PASS 3 BY TEXT (with a dense suffix array).  A walk of bwt_seed_strategy1 from x ends at the first length L >= min_seed_len + 1
@@ -362,7 +367,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
 #define EMIT_MEM()                                                                                           \
     {                                                                                                        \
         if (cinfo - (i + 1) >= o.min_seed_len) {                                                             \
-            if (on >= LH_MAX_INTV) ovf = 1;                                                                  \
+            if (on >= ICAP) ovf = 1;                                                                  \
             else {                                                                                           \
                 DIntv m_; m_.x0 = c0; m_.x1 = c1; m_.x2 = c2; m_.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32; \
                 out[on] = m_; on++;                                                                          \
@@ -390,7 +395,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                 int idx = chunk_next + lanes_below(need, lane);
                 rr = idx < chunk_end ? idx : newbase + (idx - chunk_end);
                 if (rr >= n_reads) st = S4_DONE;
-                else { off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
+                else { if (BIG) rr = big.list[rr]; off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
             }
             if (chunk_next + cnt > chunk_end) { chunk_next = newbase + (chunk_next + cnt - chunk_end); chunk_end = newbase + 64; }
             else chunk_next += cnt;
@@ -424,7 +429,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             if (st == S4_FETCH) {
                 r = rr; len = ln; rst = 0; on = 0; ovf = 0; p2mask = 0; rflags = 0;
                 if (len > LH_MAXLEN) { rst |= LH_ST_TOO_LONG; len = 0; }
-                out = intv_out + (size_t)r * LH_MAX_INTV;
+                out = BIG ? big.slab + (size_t)big.slot[r] * (2 * LH_BIG_INTV) : intv_out + (size_t)r * LH_MAX_INTV;
                 if (!DO1) { on = n_intv[r]; rst |= status[r]; }   // continue behind the intervals of the earlier passes
                 if (len >= o.min_seed_len) { x = 0; st = DO1 ? S4_P1_SCAN : DO2 ? S4_P2_NEXT : S4_P3_SCAN; }
                 else st = S4_READ_DONE;
@@ -539,7 +544,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                 st = S4_P3_SCAN;
                 for (int k = 0; k < j; ++k) {
                     if ((int)((tw0 >> (8 * k)) & 0xff) < Lw) {   // unique: the walk ends here with one occurrence
-                        if (on >= LH_MAX_INTV) ovf = 1;
+                        if (on >= ICAP) ovf = 1;
                         else { DIntv m; m.x0 = LH_POSF | (u64)(run_p + (i64)k * Lw); m.x1 = 0; m.x2 = 1; m.info = (u64)x << 32 | (u64)(x + Lw); out[on++] = m; }
                         n_ext_total += (unsigned)(Lw - 1);
                         x += Lw;
@@ -833,7 +838,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
         } else if (DO3 && st == S4_REQ_P3) {
             if (ok.x2 < (u64)o.max_mem_intv && i - x >= o.min_seed_len) {
                 if (ok.x2 > 0) {
-                    if (on >= LH_MAX_INTV) ovf = 1;
+                    if (on >= ICAP) ovf = 1;
                     else { DIntv m = ok; m.info = (u64)x << 32 | (u64)(i + 1); out[on++] = m; }
                 }
                 x = i + 1; st = S4_P3_SCAN;
@@ -890,14 +895,37 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
     }
 }
 
-// sort each read's intervals by info (rank sort; equal keys are identical intervals), seed counts, l_rep.  16 lanes per read.
+// a read's interval array: its regular slots, or the sorted half of its big-slab slot
+__device__ __forceinline__ DIntv* dev_intv_of(DIntv* intv, const K1Big& big, int r, int sorted) {
+    const int s = big.slot ? big.slot[r] : -1;
+    return s < 0 ? intv + (size_t)r * LH_MAX_INTV : big.slab + ((size_t)s * 2 + (sorted ? 1 : 0)) * LH_BIG_INTV;
+}
+// seed count of a read (mem_chain: at most max_occ sampled occurrences per interval) and l_rep from its sorted intervals
+__device__ __forceinline__ int dev_l_rep(const DOpts& o, const DIntv* a, int n) {
+    int b = 0, e = 0, l_rep = 0;
+    for (int u = 0; u < n; ++u) {
+        DIntv p = a[u];
+        if (p.x2 <= (u64)o.max_occ) continue;
+        int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
+        if (sb > e) { l_rep += e - b; b = sb; e = se; }
+        else e = e > se ? e : se;
+    }
+    return l_rep + e - b;
+}
+__device__ __forceinline__ int dev_seed_count(const DOpts& o, u64 s) {
+    u64 step = s > (u64)o.max_occ ? s / (u64)o.max_occ : 1;
+    u64 c = (s + step - 1) / step;
+    return (int)(c < (u64)o.max_occ ? c : (u64)o.max_occ);
+}
+// sort each read's intervals by info (rank sort; equal keys are identical intervals), seed counts, l_rep.  16 lanes per read
+// (reads in the big slab: k_smem_fin_big).
 __global__ void __launch_bounds__(256) k_smem_fin(DOpts o, int n_reads, DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv, int32_t* __restrict__ seed_cnt,
-                                                   int32_t* __restrict__ l_rep_out) {
+                                                   int32_t* __restrict__ l_rep_out, const int32_t* __restrict__ big_slot) {
     int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
     int r = gid < n_reads ? gid : n_reads - 1;
-    int live = gid < n_reads;
+    int live = gid < n_reads && !(big_slot && big_slot[r] >= 0);
     DIntv* a = intv + (size_t)r * LH_MAX_INTV;
-    int n = n_intv[r];
+    int n = live ? n_intv[r] : 0;
     DIntv mine[4];
     int rank[4];
     for (int t = 0; t < 4; ++t) {
@@ -916,34 +944,56 @@ __global__ void __launch_bounds__(256) k_smem_fin(DOpts o, int n_reads, DIntv* _
         int e = sub + 16 * t;
         if (e < n && live) {
             a[rank[t]] = mine[t];
-            u64 s = mine[t].x2;
-            u64 step = s > (u64)o.max_occ ? s / (u64)o.max_occ : 1;
-            u64 c = (s + step - 1) / step;
-            cnt += (int)(c < (u64)o.max_occ ? c : (u64)o.max_occ);
+            cnt += dev_seed_count(o, mine[t].x2);
         }
     }
     cnt += (int)dpp_xor1((uint32_t)cnt); cnt += (int)dpp_xor2((uint32_t)cnt); cnt += (int)dpp_half_mirror((uint32_t)cnt); cnt += (int)dpp_ror8((uint32_t)cnt);
     __syncthreads();
-    if (sub == 0 && live) {
-        int b = 0, e = 0, l_rep = 0;
-        for (int u = 0; u < n; ++u) {
-            DIntv p = a[u];
-            if (p.x2 <= (u64)o.max_occ) continue;
-            int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
-            if (sb > e) { l_rep += e - b; b = sb; e = se; }
-            else e = e > se ? e : se;
+    if (sub == 0 && live) { seed_cnt[r] = cnt; l_rep_out[r] = dev_l_rep(o, a, n); }
+}
+// the same for a read in the big slab, one wave per read: ranks against the unsorted half, written to the sorted half
+__global__ void __launch_bounds__(64) k_smem_fin_big(DOpts o, K1Big big, const int32_t* __restrict__ n_intv, int32_t* __restrict__ seed_cnt, int32_t* __restrict__ l_rep_out) {
+    const int lane = LANE(), n_big = *big.count;
+    for (int item = blockIdx.x; item < n_big; item += gridDim.x) {
+        const int r = big.list[item];
+        const DIntv* a = big.slab + (size_t)big.slot[r] * (2 * LH_BIG_INTV);
+        DIntv* b = big.slab + ((size_t)big.slot[r] * 2 + 1) * LH_BIG_INTV;
+        const int n = n_intv[r];
+        int cnt = 0;
+        for (int e = lane; e < n; e += 64) {
+            const DIntv m = a[e];
+            int rank = 0;
+            for (int u = 0; u < n; ++u) { const u64 oi = a[u].info; rank += (oi < m.info) || (oi == m.info && u < e); }
+            b[rank] = m;
+            cnt += dev_seed_count(o, m.x2);
         }
-        l_rep += e - b;
-        seed_cnt[r] = cnt; l_rep_out[r] = l_rep;
+        cnt = wave_sum_i32(cnt);
+        WAVE_SYNC();
+        if (lane == 0) { seed_cnt[r] = cnt; l_rep_out[r] = dev_l_rep(o, b, n); }
+        WAVE_SYNC();
     }
+}
+// after the three passes: the reads whose intervals did not fit their regular slots get a slot of the big slab and are listed for the
+// second chance (their flag is cleared; it is set again if LH_BIG_INTV do not hold them either, or the slab has no slot left)
+__global__ void __launch_bounds__(256) k_big_collect(int n_reads, int32_t* __restrict__ status, int32_t* __restrict__ n_intv, int32_t* __restrict__ slot, int32_t* __restrict__ list,
+                                                      int32_t* __restrict__ count, int cap) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int s = -1;
+    if (status[r] & LH_ST_INTV_OVERFLOW) {
+        s = atomicAdd(count + 1, 1);   // count[1]: slots asked for; count[0]: reads listed
+        if (s < cap) { list[atomicAdd(count, 1)] = r; status[r] &= ~LH_ST_INTV_OVERFLOW; n_intv[r] = 0; }
+        else s = -1;
+    }
+    slot[r] = s;
 }
 
 // intervals stored by text position (LH_POSF) -> suffix-array rows, as bwt_smem1a reports them: x0 = the row of the match, x1 = the row of
 // its reverse complement (the stage dump, which the tests compare with the oracle's intervals)
-__global__ void __launch_bounds__(256) k_intv_rows(DIndex ix, int n_reads, DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv) {
+__global__ void __launch_bounds__(256) k_intv_rows(DIndex ix, int n_reads, DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv, K1Big big) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads || !ix.isa) return;
-    DIntv* a = intv + (size_t)r * LH_MAX_INTV;
+    DIntv* a = dev_intv_of(intv, big, r, 1);
     const int n = n_intv[r];
     for (int k = 0; k < n; ++k) {
         DIntv p = a[k];

@@ -27,7 +27,10 @@ struct uint2 { uint32_t x, y; };
 
 #define LH_WAVE 64
 #define LH_MAXLEN 250            // LH_MAX_READ_LEN
-#define LH_MAX_INTV 64           // SMEM intervals kept per read (overflow -> status flag)
+#ifndef LH_MAX_INTV
+#define LH_MAX_INTV 64           // SMEM intervals kept per read in its regular slots; a read with more is seeded again into a big slab (k_smem4.h, BIG) — tests build with 4
+#endif
+#define LH_BIG_INTV 1024         // ... which holds this many per read (mem_collect_intv yields at most ~250 for 250 bases outside pathological re-seeding); beyond: LH_ST_INTV_OVERFLOW
 #define LH_MAX_CIGAR 64          // cigar ops per candidate
 #define LH_MAX_MM 64             // mismatch loci per candidate
 #define LH_RESCUE_SLOTS 50       // opt->max_matesw / gobwa.go:287

@@ -82,3 +82,37 @@ def repeat_windows(contigs, dups, flank=60000):
                     out.append(("%s%d" % (tag, k), int(e - b), int(b)))
                     break
     return out
+
+
+def add_alt_contigs(pac, contigs, n_alt, alt_len, identity, seed):
+    """configs[4]'s "ALT contigs = mutated copies of 1 Mb regions"  on a packed genome: appends `n_alt` contigs named
+    <source contig>_alt<k>, each a copy of `alt_len` bases of a primary contig with substitutions at 1 - identity.  Returns (pac, l_pac,
+    contigs, is_alt flags, [(src, dst, len)] in global coordinates)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lens = np.array([c[1] for c in contigs], dtype=np.int64)
+    offs = np.array([c[2] for c in contigs], dtype=np.int64)
+    alt_len = alt_len // 4 * 4
+    l_pac = int(offs[-1] + lens[-1])
+    assert l_pac % 4 == 0
+    out = list(contigs)
+    flags = [0] * len(contigs)
+    body = [pac[:l_pac >> 2]]
+    pairs = []
+    for k in range(n_alt):
+        ci = int(rng.choice(len(contigs), p=lens / lens.sum()))
+        src = int(offs[ci] + int(rng.integers(0, max(1, (lens[ci] - alt_len) // 4))) * 4)
+        seg = pac[src >> 2:(src + alt_len) >> 2].copy()
+        n_mut = int(round((1.0 - identity) * alt_len))
+        at = rng.integers(0, alt_len, size=n_mut)
+        delta = rng.integers(1, 4, size=n_mut)
+        sh = (~at & 3) << 1
+        codes = (seg[at >> 2] >> sh) & 3                     # (a position drawn twice keeps one of its draws: still a substitution)
+        seg[at >> 2] = (seg[at >> 2] & ~(3 << sh).astype(np.uint8)) | ((((codes + delta) & 3) << sh).astype(np.uint8))
+        body.append(seg)
+        out.append(("%s_alt%d" % (contigs[ci][0], k + 1), alt_len, l_pac))
+        flags.append(1)
+        pairs.append((src, l_pac, alt_len))
+        l_pac += alt_len
+    body.append(np.zeros(1, dtype=np.uint8))
+    return np.concatenate(body), l_pac, out, flags, pairs

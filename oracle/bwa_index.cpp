@@ -88,6 +88,27 @@ bool index_load(const std::string& prefix, Index& idx, std::string* err) {
                 if (sscanf(line.c_str(), "%lld %d %c", &o, &l, &ch) == 3) idx.holes.push_back(Index::Hole{o, l, ch});
             }
     }
+    {   // .alt (bntseq.c bns_restore, reached through bwa_idx_load(path, BWA_IDX_ALL): go/src/gobwa/gobwa.go:130): per line the first token up
+        // to a tab / newline / CR is a contig name ('@' lines skipped); a name found in .ann marks that contig (the last one of that name)
+        std::vector<uint8_t> a;
+        if (read_file(prefix + ".alt", a)) {
+            std::string tok;
+            size_t i = 0;
+            while (i < a.size()) {
+                char ch = (char)a[i++];
+                if (ch == '\t' || ch == '\n' || ch == '\r') {
+                    if (tok.empty() || tok[0] != '@') {
+                        int hit = -1;
+                        for (size_t k = 0; k < idx.contigs.size(); ++k) if (idx.contigs[k].name == tok) hit = (int)k;
+                        if (hit >= 0) idx.contigs[hit].is_alt = 1;
+                    }
+                    char c = ch;
+                    while (c != '\n' && i < a.size()) c = (char)a[i++];
+                    tok.clear();
+                } else tok.push_back(ch);
+            }
+        }
+    }
     // .pac (forward strand only)
     if (!read_file(prefix + ".pac", d)) { if (err) *err = "cannot read " + prefix + ".pac"; return false; }
     idx.pac.assign(d.begin(), d.begin() + (idx.l_pac / 4 + 1));

@@ -137,6 +137,9 @@ int lo_index_build_naive(int32_t n_contigs, const char* const* names, const uint
 }
 
 void lo_index_free(Index* idx) { delete idx; }
+// bntann1_t.is_alt per contig (what <prefix>.alt sets on load), for indexes made from arrays
+void lo_index_set_alt(Index* idx, const uint8_t* is_alt) { for (size_t i = 0; i < idx->contigs.size(); ++i) idx->contigs[i].is_alt = is_alt[i] ? 1 : 0; }
+int32_t lo_index_contig_alt(const Index* idx, int i) { return idx->contigs[i].is_alt; }
 int64_t lo_index_l_pac(const Index* idx) { return idx->l_pac; }
 int32_t lo_index_n_contigs(const Index* idx) { return (int32_t)idx->contigs.size(); }
 const char* lo_index_contig_name(const Index* idx, int i) { return idx->contigs[i].name.c_str(); }

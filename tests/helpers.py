@@ -167,3 +167,65 @@ def chance_match_genome_and_reads(n_pairs=24, seed=8, plant=21, rlen=150):
     rs.names = names
     rs.name_seed = synth._name_seeds(names)
     return ["chrC"], [g], rs
+
+
+def alt_genome_and_reads(seed=12, n_pairs=60):
+    """two primary contigs + one ALT contig (configs[4]: "hg38 + ALT/decoy"): the ALT is a copy of 30 kb of chrP1 in which novel 90-base
+    insertions alternate with 60 kept bases over a few kb (plus point mutations elsewhere), and chrP2 holds an exact copy of the same
+    30 kb.  Reads from the ALT's inserted stretch have a heavy chain on the ALT and two light ones on the primaries (the kept 60 bases):
+    with is_alt the light primary chains are not compared with the ALT chain in mem_chain_flt."""
+    rng = np.random.default_rng(seed)
+    p1 = rng.integers(0, 4, size=120000).astype(np.uint8)
+    p2 = rng.integers(0, 4, size=90000).astype(np.uint8)
+    src = p1[40000:70000].copy()
+    p2[20000:50000] = src
+    parts, pos = [], 0
+    while pos < len(src):
+        if 8000 <= pos < 16000:
+            parts += [src[pos:pos + 60], rng.integers(0, 4, size=90).astype(np.uint8)]
+            pos += 60
+        else:
+            seg = src[pos:pos + 500].copy()
+            m = rng.random(len(seg)) < 0.004
+            seg[m] = (seg[m] + rng.integers(1, 4, size=int(m.sum()))) % 4
+            parts.append(seg)
+            pos += 500
+    alt = np.concatenate(parts)
+    names = ["chrP1", "chrP2", "chrP1_alt1"]
+    contigs = [p1, p2, alt]
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    lo = 8000 * 150 // 60   # the inserted stretch in ALT coordinates
+    reads, rnames = [], []
+    for i in range(n_pairs):
+        ins = int(rng.integers(300, 480))
+        s = lo + int(rng.integers(0, 8000 * 150 // 60 - ins)) if i % 4 else int(rng.integers(0, len(alt) - ins))
+        r1 = alt[s:s + 143].copy()
+        r2 = comp[alt[s + ins - 150:s + ins][::-1]]
+        if i % 3 == 0:
+            r1[int(rng.integers(143))] ^= 1
+        reads += [r1, r2]
+        rnames.append("alt:%d" % i)
+    rs = synth.ReadSet()
+    lens = np.array([len(x) for x in reads], dtype=np.int64)
+    rs.seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rs.seq = np.concatenate(reads)
+    rs.bc_pair_off = np.array([0, n_pairs // 2, n_pairs], dtype=np.int32)
+    rs.names = rnames
+    rs.name_seed = synth._name_seeds(rnames)
+    return names, contigs, rs
+
+
+def low_complexity_genome(seed=9):
+    """poly-A tracts, di- and penta-nucleotide microsatellites and a 200-copy tandem repeat of a 37-base unit between random flanks: reads from
+    them have intervals with thousands of occurrences, hundreds of chains per read and long runs of equal candidates"""
+    rng = np.random.default_rng(seed)
+
+    def rnd(n):
+        return rng.integers(0, 4, size=n).astype(np.uint8)
+
+    def tandem(unit, n):
+        return np.tile(np.asarray(unit, dtype=np.uint8), n)
+
+    parts = [rnd(20000), tandem([0], 5000), rnd(3000), tandem([1, 0], 1500), rnd(3000), tandem(rnd(37), 200), rnd(3000), tandem(rnd(5), 800), rnd(3000),
+             tandem(rnd(2), 400), rnd(500), tandem([3], 600), rnd(20000)]
+    return ["chrL"], [np.concatenate(parts)]

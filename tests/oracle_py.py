@@ -29,6 +29,9 @@ class Oracle:
         L.lo_index_from_arrays.argtypes = [C.c_uint64, capi.c_u64p, capi.c_u32p, C.c_uint64, C.c_int32, capi.c_u64p, C.c_uint64, capi.c_u8p, C.c_int64, C.c_int32,
                                            capi.c_i64p, capi.c_i32p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         L.lo_index_free.argtypes = [C.c_void_p]
+        L.lo_index_set_alt.argtypes = [C.c_void_p, capi.c_u8p]
+        L.lo_index_contig_alt.argtypes = [C.c_void_p, C.c_int]
+        L.lo_index_contig_alt.restype = C.c_int32
         L.lo_index_l_pac.argtypes = [C.c_void_p]
         L.lo_index_l_pac.restype = C.c_int64
         L.lo_index_n_contigs.argtypes = [C.c_void_p]
@@ -110,6 +113,14 @@ class OracleIndex:
     @property
     def l_pac(self):
         return self.o.L.lo_index_l_pac(self.h)
+
+    def set_alt(self, flags):
+        f = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert len(f) == self.o.L.lo_index_n_contigs(self.h)
+        self.o.L.lo_index_set_alt(self.h, f.ctypes.data_as(capi.c_u8p))
+
+    def alt(self):
+        return [int(self.o.L.lo_index_contig_alt(self.h, i)) for i in range(self.o.L.lo_index_n_contigs(self.h))]
 
     def contigs(self):
         L = self.o.L

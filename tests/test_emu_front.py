@@ -233,3 +233,55 @@ def test_emu_large_barcode_position_sort(emu, oracle):
     assert int((ref.in_filtered != 0).sum()) > 800   # past LH_RFA_SORT_LDS
     helpers.assert_same_result(idx.context(rs.n_pairs).align_barcodes(b), ref, inference=True)
 
+
+
+def test_emu_alt_contigs(emu, oracle, tmp_path):
+    """ALT contigs (bwa_idx_load BWA_IDX_ALL restores <prefix>.alt: gobwa.go:130): mem_chain_flt does not let an ALT chain shadow a
+    primary one.  Same stage dumps and results as the oracle with the flags on; the flags change which chains are kept; and the .alt
+    file is read the way bns_restore reads it (first token per line, '@' lines skipped, unknown names ignored, a last line without a
+    newline not seen) by both loaders, and written back by lh_index_save."""
+    names, contigs, rs = helpers.alt_genome_and_reads()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    b = helpers.batch_of(rs)
+    plain = oidx.stage_dump(b)
+    ctx = idx.context(rs.n_pairs)
+    helpers.assert_same_dump(ctx.stage_dump(b), plain, helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    flags = [0, 0, 1]
+    oidx.set_alt(flags); idx.set_alt(flags)
+    assert idx.alt() == flags and oidx.alt() == flags
+    want = oidx.stage_dump(b)
+    helpers.assert_same_dump(ctx.stage_dump(b), want, helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b), inference=True)
+    # the ALT branch matters here: reads whose kept chains differ with and without the flags
+    changed = 0
+    for r in range(2 * rs.n_pairs):
+        a = want.chain_kept[want.chain_off[r]:want.chain_off[r + 1]]
+        p = plain.chain_kept[plain.chain_off[r]:plain.chain_off[r + 1]]
+        changed += len(a) != len(p) or not np.array_equal(a, p)
+    assert changed >= 5, changed
+    # the file
+    prefix = str(tmp_path / "alt.fa")
+    idx.save(prefix)
+    assert open(prefix + ".alt").read() == "chrP1_alt1\n"
+    open(prefix + ".alt", "w").write("@SQ\tSN:chrP2\nchrP1_alt1\t0\tchrP1\t40001\nnot_a_contig\t1\nchrP2")
+    li, lo = emu.index_load(prefix), oracle.index_load(prefix)
+    assert li.alt() == flags and lo.alt() == flags
+
+
+def test_emu_second_chance_paths(oracle):
+    """no read may fail a batch for a slot limit (BWA's vectors grow, gobwa.go:244-260): a build with FOUR regular interval slots per read
+    and two extension rounds sends nearly every read through the second chances — the three seeding passes again into the big slab, its
+    own sort, the seeds read from there; K4's leftover reads in the wave kernel — with the same stage dumps and results as the oracle"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "hipemu"), "small"])
+    small = capi.Library(os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu_small.so"))
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = small.index_from_arrays(oidx.arrays())
+    rs = helpers.small_reads(names, contigs, n_barcodes=3, pairs=30, junk=0.05, seed=29)
+    b = helpers.batch_of(rs)
+    od = oidx.stage_dump(b)
+    assert (np.diff(od.intv_off) > 4).mean() > 0.5   # most reads have more intervals than the regular slots of this build
+    ctx = idx.context(rs.n_pairs)
+    helpers.assert_same_dump(ctx.stage_dump(b), od, helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b), inference=True)

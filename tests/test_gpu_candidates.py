@@ -134,3 +134,20 @@ def test_pools_grow_on_demand(lib, oracle):
     assert d.seed_off[-1] > 32 * 2 * rs.n_pairs   # really beyond the initial pool
     helpers.assert_same_dump(d, oidx.stage_dump(b), helpers.DUMP_FRONT + helpers.DUMP_REGS)
     helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b, threads=8), inference=True)
+
+
+def test_low_complexity_reads_are_never_refused(lib, oracle):
+    """BWA never refuses a read (its vectors grow: gobwa.go:244-260 -> mem_align1_core); nor does the product.  A genome of poly-A tracts,
+    microsatellites and a 200-copy tandem repeat, noisy reads with indels drawn from in and around them (up to ~2,500 seeds and ~1,000
+    chains per read): no LH_E_LIMIT / LH_E_CAPACITY, every field of every candidate equal to the oracle's."""
+    from lariat_amd import synth
+    names, contigs = helpers.low_complexity_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs = synth.make_reads(contigs, names, n_barcodes=6, pairs_per_barcode=120, seed=3, sub_lo=0.002, sub_hi=0.03, indel_rate=0.002, mol_min=2, mol_max=3)
+    b = helpers.batch_of(rs)
+    ctx = idx.context(rs.n_pairs)
+    od = oidx.stage_dump(b)
+    assert np.diff(od.seed_off).max() > 2000 and np.diff(od.chain_off).max() > 500
+    helpers.assert_same_dump(ctx.stage_dump(b), od, helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b, threads=8), inference=True)

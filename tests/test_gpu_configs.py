@@ -148,16 +148,20 @@ def test_config2_hg38_scale(lib, oracle):
 
 
 def test_config4_like_segdup_biased(lib, oracle):
-    """configs[4] on one GPU: the hg38-scale genome with planted segmental duplications (1,500 x 20 kb at 99 %, 300 x 20 kb identical)
-    and interspersed repeat families, every read drawn from on and around them — several candidates per read, equal pair scores
-    (Go's generator decides), the RFA stress case: a sample of barcodes against the oracle on the same index, every field"""
-    ctg = workload.hg38_like_contigs(3100000000)
+    """configs[4] on one GPU: the hg38-scale genome with planted segmental duplications (1,500 x 20 kb at 99 %, 300 x 20 kb identical),
+    interspersed repeat families and 40 ALT contigs (1 Mb copies of primary regions at 99.7 %, flagged is_alt as <prefix>.alt would),
+    every read drawn from on and around them — several candidates per read, equal pair scores (Go's generator decides), chains on ALT
+    and primary copies competing in mem_chain_flt, the RFA stress case: a sample of barcodes against the oracle on the same index,
+    every field"""
+    ctg = workload.hg38_like_contigs(3060000000)
     l_pac = sum(c[1] for c in ctg)
     pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED + 4)
     dups = workload.plant_segdups(pac, ctg, 1500, 20000, 0.99, seed=41, n_families=40, family_len=320, family_copies=60)
     dups += workload.plant_segdups(pac, ctg, 300, 20000, 1.0, seed=42)
-    idx = lib.index_build_device(pac, l_pac, ctg)
-    win = workload.repeat_windows(ctg, dups[:1500] + dups[-300:], flank=50000)
+    pac, l_pac, ctg_all, alt_flags, alts = workload.add_alt_contigs(pac, ctg, 40, 1000000, 0.997, seed=43)
+    idx = lib.index_build_device(pac, l_pac, ctg_all)
+    idx.set_alt(alt_flags)
+    win = workload.repeat_windows(ctg_all, dups[:1500] + dups[-300:], flank=50000) + workload.repeat_windows(ctg_all, alts, flank=20000)
     r = lib.synth_reads(pac, l_pac, win, seed=workload.READS_SEED + 4, n_barcodes=3000, pairs_per_barcode=100, sub_hi=0.02, junk_frac=0.01)
     b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
     ctx = idx.context(r["n_pairs"])
@@ -166,10 +170,12 @@ def test_config4_like_segdup_biased(lib, oracle):
     dt = time.time() - t0
     nf = np.add.reduceat(res.in_filtered.astype(np.int64), res.cand_off[:-1])
     multi = float((nf >= 2).mean())
-    print("segdup-biased reads: %d pairs in %.2f s, %.1f candidates per read, %.0f %% of the reads with two or more equally plausible ones"
-          % (r["n_pairs"], dt, res.n_cand / res.n_reads, 100 * multi))
-    assert multi > 0.15
+    on_alt = float((np.asarray(alt_flags)[res.rid[res.rid >= 0]] == 1).mean())
+    print("segdup/ALT-biased reads: %d pairs in %.2f s, %.1f candidates per read, %.0f %% of the reads with two or more equally plausible ones, %.0f %% of the candidates on ALT contigs"
+          % (r["n_pairs"], dt, res.n_cand / res.n_reads, 100 * multi, 100 * on_alt))
+    assert multi > 0.15 and on_alt > 0.05
     oidx = oracle.index_from_arrays(idx.export(), pac)
+    oidx.set_alt(alt_flags)
     nb = 300
     p1 = int(r["bc_pair_off"][nb])
     sub = capi.Batch.from_arrays(r["seq"][: r["seq_off"][2 * p1]], r["seq_off"][: 2 * p1 + 1], r["bc_pair_off"][: nb + 1], r["name_seed"][:p1])
