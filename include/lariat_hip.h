@@ -408,6 +408,8 @@ int lh_bam_open(const char* dir, int32_t n_contigs, const char* const* contig_na
                 int32_t position_chunk_size, int32_t first_chunk, const char* command_line, int32_t threads, lh_bam_writer** out);
 /* appends the records of one batch (lh_records_text order) to bc_sorted_bam.bam and to their position bucket */
 int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_ingest_batch* in);
+int lh_bam_set_level(lh_bam_writer* w, int32_t level);  /* zlib level of the BGZF blocks written from now on: -1 (default) .. 9 */
+int lh_bam_timings(const lh_bam_writer* w, double* records_s, double* join_s, double* write_s);  /* the last lh_bam_append's phases */
 int lh_bam_set_flags(lh_bam_writer* w, int32_t flags); /* LH_REC_* for the records appended from now on (CreateBAMs' debugTags, bamwriter.go:133) */
 int lh_bam_close(lh_bam_writer* w); /* flushes, writes the BGZF end-of-file blocks, frees w */
 /* The host-side step of the multi-GPU path: every rank aligns a contiguous barcode range and writes its own file set

@@ -805,5 +805,5 @@ EXPORTED_SYMBOLS = [
     "lh_records_text", "lh_records_text_ex", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_set_flags", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_random_read", "lh_diag_go_rand",
-    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt",
+    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt", "lh_bam_set_level", "lh_bam_timings",
 ]

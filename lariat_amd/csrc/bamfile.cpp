@@ -82,6 +82,7 @@ struct lh_bam_writer {
     std::vector<std::vector<int>> bucket;        // [contig][chunk] -> outs index
     int64_t chunk = 40000000;
     int level = Z_DEFAULT_COMPRESSION, threads = 1;
+    double t_records = 0, t_join = 0, t_write = 0;   // the last lh_bam_append's phases, seconds
     bool failed = false;
 };
 
@@ -205,7 +206,6 @@ extern "C" int lh_bam_open(const char* dir, int32_t n_contigs, const char* const
     for (int i = 0; i < n_contigs; ++i) { w->names.push_back(contig_names[i]); w->lens.push_back(contig_lens[i]); w->rid_of[contig_names[i]] = i; }
     if (position_chunk_size > 0) w->chunk = position_chunk_size;
     w->threads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
-    if (const char* lv = getenv("LH_BAM_LEVEL")) w->level = atoi(lv);
     std::vector<bool> co;   // which files carry the @CO lines
     auto add = [&](const std::string& name, bool comments) { Out o; o.path = std::string(dir) + "/" + name; w->outs.push_back(o); co.push_back(comments); return (int)w->outs.size() - 1; };
     add("bc_sorted_bam.bam", first_chunk != 0);
@@ -250,9 +250,20 @@ extern "C" int lh_bam_open(const char* dir, int32_t n_contigs, const char* const
     return LH_OK;
 }
 
+extern "C" int lh_bam_set_level(lh_bam_writer* w, int32_t level) {
+    if (!w || level < -1 || level > 9) return lh_set_error_(LH_E_ARG, "lh_bam_set_level: level must be -1 (zlib's default) .. 9");
+    w->level = level;
+    return LH_OK;
+}
+extern "C" int lh_bam_timings(const lh_bam_writer* w, double* records_s, double* join_s, double* write_s) {
+    if (!w) return lh_set_error_(LH_E_ARG, "lh_bam_timings: null writer");
+    if (records_s) *records_s = w->t_records;
+    if (join_s) *join_s = w->t_join;
+    if (write_s) *write_s = w->t_write;
+    return LH_OK;
+}
 extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_ingest_batch* in) {
     if (!w || !res || !in) return lh_set_error_(LH_E_ARG, "lh_bam_append: null argument");
-    const bool timing = getenv("LH_BAM_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     std::vector<const char*> names;
@@ -260,16 +271,23 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
     // every range of pairs is rendered and encoded by its own host thread, straight from the result's arrays into BAM records
     // (no text form in between); per-file byte strings are joined in order
     std::vector<std::vector<std::string>> local;
-    int nt = 0;
+    int nt = w->threads;   // in: at most this many host threads (lh_bam_open); out: how many were used
+    std::atomic<int64_t> bad{-1};   // a record BAM cannot hold (the reference's writer rejects it too): the first one is reported, none is written wrong
     int rc = lh_records_visit_(res, in, (int32_t)names.size(), names.data(), w->rec_flags, &nt,
                                [&](int t) { if ((size_t)t >= local.size()) local.resize((size_t)t + 1); local[(size_t)t].assign(w->outs.size(), std::string()); },
                                [&](int t, const LhRec& R) {
+                                   if (R.name_len > 254 || R.cig_len.size() > 65535) { int64_t none = -1; bad.compare_exchange_strong(none, (int64_t)R.name_len << 32 | (int64_t)(R.cig_len.size() & 0xffffffff)); return; }
                                    std::string& bc = local[(size_t)t][0];          // BarcodeSortedBam
                                    const size_t at = bc.size();
                                    const int b = encode(w, R, bc);
                                    local[(size_t)t][(size_t)b].append(bc, at, std::string::npos);   // its position bucket
                                });
     if (rc) return rc;
+    if (bad.load() >= 0) {
+        const std::string m = "lh_bam_append: a record does not fit the BAM format (read name of " + std::to_string(bad.load() >> 32) + " bytes: at most 254; " +
+                              std::to_string(bad.load() & 0xffffffff) + " CIGAR operations: at most 65535); nothing was appended";
+        return lh_set_error_(LH_E_LIMIT, m.c_str());
+    }
     double t1 = now();
     double t2 = now();
     {   // per-file byte strings are joined in block order; the files are independent, so one host thread per file
@@ -293,7 +311,7 @@ extern "C" int lh_bam_append(lh_bam_writer* w, const lh_result* res, const lh_in
     }
     double t3 = now();
     if (!flush(w, false)) { w->failed = true; return lh_set_error_(LH_E_IO, "lh_bam_append: compression or write failed"); }
-    if (timing) fprintf(stderr, "[lh_bam_append] records %.3f s, join %.3f s, compress+write %.3f s (%d threads)\n", t1 - t0, t3 - t2, now() - t3, nt);
+    w->t_records = t1 - t0; w->t_join = t3 - t2; w->t_write = now() - t3;   // lh_bam_timings
     return LH_OK;
 }
 

@@ -225,9 +225,6 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
 #undef EH_MAT
     if (cells) *cells += ncell;
     *overflow = over;
-#ifdef LH_EMU
-    if (getenv("LH_DYN_TRACE")) fprintf(stderr, "dyn qlen=%d h0=%d w=%d cells=%llu over=%d score=%d\n", qlen, h0, w, (unsigned long long)ncell, over, max);
-#endif
     ExtRes r;
     r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
     return r;

@@ -119,15 +119,26 @@ __global__ void __launch_bounds__(256) k_ib_count_ties(const u64* __restrict__ k
     if (mine) atomicAdd(n_ties, mine);
 }
 
-// every group of equal keys, sorted in place by its head's lane: heap sort over the suffixes' text from symbol 32 on
-__global__ void __launch_bounds__(256) k_ib_sort_groups(const u64* __restrict__ W, u64 n, const u64* __restrict__ keys, u64* __restrict__ vals, u64 cnt) {
+// every group of equal keys (suffixes that share their first 32 symbols), sorted by direct comparison of the text from symbol 32 on.
+// Groups of up to LH_IB_LANE_GROUP suffixes are heap-sorted in place by their head's lane.  Larger ones — a real reference has
+// satellite arrays, long exact duplications and fwd / revcomp palindromes whose tie groups hold 10^5 .. 10^6 suffixes sharing
+// kilobases — are only LISTED here and sorted by k_ib_sort_big, one 256-thread block per group (a lane's heap sort of such a group
+// is m log m comparisons of L / 32 dependent reads each, all on one lane).
+#define LH_IB_LANE_GROUP 64
+__global__ void __launch_bounds__(256) k_ib_sort_groups(const u64* __restrict__ W, u64 n, const u64* __restrict__ keys, u64* __restrict__ vals, u64 cnt,
+                                                        u64* __restrict__ big_list, unsigned long long* __restrict__ big_count) {
     for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j + 1 < cnt; j += (u64)gridDim.x * blockDim.x) {
         u64 k = keys[j];
         if ((j > 0 && keys[j - 1] == k) || keys[j + 1] != k) continue;   // not the head of a group of >= 2
         u64 e = j + 2;
-        while (e < cnt && keys[e] == k) ++e;
+        while (e < cnt && e - j <= LH_IB_LANE_GROUP && keys[e] == k) ++e;
         u64* v = vals + j;
         u64 m = e - j;
+        if (m > LH_IB_LANE_GROUP) {   // (its length is found by the block that sorts it)
+            const u64 slot = atomicAdd(big_count, 1ull);
+            big_list[slot] = j;
+            continue;
+        }
         if (m == 2) {
             if (ib_suf_less(W, n, v[1], v[0], 32)) { u64 t = v[0]; v[0] = v[1]; v[1] = t; }
             continue;
@@ -156,6 +167,57 @@ __global__ void __launch_bounds__(256) k_ib_sort_groups(const u64* __restrict__ 
                 root = child;
             }
         }
+    }
+}
+// a listed group, one block per group: runs of 16 by insertion sort (one thread each), then merge passes between vals and tmp (the
+// chunk's spare value buffer) in which every thread produces segments of 32 outputs from their merge-path split.  Suffixes are
+// distinct, so the order is total: no stability question.
+__global__ void __launch_bounds__(256) k_ib_sort_big(const u64* __restrict__ W, u64 n, const u64* __restrict__ keys, u64* __restrict__ vals, u64* __restrict__ tmp, u64 cnt,
+                                                     const u64* __restrict__ big_list, const unsigned long long* __restrict__ big_count) {
+    const u64 n_big = *big_count;
+    for (u64 g = blockIdx.x; g < n_big; g += gridDim.x) {
+        const u64 j = big_list[g], k = keys[j];
+        __shared__ u64 s_m;
+        if (threadIdx.x == 0) { u64 e = j + 1; while (e < cnt && keys[e] == k) ++e; s_m = e - j; }
+        __syncthreads();
+        const u64 m = s_m;
+        u64* src = vals + j;
+        u64* dst = tmp + j;
+        for (u64 r0 = (u64)threadIdx.x * 16; r0 < m; r0 += 256 * 16) {   // runs of 16
+            const u64 r1 = r0 + 16 < m ? r0 + 16 : m;
+            for (u64 i = r0 + 1; i < r1; ++i) {
+                const u64 x = src[i];
+                u64 q = i;
+                while (q > r0 && ib_suf_less(W, n, x, src[q - 1], 32)) { src[q] = src[q - 1]; --q; }
+                src[q] = x;
+            }
+        }
+        __syncthreads();
+        for (u64 R = 16; R < m; R <<= 1) {
+            for (u64 o0 = (u64)threadIdx.x * 32; o0 < m; o0 += 256 * 32) {   // outputs [o0, o0 + 32) of this pass
+                const u64 pb = o0 / (2 * R) * (2 * R);
+                const u64 a0 = pb, a1 = pb + R < m ? pb + R : m, b0 = a1, b1 = pb + 2 * R < m ? pb + 2 * R : m;
+                const u64 na = a1 - a0, nb = b1 - b0, d = o0 - pb;
+                u64 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;   // how many of the first d outputs come from A
+                while (lo < hi) {
+                    const u64 ai = (lo + hi) >> 1;   // A[ai] vs B[d - ai - 1]: A[ai] goes before iff it is smaller
+                    if (ib_suf_less(W, n, src[b0 + (d - ai - 1)], src[a0 + ai], 32)) hi = ai; else lo = ai + 1;
+                }
+                u64 ai = lo, bi = d - lo;
+                const u64 o1 = o0 + 32 < pb + na + nb ? o0 + 32 : pb + na + nb;
+                for (u64 oo = o0; oo < o1; ++oo) {
+                    bool take_a;
+                    if (ai >= na) take_a = false;
+                    else if (bi >= nb) take_a = true;
+                    else take_a = !ib_suf_less(W, n, src[b0 + bi], src[a0 + ai], 32);
+                    dst[oo] = take_a ? src[a0 + ai++] : src[b0 + bi++];
+                }
+            }
+            __syncthreads();
+            u64* t = src; src = dst; dst = t;
+        }
+        if (src != vals + j) for (u64 i = threadIdx.x; i < m; i += 256) vals[j + i] = src[i];
+        __syncthreads();
     }
 }
 

@@ -285,8 +285,7 @@ int lh_records_visit_(const lh_result* res, const lh_ingest_batch* in, int32_t n
     // AppendBam's edits stay inside a pair (an alignment, its mate, their splits), so pairs are independent: ranges of pairs
     // are rendered by several host threads, in order inside a range.
     const int64_t n_pairs = in->batch.n_pairs;
-    int nt = (int)std::thread::hardware_concurrency();
-    if (const char* e = getenv("LH_HOST_THREADS")) nt = atoi(e);
+    int nt = n_threads && *n_threads > 0 ? *n_threads : (int)std::thread::hardware_concurrency();   // the caller's budget (one rank of several per node: cpu_count / world)
     if (nt < 1) nt = 1;
     if ((int64_t)nt > (n_pairs + 255) / 256) nt = (int)((n_pairs + 255) / 256);
     if (nt < 1) nt = 1;

@@ -76,6 +76,31 @@ def test_emu_device_build_with_repeats_and_aligns(emu, oracle):
     helpers.assert_same_result(idx.context(rs.n_pairs).align_barcodes(b), oidx.align_barcodes(b), inference=True)
 
 
+def tandem_genome():
+    """what a real reference holds and an iid one does not: a long tandem repeat (5-mer x 4 kb: tie groups of ~800 suffixes that share up
+    to 4 kb), a long exact duplication, a palindrome (a segment followed by its reverse complement) and a poly-A tract"""
+    rng = np.random.default_rng(21)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+
+    def rnd(n):
+        return rng.integers(0, 4, size=n).astype(np.uint8)
+
+    seg = rnd(3000)
+    pal = rnd(1500)
+    c0 = np.concatenate([rnd(2000), np.tile(rnd(5), 800), rnd(1000), seg, rnd(500), pal, comp[pal[::-1]], rnd(700)])
+    c1 = np.concatenate([rnd(1500), seg, rnd(300), np.zeros(900, dtype=np.uint8), rnd(1200)])
+    return ["t0", "t1"], [c0, c1]
+
+
+def test_emu_device_build_with_large_tie_groups(emu, oracle):
+    """tie groups far beyond what one lane sorts (k_ib_sort_big: a block per group, merge sort through the text): the same suffix array,
+    BWT, LCP array and k-mer tree as the oracle's builder and the text-derived tables, with one chunk and with many"""
+    names, contigs = tandem_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    check_against(emu, oidx, names, contigs)
+    check_against(emu, oidx, names, contigs, build_chunk_log2=12)
+
+
 def test_emu_export_of_a_loaded_index_is_the_file(emu):
     idx = emu.index_load(helpers.PHIX, sb_shift=9)
     got = idx.export(sa_intv=32)
@@ -91,6 +116,8 @@ def test_gpu_device_build_phix_and_repeats(oracle):
     names, contigs, oidx = phix(oracle)
     for opts in ({}, {"build_chunk_log2": 8}):
         check_against(lib, oidx, names, contigs, **opts)
+    names, contigs = tandem_genome()
+    check_against(lib, oracle.index_build_naive(names, contigs), names, contigs)
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
     idx = check_against(lib, oidx, names, contigs, build_chunk_log2=16)

@@ -46,4 +46,4 @@ dt = time.perf_counter() - t0
 print("pairs %d  wall %.2f s = %.3f M pairs/s end to end (stages run one after the other in this tool)" % (n, dt, n / dt / 1e6))
 print("  ingest   %.2f s  %.2f M pairs/s (1 thread)" % (t_in, n / t_in / 1e6))
 print("  align    %.2f s  %.2f M pairs/s (upload + K1..K8 + download)" % (t_gpu, n / t_gpu / 1e6))
-print("  bam      %.2f s  %.2f M pairs/s (%d files, BGZF level %s)" % (t_out, n / t_out / 1e6, len(os.listdir(a.out)), os.environ.get("LH_BAM_LEVEL", "default")))
+print("  bam      %.2f s  %.2f M pairs/s (%d files)" % (t_out, n / t_out / 1e6, len(os.listdir(a.out))))
