@@ -27,7 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")   # HBM-side counters of this workload (tools/pmc_summary.py), per kernel
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")   # HBM-side counters of this workload (tools/pmc_summary.py), per kernel
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -116,6 +116,7 @@ def main():
     opts = lib.opts()
     t0 = time.time()
     first = None
+    keep_reads = []
     n_slots = 0
     for slot, g in enumerate(my_batches):
         if slot and lib.device_memory(local_rank)[0] < (16 << 30):   # leave room for the kernels' scratch: later steps reuse the resident batches in turn
@@ -127,6 +128,8 @@ def main():
         n_slots = slot + 1
         if first is None:
             first = (r, b)
+        if len(keep_reads) < 3:
+            keep_reads.append(r)   # host copies of a few batches: the host-to-host leg streams them through one context
     t_reads_upload = time.time() - t0
 
     def sync_all():
@@ -150,7 +153,13 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     hbm_free, hbm_total = lib.device_memory(local_rank)
+    per_rank = None
     if dist is not None:
+        mine = torch.tensor([elapsed, t_index, t_genome, t_reads_upload], dtype=torch.float64, device="cpu" if share else "cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)   # a straggler (a slow index build, a slow rank) is visible in the line
+        per_rank = [{"rank": i, "pairs_per_s": round(n_pairs * len(my_batches) / float(t[0]), 1), "timed_s": round(float(t[0]), 3), "index_build_s": round(float(t[1]), 2),
+                     "genome_s": round(float(t[2]), 2), "reads_synth+upload_s": round(float(t[3]), 2)} for i, t in enumerate(allr)]
         te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -182,11 +191,18 @@ def main():
             "work_per_step": cnt,
             "setup_s": {"genome": round(t_genome, 2), "index_build_device": round(t_index, 2), "reads_synth+upload(all steps)": round(t_reads_upload, 2)},
         }
-        ctx.close()   # its pools and the resident batches (~70 GB next to the 131 GB index) make room for the informational runs
-        if not a.no_extras and world == 1:   # the informational legs and the CPU baseline: on the single-GPU run only
+        if per_rank:
+            out["per_rank"] = per_rank
+        ctx.close()   # its pools and the resident batches (~70 GB next to the 131 GB index) make room for the other legs
+        if not a.no_extras and world == 1:   # the other legs and the CPU baseline: on the single-GPU run only
+            out["host_to_host"] = host_to_host(lib, idx, keep_reads, n_pairs, opts)
             out.update(extras(lib, idx, first[1], n_pairs, opts, elapsed / max(1, len(my_batches))))
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, idx, pac, first[0])
+        if not a.no_extras and world == 1 and not a.repeats:
+            idx.close()   # the repeat-rich leg builds its own index: the two do not fit HBM side by side
+            del pac
+            out["repeats"] = repeats_leg(lib, a, local_rank, opts)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -217,6 +233,9 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
             pmc = json.load(open(PMC_FILE))
         except Exception:
             pmc = None
+    stale = pmc_is_stale(pmc)
+    if stale:   # counters measured before the kernels last changed describe other code: no traffic figures from them
+        pmc = None
     r = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     ms = avg[dom]
     if dom in k1:
@@ -247,6 +266,8 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
                 r["request_rate_ceiling_G"] = pmc["random_read_ceiling_Gaccess_per_s"]
                 r["request_rate_frac"] = round(r["l2_misses_per_s_G"] / r["request_rate_ceiling_G"], 4)   # of what independent random 32-B reads reach
     r["traffic"] = traffic
+    if stale:
+        r["traffic_note"] = stale
     # the whole K1 stage in the reference's bookkeeping (informational)
     k1_ms = sum(avg.get(k, 0.0) for k in k1)
     if k1_ms > 0:
@@ -255,6 +276,125 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
                          "executed_GBps": round(share * 64.0 * (cnt["n_ext_exec_p1"] + cnt["n_ext_exec_p2"] + cnt["n_ext_exec_p3"]) / (k1_ms * 1e-3) / 1e9, 1),
                          "reference_work_equiv_GBps": round(share * 64.0 * cnt["n_ext"] / (k1_ms * 1e-3) / 1e9, 1)}
     return r
+
+
+def pmc_is_stale(pmc):
+    """the committed PMC file names the commit it was measured at; if a kernel source changed after that commit the file describes other
+    code.  Returns a reason (str) or None.  (No git on the GPU box: then the file's own list of kernel-source hashes is compared.)"""
+    if not pmc:
+        return None
+    import hashlib
+    cs = os.path.join(ROOT, "lariat_amd", "csrc")
+    now = {f: hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(cs)) if f.startswith("k_") and f.endswith(".h")}
+    was = pmc.get("kernel_sources")
+    if not was:
+        return "profiles/%s does not list the kernel sources it was measured with: traffic not reported" % os.path.basename(PMC_FILE)
+    changed = sorted(f for f in set(now) | set(was) if now.get(f) != was.get(f))
+    if changed:
+        return "profiles/%s (commit %s) is older than %s: traffic not reported until it is re-measured (tools/profile_all.sh)" % (os.path.basename(PMC_FILE), pmc.get("commit"), ", ".join(changed))
+    return None
+
+
+def host_to_host(lib, idx, reads_list, n_pairs, opts):
+    """what a host with ONE context sees: batches arrive as host arrays and leave as host arrays.  A second host thread stages batch k + 1
+    (lh_batch_stage_slot, upload stream) while the main thread aligns batch k, whose result is collected after batch k + 1's kernels
+    (lh_result_download_begin / _end, copy stream) — the double buffering of lariat.go:333 / bamwriter.go:188."""
+    import threading
+    from lariat_amd import capi
+    ctx = idx.context(n_pairs)
+    # the batches in page-locked host memory (lh_host_alloc), as a host's FASTQ reader would leave them: uploads are then DMA transfers
+    batches = [capi.Batch.from_arrays(lib.pinned_copy(r["seq"]), lib.pinned_copy(r["seq_off"]), lib.pinned_copy(r["bc_pair_off"]), lib.pinned_copy(r["name_seed"])) for r in reads_list]
+    nb = len(batches)
+    rounds = 3 * nb
+    ctx.upload_slot(1, batches[0])
+    ctx.select(1)
+    ctx.align_resident(opts)            # warm-up (pools sized, pinned block allocated)
+    ctx.download_raw()
+    t0 = time.perf_counter()
+    ctx.upload_slot(1, batches[0])
+    err = []
+    phases = {}
+    kern = {}
+    for k in range(rounds):
+        ctx.select(1 + k % 2)
+        th = None
+        if k + 1 < rounds:
+            def stage(kk=k + 1):
+                try:
+                    ts = time.perf_counter()
+                    ctx.stage_slot(1 + kk % 2, batches[kk % nb])
+                    kern.setdefault("(stage_slot, host thread 2)", []).append((time.perf_counter() - ts) * 1e3)
+                except Exception as e:   # noqa
+                    err.append(e)
+            th = threading.Thread(target=stage)
+            th.start()
+        ta = time.perf_counter()
+        ctx.align_resident(opts)
+        tb = time.perf_counter()
+        for name, ms in ctx.timings():
+            kern.setdefault(name, []).append(ms)
+        if k:
+            ctx.download_end(raw=True)
+        tc = time.perf_counter()
+        ctx.download_begin()
+        td = time.perf_counter()
+        if th:
+            th.join()
+        te = time.perf_counter()
+        for name, v in (("align", tb - ta), ("download_end", tc - tb), ("download_begin", td - tc), ("wait_for_stage", te - td)):
+            phases[name] = phases.get(name, 0.0) + v
+        if err:
+            raise err[0]
+    ctx.download_end(raw=True)
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"pairs_per_s": round(rounds * n_pairs / dt, 1), "batches": rounds, "ms_per_batch": round(dt / rounds * 1e3, 2),
+            "main_thread_ms_per_batch": {k: round(v / rounds * 1e3, 2) for k, v in phases.items()},
+            "kernel_ms_under_transfers": {k: round(sum(v) / len(v), 2) for k, v in kern.items()},
+            "per_round_ms": {k: [round(x, 1) for x in v] for k, v in kern.items() if max(v) > 2 * min(v) + 0.5},
+            "how": "one context; a second host thread stages batch k+1 (lh_batch_stage_slot) under batch k's kernels; batch k's result is copied out under batch k+1's (lh_result_download_begin/_end)"}
+
+
+def repeats_leg(lib, a, local_rank, opts, steps=4):
+    """configs[4]'s regime on this GPU, in the default run: a second hg38-scale genome with planted segmental duplications (1,500 x 20 kb at
+    99 %, 300 identical), 40 repeat families and 40 ALT contigs (1 Mb copies at 99.7 %, is_alt set), every read drawn from on and around
+    them.  Its own index (the headline index has been freed by now)."""
+    from lariat_amd import capi, workload
+    t0 = time.time()
+    ctg = workload.hg38_like_contigs(int(a.genome_mb * 1e6 * 0.987))
+    l_pac = sum(c[1] for c in ctg)
+    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED + 4)
+    dups = workload.plant_segdups(pac, ctg, 1500, 20000, 0.99, seed=41, n_families=40, family_len=320, family_copies=60)
+    dups += workload.plant_segdups(pac, ctg, 300, 20000, 1.0, seed=42)
+    pac, l_pac, ctg_all, alt_flags, alts = workload.add_alt_contigs(pac, ctg, 40, min(1000000, l_pac // 200 // 4 * 4), 0.997, seed=43)
+    win = workload.repeat_windows(ctg_all, dups[:1500] + dups[-300:], flank=50000) + workload.repeat_windows(ctg_all, alts, flank=20000)
+    idx = lib.index_build_device(pac, l_pac, ctg_all, device=local_rank)
+    idx.set_alt(alt_flags)
+    n_pairs = a.barcodes * a.pairs_per_barcode
+    ctx = idx.context(n_pairs)
+    for slot in range(steps):
+        r = lib.synth_reads(pac, l_pac, win, seed=workload.READS_SEED + 400 + slot, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode)
+        ctx.upload_slot(slot, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
+    t_setup = time.time() - t0
+    ctx.select(0)
+    ctx.align_resident(opts)   # warm-up: pools grow to this workload's seed counts
+    kern = {}
+    t0 = time.perf_counter()
+    for s in range(steps):
+        ctx.select(s)
+        ctx.align_resident(opts)
+        for name, ms in ctx.timings():
+            kern.setdefault(name, []).append(ms)
+    dt = time.perf_counter() - t0
+    res = ctx.download()
+    out = {"value": round(steps * n_pairs / dt, 1), "unit": "read-pairs/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+           "kernel_ms": {k: round(sum(v) / len(v), 3) for k, v in kern.items()},
+           "candidates_per_read": round(res.n_cand / res.n_reads, 2), "setup_s": round(t_setup, 1),
+           "workload": "configs[4]-like on one GPU: %d Mb genome, 1,800 planted 20-kb segmental duplications, 40 repeat families, 40 ALT contigs (is_alt), reads drawn from on and around them, %d steps x %d pairs"
+                       % (l_pac // 1000000, steps, n_pairs)}
+    ctx.close()
+    idx.close()
+    return out
 
 
 def extras(lib, idx, batch, n_pairs, opts, step_s):

@@ -23,6 +23,7 @@
 #ifndef LARIAT_HIP_H
 #define LARIAT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -292,6 +293,21 @@ int lh_align_resident(lh_context* ctx, const lh_opts* opts);            /* enque
  * its timed region in HBM this way.  A slot's batch must fit the context's capacity like any other. */
 int lh_batch_upload_slot(lh_context* ctx, int32_t slot, const lh_batch* batch);
 int lh_batch_select(lh_context* ctx, int32_t slot);
+/* The download in two steps, for a host that keeps ONE context busy: lh_result_download_begin checks the batch (the errors of
+ * lh_result_download are reported here), packs its variable-length arrays and enqueues the device-to-host copies on the context's copy
+ * stream; lh_result_download_end waits for them and hands out the result.  Between the two the host may upload / select / align the NEXT
+ * batch: its kernels run while the copies do (lh_align_resident waits for them only before it first writes a result array), which is the
+ * double buffering of the reference's work-unit channels (inference/lariat.go:333, bamwriter.go:188).  One download in flight per context. */
+int lh_result_download_begin(lh_context* ctx);
+int lh_result_download_end(lh_context* ctx, lh_result** out);
+/* lh_batch_upload_slot without selecting the slot, on the context's upload stream: may be called from a second host thread while
+ * lh_align_resident runs on another (selected) slot.  One staging call at a time; contexts with one lane. */
+int lh_batch_stage_slot(lh_context* ctx, int32_t slot, const lh_batch* batch);
+/* page-locked host memory for the arrays of a batch: uploads from it are asynchronous DMA transfers that run beside
+ * the kernels of another batch; from ordinary memory they are staged by the calling thread and slow down under a busy device.  A host fills
+ * such buffers straight from its FASTQ reader. */
+void* lh_host_alloc(size_t bytes);
+void lh_host_free(void* p);
 int lh_result_download(lh_context* ctx, lh_result** out);
 void lh_result_free(lh_result* r);
 

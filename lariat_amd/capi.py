@@ -330,6 +330,34 @@ class Library:
         if rc != LH_OK:
             raise LhError(rc, self.L.lh_last_error().decode(errors="replace"))
 
+    def pinned_copy(self, arr):
+        """a copy of a numpy array in page-locked host memory (lh_host_alloc); freed with the returned array's `_lh_pin` holder"""
+        a = np.ascontiguousarray(arr)
+        self.L.lh_host_alloc.argtypes = [C.c_size_t]
+        self.L.lh_host_alloc.restype = C.c_void_p
+        self.L.lh_host_free.argtypes = [C.c_void_p]
+        p = self.L.lh_host_alloc(max(1, a.nbytes))
+        if not p:
+            raise LhError(5, self.L.lh_last_error().decode(errors="replace"))
+        lib = self
+
+        class _Pin:
+            def __init__(self, ptr):
+                self.ptr = ptr
+
+            def __del__(self):
+                if self.ptr:
+                    lib.L.lh_host_free(self.ptr)
+                    self.ptr = None
+
+        hold = _Pin(p)
+        buf = (C.c_uint8 * max(1, a.nbytes)).from_address(p)
+        out = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+        out[...] = a
+        self._pins = getattr(self, "_pins", [])
+        self._pins.append((out, hold))   # (kept until the library object goes away: the array must not outlive its memory)
+        return out
+
     def device_count(self):
         return self.L.lh_device_count()
 
@@ -643,6 +671,23 @@ class Context:
         self.lib.L.lh_result_free(res)
         return out
 
+    def stage_slot(self, slot, batch):
+        """lh_batch_stage_slot: upload into a slot that is not selected, on the upload stream (from a second host thread)"""
+        self.lib.L.lh_batch_stage_slot.argtypes = [C.c_void_p, C.c_int32, C.POINTER(LhBatch)]
+        self.lib.check(self.lib.L.lh_batch_stage_slot(self.h, int(slot), C.byref(batch.c)))
+
+    def download_begin(self):
+        self.lib.L.lh_result_download_begin.argtypes = [C.c_void_p]
+        self.lib.check(self.lib.L.lh_result_download_begin(self.h))
+
+    def download_end(self, raw=False):
+        self.lib.L.lh_result_download_end.argtypes = [C.c_void_p, C.POINTER(C.POINTER(LhResult))]
+        res = C.POINTER(LhResult)()
+        self.lib.check(self.lib.L.lh_result_download_end(self.h, C.byref(res)))
+        out = (int(res.contents.n_reads), int(res.contents.n_cand)) if raw else Result(res.contents)
+        self.lib.L.lh_result_free(res)
+        return out
+
     def download_raw(self):
         """lh_result_download + lh_result_free without the numpy copies of `Result`: what a cgo / C host pays, since it reads
         the library-owned SoA block in place.  Returns (n_reads, n_cand)."""
@@ -805,5 +850,5 @@ EXPORTED_SYMBOLS = [
     "lh_records_text", "lh_records_text_ex", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_set_flags", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_random_read", "lh_diag_go_rand",
-    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt", "lh_bam_set_level", "lh_bam_timings",
+    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt", "lh_bam_set_level", "lh_bam_timings", "lh_result_download_begin", "lh_result_download_end", "lh_batch_stage_slot", "lh_host_alloc", "lh_host_free",
 ]

@@ -446,6 +446,8 @@ __device__ __forceinline__ DiagScan dev_diag_scan(const DIndex& ix, const DOpts&
     d.done = 1;
     return d;
 }
+// one 64-bit value into page-locked host memory the device can write: a read-back that does not queue behind the bulk transfers of the copy engines
+__global__ void k_peek_i64(const i64* __restrict__ src, i64* __restrict__ dst_host) { *dst_host = *src; }
 // the batch's reads as a 4-bit stream (base i of the batch buffer at symbol i; non-bases = 4), two words of padding in front
 __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ seq, i64 n_bases, uint32_t* __restrict__ q4) {
     const i64 nw = (n_bases + 7) / 8;   // (the batch buffer is 8-aligned and padded past n_bases)

@@ -173,6 +173,9 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return 0; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return 0; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+#define hipStreamNonBlocking 1
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return 0; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }

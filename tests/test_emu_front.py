@@ -285,3 +285,32 @@ def test_emu_second_chance_paths(oracle):
     ctx = idx.context(rs.n_pairs)
     helpers.assert_same_dump(ctx.stage_dump(b), od, helpers.DUMP_FRONT + helpers.DUMP_REGS)
     helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b), inference=True)
+
+
+def test_emu_overlapped_download_and_staged_upload(emu, oracle):
+    """one context, three batches: batch k's result is collected (lh_result_download_end) after batch k + 1 has been aligned, and batch
+    k + 1 was staged (lh_batch_stage_slot) while batch k was the selected one — each result equals the oracle's for its own batch"""
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    sets = [helpers.small_reads(names, contigs, n_barcodes=2, pairs=16 + 6 * k, junk=0.05, seed=50 + k) for k in range(3)]
+    batches = [helpers.batch_of(rs) for rs in sets]
+    ctx = idx.context(max(rs.n_pairs for rs in sets))
+    opts = emu.opts()
+    ctx.upload_slot(1, batches[0])
+    got = []
+    for k in range(3):
+        ctx.select(1 + k % 2)
+        if k + 1 < 3:
+            ctx.stage_slot(1 + (k + 1) % 2, batches[k + 1])   # (a second host thread would do this while the align below runs)
+        ctx.align_resident(opts)
+        if k:
+            got.append(ctx.download_end())                     # batch k - 1: its copies ran under this batch's kernels
+        ctx.download_begin()
+    got.append(ctx.download_end())
+    with pytest.raises(capi.LhError):
+        ctx.download_end()                                     # nothing in flight
+    for k in range(3):
+        helpers.assert_same_result(got[k], oidx.align_barcodes(batches[k]), inference=True)
+    with pytest.raises(capi.LhError):
+        ctx.stage_slot(1 + 2 % 2, batches[0])                  # the selected slot cannot be staged into

@@ -151,3 +151,33 @@ def test_low_complexity_reads_are_never_refused(lib, oracle):
     assert np.diff(od.seed_off).max() > 2000 and np.diff(od.chain_off).max() > 500
     helpers.assert_same_dump(ctx.stage_dump(b), od, helpers.DUMP_FRONT + helpers.DUMP_REGS)
     helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b, threads=8), inference=True)
+
+
+def test_overlapped_download_and_staged_upload(lib, oracle):
+    """one context, four batches, a staging thread: batch k + 1 is uploaded (lh_batch_stage_slot) while batch k is aligned, batch k's result is
+    collected (lh_result_download_end) after batch k + 1's kernels ran beside its copies — each result equals the oracle's for its own batch"""
+    import threading
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    sets = [helpers.small_reads(names, contigs, n_barcodes=6, pairs=60 + 20 * k, junk=0.05, seed=60 + k) for k in range(4)]
+    batches = [helpers.batch_of(rs) for rs in sets]
+    ctx = idx.context(max(rs.n_pairs for rs in sets))
+    opts = lib.opts()
+    ctx.upload_slot(1, batches[0])
+    got = []
+    for k in range(4):
+        ctx.select(1 + k % 2)
+        th = None
+        if k + 1 < 4:
+            th = threading.Thread(target=lambda kk=k + 1: ctx.stage_slot(1 + kk % 2, batches[kk]))
+            th.start()
+        ctx.align_resident(opts)
+        if k:
+            got.append(ctx.download_end())
+        ctx.download_begin()
+        if th:
+            th.join()
+    got.append(ctx.download_end())
+    for k in range(4):
+        helpers.assert_same_result(got[k], oidx.align_barcodes(batches[k], threads=8), inference=True)

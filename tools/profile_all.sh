@@ -1,8 +1,8 @@
 #!/bin/bash
-# kernel-trace statistics and the three PMC passes of bench.py on the GPU box (usage: bash tools/profile_all.sh <commit>); writes gpurun_out/prof_e/
+# kernel-trace statistics and the three PMC passes of bench.py on the GPU box (usage: bash tools/profile_all.sh <commit>); writes gpurun_out/prof_r03/
 set -x
 REPO=$PWD
-OUT=$REPO/gpurun_out/prof_e
+OUT=$REPO/gpurun_out/prof_r03
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
