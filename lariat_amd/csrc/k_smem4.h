@@ -102,18 +102,105 @@ __device__ __forceinline__ PEnt pe_pack(u64 x0, u64 x1, u64 x2, int info) {
 #ifndef LH_SMEM4_WAVES
 #define LH_SMEM4_WAVES 4   // waves per SIMD the register budget is sized for
 #endif
+// THE FIRST CALL OF EVERY READ, IN LOCKSTEP (new in r03).  Measured (profiles/r03_*): pass 1 is bound by instruction issue — every turn of
+// the state machine runs the code of every state some lane of the wave is in (16 of 64 lanes active) — and most of its turns belong to the
+// read's first bwt_smem1a call, which is the same short program for every read: the k-mer tree's entry for the first ktree_levels bases,
+// a few occurrence-table steps until one occurrence is left, the suffix array, the comparison with the text.  k_smem_first runs exactly
+// that, one THREAD per read, all threads of a wave in the same loop at the same time; nothing is pushed to a forward list before the
+// interval's end reaches position LH_BLOOM_K (the sweep filter's rule for a call from position 0: see START_SMEM1), and with nothing
+// before position 0 the sweep emits the longest entry, so the call's result is [0, b) at one occurrence.  A read this does not settle
+// (a base that differs from the text at b < len; more than one occurrence left at LH_BLOOM_K bases; non-bases early on; no dense suffix
+// array or no sweep filter) is LISTED for the state machine, which takes it up where this kernel left it (K1Resume).
+struct K1Resume { i64 Pk; int32_t x, pk_len; };   // the general kernel starts its calls at x; Pk: text position of read base 0 at the locus of a unique match of pk_len bases (-1: none)
+__global__ void __launch_bounds__(256) k_smem_first(DIndex ix, DOpts o, int n_reads, const uint32_t* __restrict__ q4, const i64* __restrict__ seq_off, DIntv* __restrict__ intv_out,
+                                                     int32_t* __restrict__ n_intv, int32_t* __restrict__ status, K1Resume* __restrict__ resume, int32_t* __restrict__ todo,
+                                                     int32_t* __restrict__ todo_count, DCounters* __restrict__ ctr) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    const PEnt* const kt = (const PEnt*)ix.ktree;
+    const int ktl = kt ? ix.ktree_levels : 0;
+    const bool can = ix.isa && ix.tn && q4 && ix.bloom1 && ktl >= 2 && ktl <= 16 && ktl < LH_BLOOM_K && o.min_seed_len >= LH_BLOOM_K;
+    unsigned n_ext = 0, n_exec = 0, n_kt = 0;
+    int listed = 0;
+    if (r < n_reads) {
+        const i64 off = seq_off[r];
+        const int len = (int)(seq_off[r + 1] - off);
+        K1Resume rs; rs.Pk = -1; rs.x = 0; rs.pk_len = 0;
+        int on = -1;   // -1: not settled here (the general kernel makes every call)
+        if (can && len >= o.min_seed_len && len <= LH_MAXLEN) {
+            const uint32_t w0 = dev_nib8(q4, off), w1 = dev_nib8(q4, off + 8);
+            const uint32_t a = w0 & 0x44444444u, b = w1 & 0x44444444u;
+            const int valid = a ? (__ffs((int)a) - 1) >> 2 : 8 + (b ? (__ffs((int)b) - 1) >> 2 : 8);
+            if (valid >= ktl) {   // the forward jump of START_SMEM1 at x = 0: J = min(tree depth, valid bases, LH_BLOOM_K) = the tree's depth
+                uint32_t ca = w0 & 0x33333333u, cb = w1 & 0x33333333u;
+                ca = (ca | ca >> 2) & 0x0f0f0f0fu; ca = (ca | ca >> 4) & 0x00ff00ffu; ca = (ca | ca >> 8) & 0xffffu;
+                cb = (cb | cb >> 2) & 0x0f0f0f0fu; cb = (cb | cb >> 4) & 0x00ff00ffu; cb = (cb | cb >> 8) & 0xffffu;
+                const uint32_t code = (ca | cb << 16) & (ktl >= 16 ? 0xffffffffu : (1u << (2 * ktl)) - 1u);
+                const PEnt te = kt[(((1ull << (2 * ktl)) - 4) / 3) + code];
+                DIntv c; c.x0 = PE_X0(te); c.x1 = PE_X1(te); c.x2 = PE_X2(te); c.info = 0;
+                unsigned e1 = (unsigned)(ktl - 1), e2 = 0;
+                int i = ktl, state = c.x2 >= 1 ? 1 : 0;   // 0: give up, 1: walking, 2: the match ended with several occurrences left, 3: one occurrence left
+                while (state == 1 && c.x2 > 1) {
+                    if (i >= len || i >= LH_BLOOM_K) { state = 0; break; }   // the list closes at the read's end, or entries may be pushed from here on: the state machine's business
+                    const int bq = (int)((dev_nib8(q4, off + i)) & 0xf);
+                    if (bq > 3) { state = 0; break; }
+                    const DIntv ok = dev_extend_c(ix, c, 3 - bq, 0);
+                    ++e1; ++e2;
+                    if (ok.x2 < 1) { state = 2; break; }   // [0, i) is the whole list and shorter than a seed: the call yields nothing and returns i
+                    c = ok; ++i;
+                }
+                if (state == 1 && c.x2 == 1) state = 3;
+                if (state == 2) { on = 0; rs.x = i; n_ext = e1; n_exec = e2; n_kt = 1; }
+                if (state == 3) {   // the unique run of the state machine (S4_FRUN_*), start to end in one loop
+                    const i64 P = (i64)ix.sa[c.x0];
+                    int bnd = len;
+                    for (int k = i; k < len; k += 8) {
+                        const uint32_t qw = dev_nib8(q4, off + k), tw = dev_nib8(ix.tn, P + k);
+                        uint32_t x = qw ^ tw;
+                        if (len - k < 8) x &= (1u << (4 * (len - k))) - 1u;
+                        if (x) { bnd = k + ((__ffs((int)x) - 1) >> 2); break; }
+                    }
+                    e1 += (unsigned)(bnd - i);
+                    if (bnd < len && (int)(dev_nib8(q4, off + bnd) & 0xf) <= 3) ++e1;   // the bwt_extend that returned an empty interval
+                    on = 0;
+                    if (bnd >= o.min_seed_len) {
+                        DIntv m; m.x0 = LH_POSF | (u64)P; m.x1 = 0; m.x2 = 1; m.info = (u64)(uint32_t)bnd;
+                        intv_out[(size_t)r * LH_MAX_INTV] = m;
+                        on = 1;
+                    }
+                    rs.x = bnd; rs.Pk = P; rs.pk_len = bnd;
+                    n_ext = e1; n_exec = e2; n_kt = 1;
+                }
+            }
+        }
+        if (on >= 0) n_intv[r] = on;
+        if (on >= 0 && rs.x >= len) status[r] = 0;   // the read is finished: pass 1 of the state machine does not see it
+        else { resume[r] = rs; listed = 1; }
+    }
+    const u64 lm = __ballot(listed);
+    if (lm) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(todo_count, (int32_t)__popcll(lm));
+        basep = wave_readlane(basep, 0);
+        if (listed) todo[basep + lanes_below(lm, lane)] = r;
+    }
+    if (ctr) {
+        unsigned t1 = (unsigned)wave_sum_i32((int)n_ext), t2 = (unsigned)wave_sum_i32((int)n_exec), t3 = (unsigned)wave_sum_i32((int)n_kt);
+        if (lane == 0 && t1) { atomicAdd(&LH_CTR(ctr)->n_ext, (u64)t1); atomicAdd(&LH_CTR(ctr)->n_ext_exec[0], (u64)t2); atomicAdd(&LH_CTR(ctr)->n_ktree[0], (u64)t3); }
+    }
+}
+
 // PASS 1: all SMEMs of the read (bwt_smem1a with min_intv 1 from every position the previous call returned).  PASS 2: re-seeding inside
 // the long SMEMs pass 1 left (recognised from the stored intervals).  PASS 3: bwt_seed_strategy1, appended to the intervals the earlier
 // launches left (it depends on the read alone, and the intervals are sorted afterwards).  Each launch carries only its own states:
 // fewer instructions per turn, fewer registers.
 // BIG: the second chance of the reads whose intervals outgrew their LH_MAX_INTV regular slots (listed by k_big_collect): the same
 // passes again, over the list, into slab slots of LH_BIG_INTV intervals (BWA's interval vector grows; no read is refused for it).
-struct K1Big { const int32_t* list; const int32_t* count; const int32_t* slot; DIntv* slab; };   // slot[r]: the read's big-slab slot, -1: none; slab: 2 x LH_BIG_INTV per slot (unsorted | sorted)
+struct K1Big { const int32_t* list; const int32_t* count; const int32_t* slot; DIntv* slab; const K1Resume* resume; };   // slot[r]: the read's big-slab slot, -1: none; slab: 2 x LH_BIG_INTV per slot (unsorted | sorted); !BIG pass 1: list / count / resume = the reads k_smem_first left, and where
 template <int PASS, bool BIG>
 __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pass(DIndex ix, DOpts o, int n_reads_all, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
                                                int32_t* __restrict__ next_read, DCounters* __restrict__ ctr, K1Big big) {
-    const int n_reads = BIG ? *big.count : n_reads_all;
+    const int n_reads = (BIG || big.list) ? *big.count : n_reads_all;
     constexpr int ICAP = BIG ? LH_BIG_INTV : LH_MAX_INTV;
     __shared__ uint32_t qn[32 * 64];
     constexpr bool DO1 = PASS == 1, DO2 = PASS == 2, DO12 = DO1 || DO2, DO3 = PASS == 3, P3T = PASS == 3;
@@ -395,7 +482,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                 int idx = chunk_next + lanes_below(need, lane);
                 rr = idx < chunk_end ? idx : newbase + (idx - chunk_end);
                 if (rr >= n_reads) st = S4_DONE;
-                else { if (BIG) rr = big.list[rr]; off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
+                else { if (BIG || big.list) rr = big.list[rr]; off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
             }
             if (chunk_next + cnt > chunk_end) { chunk_next = newbase + (chunk_next + cnt - chunk_end); chunk_end = newbase + 64; }
             else chunk_next += cnt;
@@ -433,6 +520,13 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                 if (!DO1) { on = n_intv[r]; rst |= status[r]; }   // continue behind the intervals of the earlier passes
                 if (len >= o.min_seed_len) { x = 0; st = DO1 ? S4_P1_SCAN : DO2 ? S4_P2_NEXT : S4_P3_SCAN; }
                 else st = S4_READ_DONE;
+                if (DO1 && !BIG && big.resume) {   // k_smem_first made the read's first call: its interval (if any) is stored, the calls go on from x
+                    const K1Resume rs = big.resume[r];
+                    if (rs.x > 0 && st == S4_P1_SCAN) {
+                        x = rs.x; on = n_intv[r]; SET_X_PREV(0); SET_BT_SKIP(rs.x);
+                        if (rs.Pk >= 0) { Pk = rs.Pk; rflags |= RF_PK | (rs.pk_len & 0xff) << 8; }
+                    }
+                }
                 if (P3TEXT && st == S4_P3_SCAN) {   // the two longest unique SMEMs among the read's intervals
                     uspan = 0;
                     for (int k = 0; k < on; ++k) {
@@ -917,6 +1011,113 @@ __device__ __forceinline__ int dev_seed_count(const DOpts& o, u64 s) {
     u64 c = (s + step - 1) / step;
     return (int)(c < (u64)o.max_occ ? c : (u64)o.max_occ);
 }
+// PASS 3 IN LOCKSTEP, one thread per read (new in r03).  bwt_seed_strategy1 is a forward-only loop — no interval lists, no sweeps — so
+// it needs no state machine: every thread walks its own read, the threads of a wave in the same short loop.  Same shortcuts as the
+// pass-3 state machine (k_smem_pass<3>): a walk that starts inside one of the read's unique SMEMs is one PLCP byte (P3TEXT), any other
+// takes its first bases from the k-mer tree table and goes on through the occurrence table.  Measured: 0.1 G wave-instructions at
+// ~40 active lanes for what cost the state machine 1.2 G at 24.
+__global__ void __launch_bounds__(256) k_smem_p3_lock(DIndex ix, DOpts o, int n_reads, const uint32_t* __restrict__ q4, const i64* __restrict__ seq_off, DIntv* __restrict__ intv_out,
+                                                       int32_t* __restrict__ n_intv, int32_t* __restrict__ status, DCounters* __restrict__ ctr) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    const PEnt* const kt = (const PEnt*)ix.ktree;
+    const int ktl = kt ? ix.ktree_levels : 0;
+    const int Lw = o.min_seed_len + 1;
+    const bool text_ok = ix.isa != nullptr && ix.plcp != nullptr && o.max_mem_intv > 1;
+    unsigned n_ext = 0, n_exec = 0, n_kt = 0;
+    if (r < n_reads) {
+        const i64 off = seq_off[r];
+        int len = (int)(seq_off[r + 1] - off);
+        int rst = status[r], on = n_intv[r], ovf = 0;
+        if (len > LH_MAXLEN) len = 0;
+        DIntv* out = intv_out + (size_t)r * LH_MAX_INTV;
+#define QN(i_) ((int)(dev_nib8(q4, off + (i_)) & 0xf))
+        if (len >= o.min_seed_len && o.max_mem_intv > 0) {
+            // the read's two longest unique SMEMs [us, ue) and their text positions (pass 1 stored them by position; a row is one suffix-array read)
+            int us0 = 0, ue0 = 0, us1 = 0, ue1 = 0;
+            u64 up0 = 0, up1 = 0;
+            if (text_ok)
+                for (int k = 0; k < on; ++k) {
+                    const DIntv p = out[k];
+                    const int ps = (int)(p.info >> 32), pe = (int)(uint32_t)p.info;
+                    if (p.x2 != 1 || pe - ps < Lw) continue;
+                    if (pe - ps > ue0 - us0) { us1 = us0; ue1 = ue0; up1 = up0; us0 = ps; ue0 = pe; up0 = p.x0; }
+                    else if (pe - ps > ue1 - us1) { us1 = ps; ue1 = pe; up1 = p.x0; }
+                }
+            if (ue0 > us0) up0 = (up0 & LH_POSF) ? up0 & ~LH_POSF : ix.sa[up0];
+            if (ue1 > us1) up1 = (up1 & LH_POSF) ? up1 & ~LH_POSF : ix.sa[up1];
+            int x = 0, notext = 0;
+            while (x < len) {
+                if (QN(x) > 3) { ++x; continue; }
+                const int in0 = x >= us0 && x + Lw <= ue0, in1 = x >= us1 && x + Lw <= ue1;
+                if (text_ok && !notext && (in0 || in1)) {   // by text: unique iff the suffix there shares fewer than Lw bases with every other one
+                    const i64 tp = in0 ? (i64)up0 + (x - us0) : (i64)up1 + (x - us1);
+                    if ((int)ix.plcp[tp] < Lw) {
+                        if (on >= LH_MAX_INTV) ovf = 1;
+                        else { DIntv m; m.x0 = LH_POSF | (u64)tp; m.x1 = 0; m.x2 = 1; m.info = (u64)x << 32 | (u64)(x + Lw); out[on++] = m; }
+                        n_ext += (unsigned)(Lw - 1);
+                        x += Lw;
+                        continue;
+                    }
+                    notext = 1;   // it occurs again: the walk as written, from x
+                }
+                notext = 0;
+                // bwt_seed_strategy1 from x
+                DIntv c = dev_set_intv(ix, QN(x));
+                int i = x + 1;
+                uint32_t fcode = (uint32_t)QN(x);
+                if (ktl > 1 && x + ktl <= len && o.min_seed_len >= ktl) {   // the walk's first ktl bases from the tree's deepest level (none of those steps can end it)
+                    uint32_t w0 = dev_nib8(q4, off + x), w1 = dev_nib8(q4, off + x + 8);
+                    uint32_t m0 = w0, m1 = w1;
+                    if (ktl < 8) { m0 &= (1u << (4 * ktl)) - 1u; m1 = 0; }
+                    else if (ktl < 16) m1 &= (1u << (4 * (ktl - 8))) - 1u;
+                    if (!((m0 | m1) & 0x44444444u)) {
+                        uint32_t ca = w0 & 0x33333333u, cb = w1 & 0x33333333u;
+                        ca = (ca | ca >> 2) & 0x0f0f0f0fu; ca = (ca | ca >> 4) & 0x00ff00ffu; ca = (ca | ca >> 8) & 0xffffu;
+                        cb = (cb | cb >> 2) & 0x0f0f0f0fu; cb = (cb | cb >> 4) & 0x00ff00ffu; cb = (cb | cb >> 8) & 0xffffu;
+                        const uint32_t code = (ca | cb << 16) & (ktl >= 16 ? 0xffffffffu : (1u << (2 * ktl)) - 1u);
+                        const PEnt te = kt[(((1ull << (2 * ktl)) - 4) / 3) + code];
+                        c.x0 = PE_X0(te); c.x1 = PE_X1(te); c.x2 = PE_X2(te);
+                        n_ext += (unsigned)(ktl - 1);
+                        i = x + ktl;
+                    }
+                }
+                int nx = len;   // where the next walk starts
+                for (; i < len; ++i) {
+                    const int b = QN(i);
+                    if (b > 3) { nx = i + 1; break; }
+                    DIntv ok;
+                    const int lnew = i + 1 - x;
+                    if (lnew <= ktl) {   // a short match: its interval is the tree's entry
+                        fcode |= (uint32_t)b << (2 * (lnew - 1));
+                        const PEnt te = kt[(((1ull << (2 * lnew)) - 4) / 3) + fcode];
+                        ok.x0 = PE_X0(te); ok.x1 = PE_X1(te); ok.x2 = PE_X2(te); ok.info = 0;
+                        ++n_kt;
+                    } else { ok = dev_extend_c(ix, c, 3 - b, 0); ++n_exec; }
+                    ++n_ext;
+                    if (ok.x2 < (u64)o.max_mem_intv && i - x >= o.min_seed_len) {
+                        if (ok.x2 > 0) {
+                            if (on >= LH_MAX_INTV) ovf = 1;
+                            else { ok.info = (u64)x << 32 | (u64)(i + 1); out[on++] = ok; }
+                        }
+                        nx = i + 1;
+                        break;
+                    }
+                    c = ok;
+                }
+                x = nx;
+            }
+        }
+#undef QN
+        if (ovf) rst |= LH_ST_INTV_OVERFLOW;
+        n_intv[r] = on;
+        status[r] = rst;
+    }
+    if (ctr) {
+        unsigned t1 = (unsigned)wave_sum_i32((int)n_ext), t2 = (unsigned)wave_sum_i32((int)n_exec), t3 = (unsigned)wave_sum_i32((int)n_kt);
+        if (lane == 0 && t1) { atomicAdd(&LH_CTR(ctr)->n_ext, (u64)t1); atomicAdd(&LH_CTR(ctr)->n_ext_exec[2], (u64)t2); atomicAdd(&LH_CTR(ctr)->n_ktree[2], (u64)t3); }
+    }
+}
+
 // sort each read's intervals by info (rank sort; equal keys are identical intervals), seed counts, l_rep.  16 lanes per read
 // (reads in the big slab: k_smem_fin_big).
 __global__ void __launch_bounds__(256) k_smem_fin(DOpts o, int n_reads, DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv, int32_t* __restrict__ seed_cnt,
