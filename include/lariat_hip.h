@@ -76,7 +76,7 @@ typedef struct lh_opts {
 #define LH_F_NO_SWEEP_FILTER 1u  /* K1 sweeps every interval like bwt_smem1a does (n_ext then counts every bwt_extend of the reference) */
 #define LH_F_SMEM_FUSED 2u       /* (reserved: accepted and ignored since r03 — K1 is always one launch per pass) */
 #define LH_F_SMEM_P12 4u         /* (reserved, ignored) */
-#define LH_F_SMEM_MACHINE 8u     /* K1 pass 1: every call after a read's first through the per-lane state machine (no k_smem_rest) */
+#define LH_F_SMEM_LANE 8u        /* (reserved, ignored) */
 #define LH_F_EXT_WAVE 16u        /* K4 wave-per-read only */
 #define LH_F_EXT_SERIAL 32u      /* K4's rounds and wave-kernel launches one after the other on one stream (per-round timings) */
 #define LH_F_SMEM_SPLIT 64u      /* (reserved, ignored) */

@@ -695,30 +695,37 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             WAVE_SYNC();
         }
         RFA_T(10)
-        // ---- calculateLogMoleculePenalty ----
-        if (lane == 0) {
-            double lmp = 0.0;
+        // ---- calculateLogMoleculePenalty (lariat.go:1061-1086) ----
+        // Every term of dnaLength is an integer-valued double far below 2^53, so the sum is exact in any order: the lanes share a
+        // molecule's alignments (it was one lane walking all of them, 16 % of the kernel's time), the wave adds up.
+        {
+            double part = 0.0;
             if (do_rfa && M > 0) {
-                double dnaLength = 1000.0;
                 for (int m = 0; m < M; ++m) {
+                    const int al = T.alen[m], ao = T.aoff[m];
                     if (T.mflag[m]) {
                         i64 smallest = 0x7fffffffffffffffll, biggest = -1;
-                        for (int k = 0; k < T.alen[m]; ++k) {
-                            i64 p = R.pos[c_lo + T.act_store[T.aoff[m] + k]];
+                        for (int k = lane; k < al; k += 64) {
+                            i64 p = R.pos[c_lo + T.act_store[ao + k]];
                             if (p > biggest) biggest = p;
                             if (p < smallest) smallest = p;
                         }
-                        if (biggest >= smallest) dnaLength += (double)(biggest - smallest) + 1000.0;
+                        for (int msk = 32; msk >= 1; msk >>= 1) {
+                            const i64 ob = shfl_xor_i64(biggest, msk), os = shfl_xor_i64(smallest, msk);
+                            if (ob > biggest) biggest = ob;
+                            if (os < smallest) smallest = os;
+                        }
+                        if (lane == 0 && biggest >= smallest) part += (double)(biggest - smallest) + 1000.0;
                     } else {
-                        for (int k = 0; k < T.alen[m]; ++k) {
-                            i64 g = c_lo + T.act_store[T.aoff[m] + k];
-                            dnaLength += (double)(R.aend[g] - R.pos[g]) * 2.0;
+                        for (int k = lane; k < al; k += 64) {
+                            i64 g = c_lo + T.act_store[ao + k];
+                            part += (double)(R.aend[g] - R.pos[g]) * 2.0;
                         }
                     }
                 }
-                lmp = log10(dnaLength / o.genome_length * 0.05);
             }
-            shd[0] = lmp;
+            for (int msk = 32; msk >= 1; msk >>= 1) part += __shfl_xor(part, msk);
+            if (lane == 0) shd[0] = (do_rfa && M > 0) ? log10((1000.0 + part) / o.genome_length * 0.05) : 0.0;
         }
         WAVE_SYNC();
         double lmp = shd[0];
@@ -739,16 +746,17 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         for (int r = lane; r < nR; r += 64) {
             int gr = r0 + r, gm = r0 + (r ^ 1);
             i64 a0 = R.cand_off[gr], a1 = R.cand_off[gr + 1], m0 = R.cand_off[gm], m1 = R.cand_off[gm + 1];
-            double top[15];
+            double* const top = (double*)lds_raw;   // the read's 15 best scores, lane-strided in LDS (the phases that staged things there are over): no scratch
+#define TOPV(k_) top[(k_) * 64 + lane]
             int ntop = 0;
 #define TOP_PUSH(v_)                                                                   \
     {                                                                                  \
         double v = (v_);                                                               \
         int k_ = ntop < 15 ? ntop : 15;                                                \
-        if (ntop < 15 || v > top[14]) {                                                \
+        if (ntop < 15 || v > TOPV(14)) {                                               \
             if (ntop < 15) ntop++; else k_ = 14;                                       \
-            while (k_ > 0 && top[k_ - 1] < v) { top[k_] = top[k_ - 1]; k_--; }         \
-            top[k_] = v;                                                               \
+            while (k_ > 0 && TOPV(k_ - 1) < v) { TOPV(k_) = TOPV(k_ - 1); k_--; }      \
+            TOPV(k_) = v;                                                              \
         }                                                                              \
     }
             // pseudo-count entry (appendPsuedocountAlignmentScore): first filtered alignment of the read + best single mate
@@ -787,7 +795,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             S.second_best_idx[gr] = sb_aln; S.second_best_score[gr] = sb_raw;
             S.as_score[gr] = dev_score_aln(R, S, improper, act, S.mate[act], 0.0);
             double total = 0;
-            for (int k = 0; k < ntop; ++k) total += pow(10.0, top[k]);
+            for (int k = 0; k < ntop; ++k) total += pow(10.0, TOPV(k));
             for (i64 a = a0; a < a1; ++a) {
                 if (!R.in_filtered[a]) continue;
                 double score = dev_score_aln(R, S, improper, a, S.mate[a], lmp);
@@ -801,6 +809,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 S.mapq[a] = (mapq != mapq) ? (int)0x80000000 : (int)mapq;
             }
 #undef TOP_PUSH
+#undef TOPV
         }
         WAVE_SYNC();
         RFA_T(12)

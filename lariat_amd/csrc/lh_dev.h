@@ -162,6 +162,11 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
     return (u64)hi << 32 | lo;
 }
 __device__ __forceinline__ i64 shfl_i64(i64 v, int src) { return (i64)shfl_u64((u64)v, src); }
+__device__ __forceinline__ i64 shfl_xor_i64(i64 v, int m) {
+    uint32_t lo = (uint32_t)(u64)v, hi = (uint32_t)((u64)v >> 32);
+    lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
+    return (i64)((u64)hi << 32 | lo);
+}
 __device__ __forceinline__ u64 shfl_up_u64(u64 v, int d) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl_up(lo, d); hi = __shfl_up(hi, d);

@@ -101,11 +101,11 @@ def test_emu_k1_sweep_filter_and_text_shortcuts(emu, oracle):
     ctx = idx.context(rs.n_pairs)
     seen = {}
     NOF = capi.LH_F_NO_SWEEP_FILTER
-    for flags in (0, capi.LH_F_SMEM_MACHINE, NOF):   # (LH_F_SMEM_MACHINE: the calls after a read's first through the state machine instead of k_smem_rest)
+    for flags in (0, NOF):
         helpers.assert_same_dump(ctx.stage_dump(b, emu.opts(flags=flags)), want, helpers.DUMP_FRONT)
         seen[flags] = ctx.align_barcodes(b, emu.opts(run_inference=0, flags=flags)).counters["n_ext"]
     assert seen[NOF] == want_ext
-    assert seen[0] < want_ext and seen[capi.LH_F_SMEM_MACHINE] < want_ext
+    assert seen[0] < want_ext
 
 
 def test_emu_many_candidate_pairs_go_rng_ring(emu, oracle):

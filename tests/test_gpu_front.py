@@ -36,8 +36,6 @@ def test_front_synthetic(lib, oracle):
     ctx = idx.context(rs.n_pairs)
     want = oidx.stage_dump(b)
     helpers.assert_same_dump(ctx.stage_dump(b), want, helpers.DUMP_FRONT)
-    # K1 pass 1 with every call after a read's first through the state machine instead of the lockstep kernel: the same intervals
-    helpers.assert_same_dump(ctx.stage_dump(b, lib.opts(flags=capi.LH_F_SMEM_MACHINE)), want, helpers.DUMP_FRONT)
 
 
 @pytest.mark.gpu

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--chunk-log2", type=int, default=0)
     ap.add_argument("--out", default=None)
     ap.add_argument("--smem-grid", type=int, default=0)
+    ap.add_argument("--rfa-grid", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0, help="lh_opts.flags (e.g. 32 = K4 classes one after the other)")
     ap.add_argument("--lib", default=None, help="a development build of the library (e.g. with -DLH_SMEM_TURNS)")
     a = ap.parse_args()
@@ -50,7 +51,7 @@ def main():
     r = lib.synth_reads(pac, l_pac, ctg, seed=20261005, n_barcodes=a.barcodes, pairs_per_barcode=100)
     info["t_reads_s"] = round(time.time() - t, 2)
     b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
-    ctx = idx.context(r["n_pairs"], smem_grid=a.smem_grid)
+    ctx = idx.context(r["n_pairs"], smem_grid=a.smem_grid, rfa_grid=a.rfa_grid)
     ctx.upload(b)
     opts = lib.opts(flags=a.flags)
     kern = {}
