@@ -193,6 +193,9 @@ __global__ void __launch_bounds__(256) k_smem_first(DIndex ix, DOpts o, int n_re
 // forward list in LDS, one call per read and launch, four launches before the state machine took the remainder.  Bit-exact, but 13 of 64
 // lanes active (the calls after the first are not one program: calls by text, walks with and without pushes, three kinds of sweep) and
 // latency-bound at 4 waves per SIMD: 13.0 ms against the 10.5 ms of k_smem_first + the state machine.  See the git history.)
+// (Also measured and dropped: the sweep filter's answers for a walk's first 16 levels read ahead, four per turn, so that a walk from
+// beyond position LH_BLOOM_K can jump to the tree's depth — 28 M fewer tree reads per launch, but the extra state costs every turn: 9.5 ms
+// against 8.8; and the reads with work in pass 2 listed by a thread-per-read kernel first: the state machine saves 0.5 ms, the list costs 0.8.)
 // PASS 1: all SMEMs of the read (bwt_smem1a with min_intv 1 from every position the previous call returned).  PASS 2: re-seeding inside
 // the long SMEMs pass 1 left (recognised from the stored intervals).  PASS 3: bwt_seed_strategy1, appended to the intervals the earlier
 // launches left (it depends on the read alone, and the intervals are sorted afterwards).  Each launch carries only its own states:

@@ -30,6 +30,10 @@ def run_case(lib, oracle, seed):
         idx = lib.index_from_arrays(oidx.arrays(), **iopts)
     if rng.random() < 0.3:
         idx.resample_sa(int(rng.choice([2, 8, 32])))
+    alt = None
+    if ncont > 1 and rng.random() < 0.3:   # some contigs are ALT contigs (mem_chain_flt's is_alt rule, the regions' is_alt)
+        alt = (rng.random(ncont) < 0.5).astype(np.uint8)
+        idx.set_alt(alt); oidx.set_alt(alt)
     l1, l2 = int(rng.integers(50, 240)), int(rng.integers(50, 240))
     rs = synth.make_reads(contigs, names, n_barcodes=int(rng.integers(1, 12)), pairs_per_barcode=int(rng.integers(1, 120)), seed=seed + 7, len1=l1, len2=l2,
                           sub_lo=0.0, sub_hi=float(rng.uniform(0.0, 0.06)), indel_rate=float(rng.choice([0.0, 0.001, 0.01])), junk_frac=float(rng.choice([0.0, 0.05, 0.3])))
@@ -44,12 +48,17 @@ def run_case(lib, oracle, seed):
     if rng.random() < 0.3:
         kw = dict(b=int(rng.integers(2, 7)), o_del=int(rng.integers(3, 9)), o_ins=int(rng.integers(3, 9)), e_del=int(rng.integers(1, 3)), e_ins=int(rng.integers(1, 3)),
                   w=int(rng.choice([20, 100])), zdrop=int(rng.choice([50, 100])), min_seed_len=int(rng.choice([15, 19, 25])))
-    what = "contigs %s, reads %dx%d/%d, opts %s, index %s" % (lens, l1, l2, rs.n_pairs, kw, iopts)
+    what = "contigs %s, alt %s, reads %dx%d/%d, opts %s, index %s" % (lens, None if alt is None else alt.tolist(), l1, l2, rs.n_pairs, kw, iopts)
     try:
         ctx = idx.context(rs.n_pairs)
         okw = {k: v for k, v in kw.items() if k != "flags"}
         helpers.assert_same_dump(ctx.stage_dump(b, lib.opts(**kw)), oidx.stage_dump(b, oracle.opts(**okw)), helpers.DUMP_FRONT + helpers.DUMP_REGS)
-        helpers.assert_same_result(ctx.align_barcodes(b, lib.opts(**kw)), oidx.align_barcodes(b, oracle.opts(**okw), threads=16), inference=True)
+        want = oidx.align_barcodes(b, oracle.opts(**okw), threads=16)
+        if rng.random() < 0.5:
+            helpers.assert_same_result(ctx.align_barcodes(b, lib.opts(**kw)), want, inference=True)
+        else:   # the split boundary: resident slot, align, download in two steps
+            ctx.upload_slot(1, b); ctx.select(1); ctx.align_resident(lib.opts(**kw)); ctx.download_begin()
+            helpers.assert_same_result(ctx.download_end(), want, inference=True)
     except Exception as e:
         raise AssertionError("seed %d (%s): %s" % (seed, what, str(e)[:600]))
 

@@ -236,3 +236,26 @@ def test_bam_shard_concat_equals_single_process(hostlib, oracle, tmp_path):
             assert l1 == l2 and len(l1) > 400
         else:
             assert sorted(l1) == sorted(l2)
+
+
+def test_bam_record_limits_are_errors(hostlib, oracle, tmp_path):
+    """the BAM format holds read names of at most 254 bytes (l_read_name is one byte, NUL included): a longer one is LH_E_LIMIT from
+    lh_bam_append with nothing appended — not a truncated name or a corrupt record"""
+    import bam_reader
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = synth.make_reads(contigs, names, n_barcodes=1, pairs_per_barcode=6, seed=71)
+    text = synth.to_fastq9(rs, trim_prefix=7).split("\n")
+    text[9] = "@" + "n" * 300 + " rest"   # the second record's header (9 lines per record)
+    p = tmp_path / "long.fastq"
+    p.write_text("\n".join(text))
+    d = tmp_path / "o"
+    d.mkdir()
+    w = hostlib.bam_writer(str(d), names, [len(c) for c in contigs])
+    for b in hostlib.ingest(str(p), trim=7, max_pairs=100):
+        res = oidx.align_barcodes(b, threads=2)
+        with pytest.raises(capi.LhError) as e:
+            w.append(res, b)
+        assert e.value.code == capi.LH_E_LIMIT and "254" in str(e.value)
+    w.close()
+    assert bam_reader.read_bam(str(d / "bc_sorted_bam.bam"))[2] == []   # nothing was appended
