@@ -193,7 +193,9 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
     }
 }
 
-#define LH_CHAIN_LANE_MAX 16     // seeds a lane chains (k_chain_lane.h); reads with more are chained by the wave kernel above
+#ifndef LH_CHAIN_LANE_MAX
+#define LH_CHAIN_LANE_MAX 32     // seeds a lane chains (k_chain_lane.h: one nibble per seed in two registers); reads with more are chained by the wave kernel above
+#endif
 #ifndef LH_EXT_HEAVY_COLS
 #define LH_EXT_HEAVY_COLS 64     // a full-band extension of this many query columns or more is "heavy" for a lane (k_extend2.h); measured 32 / 48 / 64 / 80 / 96: K4 8.87 / 8.68 / 8.33 / 8.79 / 8.99 ms (the deferred reads run in the wave kernel beside the rounds just as well: no difference)
 #endif

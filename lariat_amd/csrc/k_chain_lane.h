@@ -74,7 +74,9 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
             const int32_t* rid_ = s_rid + base;
             int nch = 0;
             uint32_t od = 0;    // chain ids in B-tree (position) order: insertion after equals
-            u64 smap = ~0ull;   // nibble s: the chain seed s was appended to (0xf: none — contained in its chain, or bridging contigs)
+            u64 smap0 = ~0ull, smap1 = ~0ull;   // nibble s (seeds 0..15 / 16..31): the chain seed s was appended to (0xf: none — contained in its chain, or bridging contigs)
+#define SMAP_SET(s_, v_) { if ((s_) < 16) smap0 = (smap0 & ~(0xfull << ((s_) << 2))) | ((u64)(v_) << ((s_) << 2)); else smap1 = (smap1 & ~(0xfull << (((s_) - 16) << 2))) | ((u64)(v_) << (((s_) - 16) << 2)); }
+#define SMAP_GET(s_) ((int)((((s_) < 16 ? smap0 : smap1) >> (((s_) & 15) << 2)) & 0xf))
             DSeed pn; pn.rbeg = 0; pn.qbeg = 0; pn.len = 0;
             int ridn = -1;
             if (S > 0) { pn = sd_[0]; ridn = rid_[0]; }
@@ -116,7 +118,7 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
                         if (rr >= endr) wr += p.len; else if (rr + p.len > endr) wr += rr + p.len - endr;
                         endr = endr > rr + p.len ? endr : rr + p.len;
                         CLW(ci, 5) = (uint32_t)(n + 1) | (uint32_t)wq << 8; CLW(ci, 6) = (uint32_t)endq | (uint32_t)wr << 8; CLW(ci, 7) = (uint32_t)endr;
-                        smap = (smap & ~(0xfull << (s << 2))) | ((u64)ci << (s << 2));
+                        SMAP_SET(s, ci)
                     }
                     to_add = (res == 0);
                 }
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
                     CLW(nch, 3) = (uint32_t)p.qbeg | (uint32_t)p.qbeg << 8 | (uint32_t)p.len << 16;
                     CLW(nch, 4) = (uint32_t)rid | ((ix.contig_alt && ix.contig_alt[rid]) ? 1u << 30 : 0u);
                     CLW(nch, 5) = 1u | (uint32_t)p.len << 8; CLW(nch, 6) = (uint32_t)(p.qbeg + p.len) | (uint32_t)p.len << 8; CLW(nch, 7) = (uint32_t)p.len;
-                    smap = (smap & ~(0xfull << (s << 2))) | ((u64)nch << (s << 2));
+                    SMAP_SET(s, nch)
                     nch++;
                 }
             }
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
             }
             for (int k = 0; k < nch; ++k) if (C_W(k) < o.min_chain_weight) CLW(k, 7) = 0xffffffffu;   // (never entered st)
             for (int s = 0; s < S; ++s) {   // every kept chain's seed list, flattened, in the order the seeds were appended
-                const int id = (int)((smap >> (s << 2)) & 0xf);
+                const int id = SMAP_GET(s);
                 if (id == 0xf) continue;
                 const uint32_t ss = CLW(id, 7);
                 if (ss == 0xffffffffu) continue;
@@ -222,6 +224,8 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
                 CLW(id, 2) = t + 1;
             }
             n_chains[r] = m;
+#undef SMAP_SET
+#undef SMAP_GET
 #undef C_W
 #undef C_BEG
 #undef C_END
