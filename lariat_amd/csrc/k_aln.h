@@ -333,6 +333,7 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                 int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
                 int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
                 int nmm = 0, n_amb = 0, xo = -2;   // n_amb: mismatching pairs with an ambiguous base (scored -1, not -b)
+                int t_first = lq, t_last = -1;     // the first and the last mismatching pair
                 // 32 pairs per round trip, eight per XOR: the batch's 4-bit reads against the 4-bit text (both strands: rb + t is a text position);
                 // without those tables the same words are put together from the bytes and the 2-bit reference
                 LaneTgt tg;
@@ -377,6 +378,7 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                             }
                             nmm++;
                             n_amb += ((qw >> (4 * u)) & 0xf) > 3;
+                            t_first = t_first < t ? t_first : t; t_last = t;
                         }
                     }
                 }
@@ -384,7 +386,56 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
                 if (w2 != 0) {
                     const int S0 = lq * o.a - (nmm - n_amb) * (o.a + o.b) - n_amb * (o.a + 1);
                     const int bound = (lq - 1) * o.a - (o.o_ins + o.e_ins) - (o.o_del + o.e_del);
-                    if (S0 < bound) { slow_mask |= 1u << ci; n_slow++; continue; }   // a gapped path could win: run the DP (k_aln)
+                    if (S0 < bound) {
+                        // A FEW MORE MISMATCHES (new in r03: 37 % of the candidates that used to need the wave DP).  The diagonal still wins when no
+                        // path with gaps reaches it at ANY diagonal cell: let D(t) be the diagonal's score up to pair t and G(t) the best score of a
+                        // path to (t, t) with gaps; ksw_global2 picks M at (t, t) iff H(t-1,t-1) + s >= E, F (ties towards the diagonal), and
+                        // E(t,t), F(t,t) <= G(t), so G(t) <= D(t) for all t leaves score S0 and the CIGAR lq M, in every band and every retry.
+                        // A path back on the diagonal has as many inserted as deleted bases.  (1) Three or more gap runs: at least two runs on one
+                        // side, so >= 2 bases each way, cost >= C3 and at most t + 1 - 2 aligned pairs: below D(t) whenever the diagonal's total
+                        // loss is <= 2a + C3.  (2) One run each way of g bases, cost c(g) = o_ins + o_del + g (e_ins + e_del): the detour replaces
+                        // the pairs [x, e + g) by the pairs of the diagonal shifted by g over [x, e); its gain is (a + b) x (mismatches of the main
+                        // diagonal in [x, e + g) - mismatches of the shifted one in [x, e)) - g a - c(g) <= loss - g a - c(g): never positive
+                        // for g >= g0.  (3) For g < g0, both shifts: the largest gain over all x <= e is a running maximum (Kadane) over the two
+                        // mismatch patterns, compared eight bases per word against the 4-bit text — this is where low-complexity sequence, whose
+                        // shifted diagonals do match, is told apart.  Reads with an ambiguous base in the span take the DP.
+                        const int loss = lq * o.a - S0;
+                        const int c3a = 2 * o.o_ins + 2 * o.e_ins + o.o_del + 2 * o.e_del, c3b = 2 * o.o_del + 2 * o.e_del + o.o_ins + 2 * o.e_ins;
+                        int okd = packed && n_amb == 0 && loss <= 2 * o.a + (c3a < c3b ? c3a : c3b);
+                        int g0 = 1;
+                        while (okd && o.o_ins + o.o_del + g0 * (o.e_ins + o.e_del + o.a) < loss) { if (++g0 > 5) okd = 0; }
+                        if (okd && g0 > 3) okd = 0;   // (shifts of one and two bases are checked below: enough for every loss the bound of (1) admits with BWA's usual penalties)
+                        if (okd) {
+                            // shifts 1 and 2, both directions, in one sweep from the first to the last mismatch of the main diagonal (outside, every gain is
+                            // zero or falling): sixteen bases of read and text per step in two 64-bit words, the shifted diagonals are shifts of those
+                            const i64 qp0 = off + qb;
+                            int K[4] = {0, 0, 0, 0};   // running maxima: (g = 1, insertion first), (1, deletion first), (2, ins), (2, del)
+                            const int e_beg = (t_first - 1 > 0 ? t_first - 1 : 0) & ~7;
+                            for (int e8 = e_beg; e8 <= t_last + 1 && okd; e8 += 8) {
+                                const u64 qq = (u64)dev_nib8(q4, qp0 + e8) | (u64)dev_nib8(q4, qp0 + e8 + 8) << 32;
+                                const u64 tt = (u64)dev_nib8(ix.tn, rb + e8) | (u64)dev_nib8(ix.tn, rb + e8 + 8) << 32;
+                                const u64 xm = qq ^ tt;   // (nibbles past the spans are never looked at: see the limits below)
+                                const u64 xs[4] = {(qq >> 4) ^ tt, qq ^ (tt >> 4), (qq >> 8) ^ tt, qq ^ (tt >> 8)};
+                                for (int u = 0; u < 8; ++u) {
+                                    const int e = e8 + u;
+                                    if (e > t_last + 1) break;
+                                    const int m0 = ((xm >> (4 * u)) & 0xf) != 0, m1 = ((xm >> (4 * u + 4)) & 0xf) != 0;
+#pragma unroll
+                                    for (int v = 0; v < 4; ++v) {
+                                        const int g = 1 + (v >> 1);
+                                        if (g >= g0 || e + g > lq) continue;
+                                        const int lim = g * o.a + o.o_ins + o.o_del + g * (o.e_ins + o.e_del);   // g a + c(g)
+                                        const int tail = m0 + (g == 2 ? m1 : 0);
+                                        if ((o.a + o.b) * (K[v] + tail) > lim) okd = 0;
+                                        const int mb = ((xs[v] >> (4 * u)) & 0xf) != 0;
+                                        K[v] += m0 - mb;
+                                        K[v] = K[v] > 0 ? K[v] : 0;
+                                    }
+                                }
+                            }
+                        }
+                        if (!okd) { slow_mask |= 1u << ci; n_slow++; continue; }   // a gapped path could win: run the DP (k_aln)
+                    }
                     // the DP cells mem_reg2aln would have evaluated (telemetry stays comparable with the reference's work)
                     int wq = w2, it = 0, last_sc = -(1 << 30);
                     do {
