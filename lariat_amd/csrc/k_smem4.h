@@ -1142,22 +1142,28 @@ __global__ void __launch_bounds__(256) k_smem_fin(DOpts o, int n_reads, DIntv* _
         if (e < n) mine[t] = a[e];
         rank[t] = 0;
     }
+    const int nt = (n + 15) >> 4;   // slots in use (one for the usual dozen intervals: the others' compares are skipped by the whole wave)
     for (int u = 0; u < n; ++u) {
         u64 oi = a[u].info;
-        for (int t = 0; t < 4; ++t) { int e = sub + 16 * t; rank[t] += (oi < mine[t].info) || (oi == mine[t].info && u < e); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < nt) { int e = sub + 16 * t; rank[t] += (oi < mine[t].info) || (oi == mine[t].info && u < e); }
     }
     __syncthreads();   // every lane holds its entries before any is overwritten
-    int cnt = 0;
+    int cnt = 0, rep = 0;   // rep: intervals with more than max_occ occurrences (none, usually: l_rep is 0 without another walk over the intervals)
+#pragma unroll
     for (int t = 0; t < 4; ++t) {
         int e = sub + 16 * t;
-        if (e < n && live) {
+        if (t < nt && e < n && live) {
             a[rank[t]] = mine[t];
             cnt += dev_seed_count(o, mine[t].x2);
+            rep += mine[t].x2 > (u64)o.max_occ;
         }
     }
     cnt += (int)dpp_xor1((uint32_t)cnt); cnt += (int)dpp_xor2((uint32_t)cnt); cnt += (int)dpp_half_mirror((uint32_t)cnt); cnt += (int)dpp_ror8((uint32_t)cnt);
+    rep += (int)dpp_xor1((uint32_t)rep); rep += (int)dpp_xor2((uint32_t)rep); rep += (int)dpp_half_mirror((uint32_t)rep); rep += (int)dpp_ror8((uint32_t)rep);
     __syncthreads();
-    if (sub == 0 && live) { seed_cnt[r] = cnt; l_rep_out[r] = dev_l_rep(o, a, n); }
+    if (sub == 0 && live) { seed_cnt[r] = cnt; l_rep_out[r] = rep ? dev_l_rep(o, a, n) : 0; }
 }
 // the same for a read in the big slab, one wave per read: ranks against the unsorted half, written to the sorted half
 __global__ void __launch_bounds__(64) k_smem_fin_big(DOpts o, K1Big big, const int32_t* __restrict__ n_intv, int32_t* __restrict__ seed_cnt, int32_t* __restrict__ l_rep_out) {
