@@ -102,9 +102,12 @@ __global__ void __launch_bounds__(256) k_seed(DIndex ix, DOpts o, int n_reads, c
             u64 x0 = 0, step = 1, info = 0;
             for (int t = 0; t < n; ++t) {
                 u64 s = iv[t].x2;
-                u64 st = s > (u64)o.max_occ ? s / (u64)o.max_occ : 1;
-                u64 c = (s + st - 1) / st;
-                if (c > (u64)o.max_occ) c = (u64)o.max_occ;
+                u64 st = 1, c = s;   // (the usual interval has at most max_occ occurrences: every one is a seed; the 64-bit divisions are for the others)
+                if (s > (u64)o.max_occ) {
+                    st = s / (u64)o.max_occ;
+                    c = (s + st - 1) / st;
+                    if (c > (u64)o.max_occ) c = (u64)o.max_occ;
+                }
                 if ((u64)u < c) { x0 = iv[t].x0; step = st; info = iv[t].info; break; }
                 u -= (i64)c;
             }

@@ -1014,7 +1014,8 @@ __device__ __forceinline__ int dev_l_rep(const DOpts& o, const DIntv* a, int n) 
     return l_rep + e - b;
 }
 __device__ __forceinline__ int dev_seed_count(const DOpts& o, u64 s) {
-    u64 step = s > (u64)o.max_occ ? s / (u64)o.max_occ : 1;
+    if (s <= (u64)o.max_occ) return (int)s;   // (no 64-bit division for the usual interval)
+    u64 step = s / (u64)o.max_occ;
     u64 c = (s + step - 1) / step;
     return (int)(c < (u64)o.max_occ ? c : (u64)o.max_occ);
 }
