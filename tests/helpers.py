@@ -229,3 +229,23 @@ def low_complexity_genome(seed=9):
     parts = [rnd(20000), tandem([0], 5000), rnd(3000), tandem([1, 0], 1500), rnd(3000), tandem(rnd(37), 200), rnd(3000), tandem(rnd(5), 800), rnd(3000),
              tandem(rnd(2), 400), rnd(500), tandem([3], 600), rnd(20000)]
     return ["chrL"], [np.concatenate(parts)]
+
+
+def k7_shift_case(g, ins_first):
+    """a read pair whose read 1 has four mismatches on the diagonal of its alignment and NONE on a path with one insertion and one deletion of g
+    bases: a stretch of A's with two interruptions, shifted by g inside its own span (K7's shifted-diagonal check, k_aln.h).  Returns
+    (names, contigs, batch, position of the stretch)."""
+    from lariat_amd import capi
+    rng = np.random.default_rng(23)
+    rnd = lambda n: rng.integers(0, 4, size=n).astype(np.uint8)
+    seg = np.array([0] * 6 + [2] + [0] * 6 + [3] + [0] * 6, dtype=np.uint8)                 # AAAAAA G AAAAAA T AAAAAA
+    left, right = rnd(4000), rnd(4000)
+    left[-1] = 1; right[0] = 1                                                                # (no A next to the stretch: the indels cannot slide out of it)
+    contig = np.concatenate([left, seg, right])
+    p = len(left)
+    body = np.concatenate([[0] * g, seg[:-g]]) if ins_first else np.concatenate([seg[g:], [0] * g])   # the stretch shifted by g inside its own span
+    r1 = np.concatenate([contig[p - 66:p], body, contig[p + len(seg):p + len(seg) + 150 - 66 - len(seg)]]).astype(np.uint8)
+    assert len(r1) == 150 and int((r1 != contig[p - 66:p + 84]).sum()) == 4
+    mate = contig[p + 250:p + 400]
+    r2 = (3 - mate[::-1]).astype(np.uint8)
+    return ["chrK"], [contig], capi.Batch([r1, r2], [0, 1]), p

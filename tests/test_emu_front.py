@@ -314,3 +314,40 @@ def test_emu_overlapped_download_and_staged_upload(emu, oracle):
         helpers.assert_same_result(got[k], oidx.align_barcodes(batches[k]), inference=True)
     with pytest.raises(capi.LhError):
         ctx.stage_slot(1 + 2 % 2, batches[0])                  # the selected slot cannot be staged into
+
+
+def test_emu_k7_four_mismatches_and_shifted_diagonals(emu, oracle):
+    """K7 settles a candidate with equal spans without the DP when no path with gaps can reach the diagonal (k_aln.h: bounds + the diagonals
+    shifted by one and two bases).  Reads with 3-5 % substitutions and no indels, half of them from microsatellites and tandem repeats — where
+    shifted diagonals DO match and the DP has to run — against the oracle, every field (the GPU suite has the same on the 80-kb low-complexity genome)"""
+    from lariat_amd import synth
+    rng = np.random.default_rng(17)
+    rnd = lambda n: rng.integers(0, 4, size=n).astype(np.uint8)
+    tandem = lambda unit, n: np.tile(np.asarray(unit, dtype=np.uint8), n)
+    names, contigs = ["chrL"], [np.concatenate([rnd(2500), tandem([0], 300), rnd(700), tandem([1, 0], 150), rnd(700), tandem(rnd(37), 30), rnd(700), tandem(rnd(5), 80), rnd(2500)])]
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs = synth.make_reads(contigs, names, n_barcodes=1, pairs_per_barcode=16, seed=5, sub_lo=0.03, sub_hi=0.05, indel_rate=0.0, mol_min=2, mol_max=3)
+    b = helpers.batch_of(rs)
+    res = idx.context(rs.n_pairs).align_barcodes(b)
+    ores = oidx.align_barcodes(b, threads=8)
+    helpers.assert_same_result(res, ores, inference=True)
+    ok = ores.rid >= 0
+    assert int(((ores.indels[ok] == 0) & (ores.mismatches[ok] >= 4)).sum()) > 8   # the proof's (and the DP's) cases are there
+
+
+@pytest.mark.parametrize("g,ins_first", [(1, False), (1, True), (2, False), (2, True)])
+def test_emu_k7_gapped_path_beats_a_four_mismatch_diagonal(emu, oracle, g, ins_first):
+    """the case the shifted-diagonal check of K7 exists for: a read that lost g bases before a stretch of A's with two interruptions and gained g
+    behind it (or the other way round) has FOUR mismatches on the diagonal (loss 20) — and a path with one deletion and one insertion (cost
+    12 + 2g + g pairs) that has none.  Equal spans, so bwa_gen_cigar2's shortcut does not apply; the bounds of k_aln.h do not exclude the path;
+    the diagonal shifted by g matches through all four mismatches: the DP must run (CIGAR with I and D).  A kernel that skipped the check
+    would report 150M (checked by disabling it: this test fails)."""
+    names, contigs, b, p = helpers.k7_shift_case(g, ins_first)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    res = idx.context(8).align_barcodes(b, emu.opts(run_inference=0))
+    ores = oidx.align_barcodes(b, oracle.opts(run_inference=0))
+    helpers.assert_same_result(res, ores, inference=False)
+    c = list(ores.cands_of_read(0))[0]
+    assert int(ores.indels[c]) == 2 and int(ores.mismatches[c]) == 0 and int(ores.pos[c]) == p - 66

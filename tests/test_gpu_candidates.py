@@ -181,3 +181,16 @@ def test_overlapped_download_and_staged_upload(lib, oracle):
     got.append(ctx.download_end())
     for k in range(4):
         helpers.assert_same_result(got[k], oidx.align_barcodes(batches[k], threads=8), inference=True)
+
+
+@pytest.mark.parametrize("g,ins_first", [(1, False), (1, True), (2, False), (2, True)])
+def test_gapped_path_beats_a_four_mismatch_diagonal(lib, oracle, g, ins_first):
+    """K7's shifted-diagonal check on the device (the construction and the argument: tests/test_emu_front.py, helpers.k7_shift_case)"""
+    names, contigs, b, p = helpers.k7_shift_case(g, ins_first)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    res = idx.context(8).align_barcodes(b, lib.opts(run_inference=0))
+    ores = oidx.align_barcodes(b, oracle.opts(run_inference=0))
+    helpers.assert_same_result(res, ores, inference=False)
+    c = list(res.cands_of_read(0))[0]
+    assert int(res.indels[c]) == 2 and int(res.mismatches[c]) == 0 and int(res.pos[c]) == p - 66
