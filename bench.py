@@ -263,6 +263,7 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
         if k.get("FETCH_SIZE_KB") is not None and k.get("WRITE_SIZE_KB") is not None and k.get("calls"):
             traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["calls"]
             r["traffic_source"] = "profiles/%s (commit %s, %s)" % (os.path.basename(PMC_FILE), pmc.get("commit"), pmc.get("command"))
+            r["traffic_age_commits"] = commits_since(pmc.get("commit"))
             r["traffic_GBps"] = round(traffic / (ms * 1e-3) / 1e9, 2)
             r["traffic_frac"] = round(r["traffic_GBps"] / HBM_PEAK_GBPS, 5)
             if k.get("TCC_MISS") and pmc.get("random_read_ceiling_Gaccess_per_s"):
@@ -282,6 +283,16 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
     return r
 
 
+def commits_since(commit):
+    """how many commits HEAD is ahead of the one the PMC file was measured at (None where there is no git: the driver's GPU box; the
+    source-hash guard of pmc_is_stale is what holds there)"""
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "rev-list", "--count", "%s..HEAD" % commit], capture_output=True, text=True, timeout=10)
+        return int(out.stdout.strip()) if out.returncode == 0 else None
+    except Exception:
+        return None
+
+
 def pmc_is_stale(pmc):
     """the committed PMC file names the commit it was measured at; if a kernel source changed after that commit the file describes other
     code.  Returns a reason (str) or None.  (No git on the GPU box: then the file's own list of kernel-source hashes is compared.)"""
@@ -289,7 +300,7 @@ def pmc_is_stale(pmc):
         return None
     import hashlib
     cs = os.path.join(ROOT, "lariat_amd", "csrc")
-    now = {f: hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(cs)) if f.startswith("k_") and f.endswith(".h")}
+    now = {f: hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(cs)) if f.endswith((".h", ".inc", ".hip"))}
     was = pmc.get("kernel_sources")
     if not was:
         return "profiles/%s does not list the kernel sources it was measured with: traffic not reported" % os.path.basename(PMC_FILE)

@@ -74,12 +74,8 @@ typedef struct lh_opts {
 
 /* lh_opts.flags (development / measurement; the defaults are the measured best) */
 #define LH_F_NO_SWEEP_FILTER 1u  /* K1 sweeps every interval like bwt_smem1a does (n_ext then counts every bwt_extend of the reference) */
-#define LH_F_SMEM_FUSED 2u       /* (reserved: accepted and ignored since r03 — K1 is always one launch per pass) */
-#define LH_F_SMEM_P12 4u         /* (reserved, ignored) */
-#define LH_F_SMEM_LANE 8u        /* (reserved, ignored) */
 #define LH_F_EXT_WAVE 16u        /* K4 wave-per-read only */
 #define LH_F_EXT_SERIAL 32u      /* K4's rounds and wave-kernel launches one after the other on one stream (per-round timings) */
-#define LH_F_SMEM_SPLIT 64u      /* (reserved, ignored) */
 
 /* how an index is made resident (lh_index_load / lh_index_from_arrays / lh_index_build_device); NULL = defaults */
 typedef struct lh_index_opts {
@@ -104,7 +100,9 @@ typedef struct lh_context_opts {
     int32_t lanes;        /* 1 (default) .. 4: with L > 1 the context owns L - 1 further, smaller pipelines; every batch is cut at barcode
                            * boundaries and the L parts (barcodes are independent) are aligned side by side from L host threads, so
                            * that one part's kernels fill the idle tails of the others'; results are merged.  No stage dumps then. */
-    int32_t reserved[2];
+    int32_t big_slots;    /* K1: slots of the slab for reads with more than 64 SMEM intervals (max_pairs / 128, at least 64); the slab grows when a
+                           * batch needs more, tests force that with a small value */
+    int32_t reserved;
 } lh_context_opts;
 void lh_context_opts_init(lh_context_opts* co);
 

@@ -17,7 +17,7 @@ LH_ABI_VERSION = 3
 LH_E_ARG, LH_E_IO, LH_E_HIP, LH_E_CAPACITY, LH_E_NODEVICE, LH_E_LIMIT = 1, 2, 3, 4, 5, 6
 # lh_opts.flags
 LH_REC_DEBUG_TAGS = 1
-LH_F_NO_SWEEP_FILTER, LH_F_SMEM_FUSED, LH_F_SMEM_P12, LH_F_SMEM_LANE, LH_F_EXT_WAVE, LH_F_EXT_SERIAL, LH_F_SMEM_SPLIT = 1, 2, 4, 8, 16, 32, 64
+LH_F_NO_SWEEP_FILTER, LH_F_EXT_WAVE, LH_F_EXT_SERIAL = 1, 16, 32
 LH_MAX_READ_LEN = 250
 
 c_i32p = C.POINTER(C.c_int32)
@@ -54,7 +54,7 @@ class LhIndexOpts(C.Structure):
 
 class LhContextOpts(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("smem_grid", C.c_int32), ("aln_grid", C.c_int32), ("rfa_grid", C.c_int32), ("rfa_slab_kb", C.c_int32),
-                ("lanes", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("lanes", C.c_int32), ("big_slots", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LhBatch(C.Structure):

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
         }
         int nk = 0;   // kept-chain list reuses od[]
         if (n > 0) {
-            dev_introsort(n, st, [&](int x, int y) { return C[x].w > C[y].w; });
+            dev_introsort(n, st, [&](int x, int y) { return C[x].w > C[y].w; }, o.wd);
             C[st[0]].kept = 3;
             od[nk++] = 0;
             for (int i = 1; i < n; ++i) {

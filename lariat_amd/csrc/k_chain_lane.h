@@ -24,7 +24,7 @@
 #define NIB(x_, i_) ((int)(((x_) >> ((i_) << 2)) & 0xf))
 #define NIB_SET(x_, i_, v_) ((x_) = ((x_) & ~(0xfu << ((i_) << 2))) | ((uint32_t)(v_) << ((i_) << 2)))
 // klib's ks_introsort for n <= 16 (see dev_introsort_small) over the nibbles of a register
-template <class Lt> __device__ __forceinline__ void dev_introsort_small_nib(int n, uint32_t& a, Lt lt) {
+template <class Lt> __device__ __forceinline__ void dev_introsort_small_nib(int n, uint32_t& a, Lt lt, int32_t* wdp) {
     if (n < 1) return;
     if (n == 2) {
         if (lt(NIB(a, 1), NIB(a, 0))) { int x = NIB(a, 0), y = NIB(a, 1); NIB_SET(a, 0, y); NIB_SET(a, 1, x); }
@@ -39,8 +39,8 @@ template <class Lt> __device__ __forceinline__ void dev_introsort_small_nib(int 
         if (k != t) { int y = NIB(a, t); NIB_SET(a, k, y); NIB_SET(a, t, rp); }
         int wd = 4 * LH_CHAIN_LANE_MAX + 8;
         for (;;) {
-            do { ++i; LH_WATCH(wd, 4, return) } while (lt(NIB(a, i), rp));
-            do { --j; LH_WATCH(wd, 5, return) } while (i <= j && lt(rp, NIB(a, j)));
+            do { ++i; LH_WATCH(wdp, wd, 4, return) } while (lt(NIB(a, i), rp));
+            do { --j; LH_WATCH(wdp, wd, 5, return) } while (i <= j && lt(rp, NIB(a, j)));
             if (j <= i) break;
             int x = NIB(a, i), y = NIB(a, j); NIB_SET(a, i, y); NIB_SET(a, j, x);
         }
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64, LH_CHAIN_LANE_WAVES) k_chain_lane(DIndex i
                 NIB_SET(st, n, id); n++;
             }
             if (n > 0) {
-                dev_introsort_small_nib(n, st, [&](int x, int y) { return C_W(x) > C_W(y); });
+                dev_introsort_small_nib(n, st, [&](int x, int y) { return C_W(x) > C_W(y); }, o.wd);
                 uint32_t kl = 0;   // the kept chains (indices into st)
                 int nk = 0;
                 C_SET_KEPT(NIB(st, 0), 3);

@@ -40,7 +40,7 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     if (n <= 1) return n;
     if (lane == 0) {
         for (int i = 0; i < n; ++i) { ia[i] = i; av[i].n_comp = 1; }
-        dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; });   // sort by the END position, not START!
+        dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; }, o.wd);   // sort by the END position, not START!
     }
     WAVE_SYNC();
     int wd = 1000000;
@@ -50,7 +50,7 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
         if (p.rid != pm.rid || p.rb >= pm.re + o.max_chain_gap) continue;   // then no need to go into the loop below
         for (int j = i - 1; j >= 0; --j) {
             DReg qq = av[ia[j]];
-            LH_WATCH_D(wd, 4, break)
+            LH_WATCH_D(o.wd, wd, 4, break)
             WAVE_SYNC();   // every lane has its copy before lane 0 may overwrite the entry
             if (!(p.rid == qq.rid && p.rb < qq.re + o.max_chain_gap)) break;
             if (qq.qe == qq.qb) continue;   // a[j] has been excluded
@@ -89,7 +89,7 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
         dev_introsort(m, ia, [&](int x, int y) {
             const DReg &A = av[x], &B = av[y];
             return A.score > B.score || (A.score == B.score && (A.rb < B.rb || (A.rb == B.rb && A.qb < B.qb)));
-        });
+        }, o.wd);
         for (int i = 1; i < m; ++i)   // mark identical hits
             if (av[ia[i]].score == av[ia[i - 1]].score && av[ia[i]].rb == av[ia[i - 1]].rb && av[ia[i]].qb == av[ia[i - 1]].qb) av[ia[i]].qe = av[ia[i]].qb;
         int m2 = m ? 1 : 0;

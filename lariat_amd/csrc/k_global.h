@@ -69,7 +69,7 @@ __device__ __forceinline__ int wave_ksw_global2(const DIndex& ix, const DOpts& o
 #undef LH_GLB_INIT
     int tchunk = 4;
     u64 ncell = 0;
-    if (tlen > 100000) { lh_dbg[5] = 1; lh_dbg[6] = tlen; tlen = 0; }
+    if (tlen > 100000) { o.wd[5] = 1; o.wd[6] = tlen; tlen = 0; }
     for (int i = 0; i < tlen; ++i) {
         if ((i & 63) == 0) {
             int ii = i + lane;

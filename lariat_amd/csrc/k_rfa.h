@@ -178,6 +178,7 @@ __device__ __forceinline__ int dev_mol_active(int alen, int nbest, int change) {
 #define LH_RFA_SORT_LDS 768   // filtered candidates of a barcode whose position sort is staged in LDS (9 KB: 16 single-wave blocks per CU)
 #endif
 #define LH_RFA_LDS_BYTES (LH_RFA_SORT_LDS * 12)
+static_assert(LH_RFA_LDS_BYTES >= 15 * 64 * (int)sizeof(double), "estimateMapQualities keeps a read's top-15 scores per lane in lds_raw (top[k * 64 + lane])");
 #define LH_RFA_NCONT_LDS 1024  // contig slots of a barcode kept in LDS while grouping (index with more contigs: slab copy)
 #define LH_RFA_SRC_CHUNK 256   // source-molecule alignments staged per pass of fastScore
 
@@ -245,7 +246,7 @@ __device__ __forceinline__ u64 dev_mix64(u64 x) {
 }
 
 #ifdef LH_RFA_PROF   // development aid: per-phase wall-clock (100 MHz ticks -> us) summed over waves into lh_dbg[16..]
-#define RFA_T(k) { if (lane == 0) { u64 now_ = wall_clock64(); atomicAdd(&lh_dbg[16 + (k)], (int)((now_ - t_prof) / 100)); t_prof = now_; } }
+#define RFA_T(k) { if (lane == 0) { u64 now_ = wall_clock64(); atomicAdd(&o.wd[16 + (k)], (int)((now_ - t_prof) / 100)); t_prof = now_; } }
 #else
 #define RFA_T(k)
 #endif
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
     }
     int wd_main = 1 << 24;
     for (;;) {
-        LH_WATCH(wd_main, 12, break)
+        LH_WATCH(o.wd, wd_main, 12, break)
         if (lane == 0) shi[5] = atomicAdd(bc_next, 1);
         WAVE_SYNC();
         const int widx = shi[5];
@@ -829,7 +830,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 int slot = (int)(dev_mix64(k0 ^ dev_mix64(k1 ^ dev_mix64(k2 ^ dev_mix64(k3)))) & (u64)hmask);
                 int wd_ins = hmask + 2;
                 for (;;) {
-                    LH_WATCH(wd_ins, 13, break)
+                    LH_WATCH(o.wd, wd_ins, 13, break)
                     int cur = atomicCAS(&T.htab[slot], -1, r);
                     if (cur == -1) break;
                     if (T.dk0[cur] == k0 && T.dk1[cur] == k1 && T.dk2[cur] == k2 && T.dk3[cur] == k3) { atomicMin(&T.htab[slot], r); break; }
@@ -843,7 +844,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 int dup = 0;
                 int wd_look = hmask + 2;
                 for (;;) {
-                    LH_WATCH(wd_look, 14, break)
+                    LH_WATCH(o.wd, wd_look, 14, break)
                     int cur = atomicAdd(&T.htab[slot], 0);   // read at L2, where the atomics above landed
                     if (T.dk0[cur] == k0 && T.dk1[cur] == k1 && T.dk2[cur] == k2 && T.dk3[cur] == k3) { dup = cur != r; break; }
                     slot = (slot + 1) & hmask;

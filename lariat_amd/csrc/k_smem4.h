@@ -1190,14 +1190,17 @@ __global__ void __launch_bounds__(64) k_smem_fin_big(DOpts o, K1Big big, const i
 }
 // after the three passes: the reads whose intervals did not fit their regular slots get a slot of the big slab and are listed for the
 // second chance (their flag is cleared; it is set again if LH_BIG_INTV do not hold them either, or the slab has no slot left)
+// base > 0: a further round after the slab has grown (the host saw more reads asking than there were slots): only the reads the round before
+// left without a slot are listed, for slots base .. base + cap - 1
 __global__ void __launch_bounds__(256) k_big_collect(int n_reads, int32_t* __restrict__ status, int32_t* __restrict__ n_intv, int32_t* __restrict__ slot, int32_t* __restrict__ list,
-                                                      int32_t* __restrict__ count, int cap) {
+                                                      int32_t* __restrict__ count, int base, int cap) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
+    if (base > 0 && slot[r] >= 0) return;   // listed by an earlier round (if its flag is set again, LH_BIG_INTV slots did not hold it either)
     int s = -1;
     if (status[r] & LH_ST_INTV_OVERFLOW) {
         s = atomicAdd(count + 1, 1);   // count[1]: slots asked for; count[0]: reads listed
-        if (s < cap) { list[atomicAdd(count, 1)] = r; status[r] &= ~LH_ST_INTV_OVERFLOW; n_intv[r] = 0; }
+        if (s < cap) { list[atomicAdd(count, 1)] = r; status[r] &= ~LH_ST_INTV_OVERFLOW; n_intv[r] = 0; s += base; }
         else s = -1;
     }
     slot[r] = s;

@@ -60,20 +60,17 @@ typedef int64_t i64;
 #define LH_UNI(c) (__builtin_amdgcn_readfirstlane((int)(c)) != 0)
 #endif
 
-// development watchdog: loops that should be short bump a budget; on exhaustion they record a site code and bail out
-#ifdef LH_EMU
-static int lh_dbg[32];
-#else
-__device__ int lh_dbg[32];
-#endif
-#define LH_WATCH(budget, code, action) if (--(budget) < 0) { lh_dbg[code] = 1; action; }
+// watchdog: loops that should be short bump a budget; on exhaustion they record a site code in the PIPELINE's slots (DOpts::wd: 32 words owned
+// by the lh_context whose kernels these are, read back and cleared with that context's result) and bail out
+#define LH_WD_SLOTS 32
+#define LH_WATCH(wdp, budget, code, action) if (--(budget) < 0) { (wdp)[code] = 1; action; }
 #ifdef LH_NOWATCH_SORT
-#define LH_WATCH_S(budget, code, action)
+#define LH_WATCH_S(wdp, budget, code, action)
 #else
 #define LH_WATCH_S LH_WATCH
 #endif
 #ifdef LH_NOWATCH_DEDUP
-#define LH_WATCH_D(budget, code, action)
+#define LH_WATCH_D(wdp, budget, code, action)
 #else
 #define LH_WATCH_D LH_WATCH
 #endif
@@ -139,6 +136,7 @@ struct DOpts {   // mem_opt_t + lariat knobs, POD
     int32_t pes_low, pes_high, rescue_score_delta, rescue_max_hits, aln_score_delta, run_inference;
     double improper_pair_penalty, genome_length;
     int8_t mat[25];
+    int32_t* wd;   // the pipeline's watchdog slots (LH_WATCH)
 };
 
 struct DIntv { u64 x0, x1, x2, info; };   // bwtintv_t
@@ -453,6 +451,7 @@ __device__ __forceinline__ DiagScan dev_diag_scan(const DIndex& ix, const DOpts&
 }
 // one 64-bit value into page-locked host memory the device can write: a read-back that does not queue behind the bulk transfers of the copy engines
 __global__ void k_peek_i64(const i64* __restrict__ src, i64* __restrict__ dst_host) { *dst_host = *src; }
+__global__ void k_peek_i64_i32(const i64* __restrict__ src, const int32_t* __restrict__ src2, i64* __restrict__ dst_host) { dst_host[0] = *src; dst_host[1] = *src2; }
 // the batch's reads as a 4-bit stream (base i of the batch buffer at symbol i; non-bases = 4), two words of padding in front
 __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ seq, i64 n_bases, uint32_t* __restrict__ q4) {
     const i64 nw = (n_bases + 7) / 8;   // (the batch buffer is 8-aligned and padded past n_bases)

@@ -32,7 +32,7 @@ template <class T, class Lt> __device__ inline void dev_combsort(int n, T* a, Lt
     if (gap != 1) dev_insertsort(a, a + n, lt);
 }
 
-template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, Lt lt) {
+template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, Lt lt, int32_t* wdp) {
     struct Stk { T *left, *right; int depth; };
     Stk stack[72];
     int d;
@@ -48,7 +48,7 @@ template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, L
     s = a; t = a + (n - 1); d <<= 1;
     int wd = 100000 + 64 * n;
     while (1) {
-        LH_WATCH_S(wd, 1, return)
+        LH_WATCH_S(wdp, wd, 1, return)
         if (LH_UNI(s < t)) {
             if (LH_UNI(--d == 0)) {
                 dev_combsort((int)(t - s + 1), s, lt);
@@ -62,8 +62,8 @@ template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, L
             rp = *k;
             if (k != t) { swap_tmp = *k; *k = *t; *t = swap_tmp; }
             for (;;) {
-                do { ++i; LH_WATCH_S(wd, 2, return) } while (LH_UNI(lt(*i, rp)));
-                do { --j; LH_WATCH_S(wd, 3, return) } while (LH_UNI(i <= j && lt(rp, *j)));
+                do { ++i; LH_WATCH_S(wdp, wd, 2, return) } while (LH_UNI(lt(*i, rp)));
+                do { --j; LH_WATCH_S(wdp, wd, 3, return) } while (LH_UNI(i <= j && lt(rp, *j)));
                 if (LH_UNI(j <= i)) break;
                 swap_tmp = *i; *i = *j; *j = swap_tmp;
             }

@@ -116,3 +116,122 @@ def add_alt_contigs(pac, contigs, n_alt, alt_len, identity, seed):
         l_pac += alt_len
     body.append(np.zeros(1, dtype=np.uint8))
     return np.concatenate(body), l_pac, out, flags, pairs
+
+
+# ---- BASELINE.json configs[4]: "hg38 + ALT/decoy contigs, pairs biased to segdup/repeat loci (high candidate multiplicity per read)" ----
+# segmental duplications (200 copies x 20 kb at 98-99.5 % identity), 300-bp / 6-kb interspersed repeat families, ALT contigs =
+# mutated copies of 1 Mb regions.  What multiplies the candidates of a read (mem_align1_core regions, gobwa.go:244,253), the rescue attempts of
+# a pair (gobwa.go:286-325: up to 50 hits of the mate each) and the molecules of a barcode (lariat.go:1135-1167: 8 M^2 fastScore calls) is a
+# FAMILY: n copies that all resemble each other — n - 1 further candidates for a read from any of them — not n independent pairs of copies.
+
+def _unpack(pac, p, n):
+    """nt4 codes of the n bases from p (both multiples of 4) of a packed genome"""
+    import numpy as np
+    b = pac[p >> 2:(p + n) >> 2]
+    return np.stack([(b >> 6) & 3, (b >> 4) & 3, (b >> 2) & 3, b & 3], axis=1).reshape(-1).astype(np.uint8)
+
+
+def _repack(pac, p, seg):
+    q = seg.reshape(-1, 4)
+    pac[p >> 2:(p + len(seg)) >> 2] = (q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]
+
+
+def plant_family(pac, contigs, rng, unit_len, n_copies, div_lo, div_hi, indel_per_base=0.0, revcomp=True, consensus=None):
+    """one repeat family on a packed genome, in place: a consensus of `unit_len` bases (a stretch of the genome unless given) and `n_copies`
+    copies of it at random places of the primary contigs, each with its own divergence d ~ U(div_lo, div_hi) from the consensus (substitutions at
+    rate d, indels of 1-8 bases at `indel_per_base`, the copy cut or padded back to unit_len), on either strand.  Two copies differ from each
+    other by about the sum of their divergences.  Returns [(global position, unit_len)]."""
+    import numpy as np
+    lens = np.array([c[1] for c in contigs], dtype=np.int64)
+    offs = np.array([c[2] for c in contigs], dtype=np.int64)
+    w = lens / lens.sum()
+    unit_len = unit_len // 4 * 4
+
+    def place():
+        k = int(rng.choice(len(contigs), p=w))
+        return int(offs[k] + int(rng.integers(0, max(1, (lens[k] - unit_len) // 4))) * 4)
+
+    if consensus is None:
+        consensus = _unpack(pac, place(), unit_len).copy()
+    out = []
+    for _ in range(n_copies):
+        d = float(rng.uniform(div_lo, div_hi))
+        seg = consensus.copy()
+        m = rng.random(unit_len) < d
+        seg[m] = (seg[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+        n_indel = int(rng.poisson(indel_per_base * unit_len)) if indel_per_base > 0 else 0
+        if n_indel:
+            parts, last = [], 0
+            for at in np.sort(rng.integers(10, unit_len - 10, size=n_indel)):
+                at, ln = int(at), 1 + int(rng.integers(0, 8))
+                if at < last:
+                    continue
+                parts.append(seg[last:at])
+                if rng.random() < 0.5:
+                    last = min(unit_len, at + ln)                                   # deletion
+                else:
+                    parts.append(rng.integers(0, 4, size=ln).astype(np.uint8))      # insertion
+                    last = at
+            parts.append(seg[last:])
+            seg = np.concatenate(parts)
+            if len(seg) < unit_len:
+                seg = np.concatenate([seg, rng.integers(0, 4, size=unit_len - len(seg)).astype(np.uint8)])
+            seg = seg[:unit_len]
+        if revcomp and rng.random() < 0.5:
+            seg = (3 - seg[::-1]).astype(np.uint8)
+        p = place()
+        _repack(pac, p, np.ascontiguousarray(seg))
+        out.append((p, unit_len))
+    return out
+
+
+def windows_on(contigs, copies, flank):
+    """[(name, len, offset)] of windows over planted copies +- flank, clipped to their contigs: passed to lh_synth_reads as its contig
+    list, so that every molecule (and so every read) lies ON a copy or within `flank` of one"""
+    import numpy as np
+    offs = np.array([c[2] for c in contigs], dtype=np.int64)
+    out = []
+    for k, (p, n) in enumerate(copies):
+        ci = int(np.searchsorted(offs, p, side="right")) - 1
+        off, ln = contigs[ci][2], contigs[ci][1]
+        b = max(off, p - flank)
+        e = min(off + ln, p + n + flank)
+        if e - b >= 2000:
+            out.append(("w%d" % k, int(e - b), int(b)))
+    return out
+
+
+def config4_genome(lib, total_bases, seed=GENOME_SEED + 4, scale=1.0, n_alt=40, alt_len=1000000, threads=0, flank=2000, quiet=True):
+    """configs[4]'s reference and the windows its reads are drawn from.  At scale 1 (hg38 size):
+      * 120 segmental-duplication families of 50-200 copies x 20 kb, each copy 0.25-1 % off its family's consensus (pairs of copies at 98-99.5 %),
+        with an indel per ~4 kb, either strand: ~300 Mb, as much of the genome as real segmental duplications take (5-10 %);
+      * 40 families of 100-400 copies x 6 kb at 1-4 % from the consensus (LINE-like), 80 families of 500-3,000 copies x 300 bp at 2-10 % (SINE-like);
+      * `n_alt` ALT contigs: copies of `alt_len` bases of the primary assembly at 99.7 %, flagged is_alt as <prefix>.alt would.
+    `scale` multiplies the numbers of families (small genomes of the tests).  Reads are drawn on the copies +- `flank` (<= 2 kb).
+    Returns dict(pac, l_pac, contigs, alt_flags, windows, families=[(kind, [(pos, len)])])."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    ctg = hg38_like_contigs(int(total_bases))
+    l_pac = sum(c[1] for c in ctg)
+    pac = lib.synth_genome(l_pac, seed=seed, threads=threads)
+    fams = []
+    n_sd, n_l, n_s = max(1, int(round(120 * scale))), max(1, int(round(40 * scale))), max(1, int(round(80 * scale)))
+    for _ in range(n_s):   # the short ones first: later, longer copies overwrite some of them (old repeats inside young duplications)
+        fams.append(("sine300", plant_family(pac, ctg, rng, 300, int(rng.integers(500, 3001)), 0.02, 0.10, indel_per_base=1 / 300.0)))
+    for _ in range(n_l):
+        fams.append(("line6k", plant_family(pac, ctg, rng, 6000, int(rng.integers(100, 401)), 0.01, 0.04, indel_per_base=1 / 1500.0)))
+    for _ in range(n_sd):
+        fams.append(("segdup20k", plant_family(pac, ctg, rng, 20000, int(rng.integers(50, 201)), 0.0025, 0.01, indel_per_base=1 / 4000.0)))
+    alt_flags = [0] * len(ctg)
+    ctg_all, alts = ctg, []
+    if n_alt:
+        pac, l_pac, ctg_all, alt_flags, alts = add_alt_contigs(pac, ctg, n_alt, min(alt_len, l_pac // 200 // 4 * 4), 0.997, seed=seed + 1)
+    win = []
+    for kind, copies in fams:
+        win += windows_on(ctg_all, copies, flank if kind != "sine300" else min(flank, 850))
+    for src, dst, n in alts:   # reads from the ALT contigs and from the primary regions they copy: 2 kb windows spread over them, one per 25 kb
+        for p0 in (src, dst):
+            win += windows_on(ctg_all, [(p0 + o, 2000) for o in range(0, n - 2000, 25000)], 1000)
+    if not quiet:
+        print("config4 genome: %d Mb, %d families, %d copies, %d windows (%.0f Mb)" % (l_pac // 1000000, len(fams), sum(len(c) for _, c in fams), len(win), sum(w[1] for w in win) / 1e6))
+    return dict(pac=pac, l_pac=l_pac, contigs=ctg_all, alt_flags=alt_flags, windows=win, families=fams)

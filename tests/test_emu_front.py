@@ -285,6 +285,10 @@ def test_emu_second_chance_paths(oracle):
     ctx = idx.context(rs.n_pairs)
     helpers.assert_same_dump(ctx.stage_dump(b), od, helpers.DUMP_FRONT + helpers.DUMP_REGS)
     helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b), inference=True)
+    # ... and when more reads need a slot of that slab than it has, the slab grows and the reads left out run again (three slots for ~100 reads)
+    tiny = idx.context(rs.n_pairs, big_slots=3)
+    helpers.assert_same_dump(tiny.stage_dump(b), od, helpers.DUMP_FRONT + helpers.DUMP_REGS)
+    helpers.assert_same_result(tiny.align_barcodes(b), oidx.align_barcodes(b), inference=True)
 
 
 def test_emu_overlapped_download_and_staged_upload(emu, oracle):

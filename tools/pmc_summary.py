@@ -44,8 +44,11 @@ def main():
     if a.out:
         import hashlib, os
         cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lariat_amd", "csrc")
-        srcs = {f: hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(cs)) if f.startswith("k_") and f.endswith(".h")}
-        doc = {"commit": a.commit, "command": a.command, "note": a.note, "kernel_sources": srcs,   # bench.py reports traffic only while these still match "units": "FETCH_SIZE_KB / WRITE_SIZE_KB: KB summed over the kernel's dispatches; calls = dispatches",
+        # every device-side source (kernels, lh_dev.h, the host files that set launch geometry and streams): bench.py reports traffic only while
+        # these still match (bench.pmc_is_stale uses the same list)
+        srcs = {f: hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(cs)) if f.endswith((".h", ".inc", ".hip"))}
+        doc = {"commit": a.commit, "command": a.command, "note": a.note, "kernel_sources": srcs,
+               "units": "FETCH_SIZE_KB / WRITE_SIZE_KB: KB summed over the kernel's dispatches; calls = dispatches",
                "random_read_ceiling_Gaccess_per_s": a.ceiling, "kernels": kernels}
         json.dump(doc, open(a.out, "w"), indent=1, sort_keys=True)
     else:
