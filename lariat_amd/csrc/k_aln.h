@@ -8,7 +8,7 @@
 // writes the others to a list; k_aln (one WAVE per listed candidate) runs the banded global alignment with traceback.
 // Measured: one wave per read for everything was a chain of ~10 dependent phases per candidate (11.7 ms per 2 M reads).
 #pragma once
-#include "k_rescue.h"
+#include "k_rescue2.h"
 #include "k_extend2.h"   // LaneTgt
 
 #define LH_MAXT 704                       // reference bases staged per candidate (re - rb)

@@ -1,0 +1,437 @@
+// k_rescue2.h — K6 when rescue is the bulk of the work (BASELINE configs[4]: reads on segmental duplications and repeat families, where
+// GoBwaMemMateSW, gobwa.go:286-325, asks for up to 50 + 50 mem_matesw calls per pair — 100 k DP cells each).
+//
+// The loop of gobwa.go is sequential per pair (every attempt's first test looks at the regions rescued so far), but the Smith-Waterman of an
+// attempt depends on its anchor alone: the window [a.rb + low - l_ms, a.rb + high) and the mate's bases.  So, per direction (read 1 from read 2's
+// hits, then read 2 from read 1's post-rescue hits):
+//   k_resc_count / k_resc_emit   one lane per pair: the attempts that get past mem_matesw's first test against the regions the mate has NOW
+//                                become jobs, bucketed by the striping of their query (slen = ceil(qlen / 16));
+//   k_resc_sw<false>             ksw_u8's forward pass over every job, 8 jobs per wave (below);
+//   k_resc_sw<true>              the reverse pass (KSW_XSTART) of the jobs that reached min_seed_len, bucketed by THEIR striping;
+//   k_resc_apply                 one wave per pair replays the loop in order with the jobs' results at hand: first test against the CURRENT
+//                                regions, insert, mem_sort_dedup_patch — an attempt that has become unnecessary drops its job's result, one that
+//                                has become necessary (a region that made it unnecessary was merged away) runs k_rescue.h's wave kernel in place.
+//
+// The DP.  ksw_u8 is Farrar's striped kernel: lane L of 16 owns query columns [L * slen, (L + 1) * slen), F runs along a stripe inside the
+// main loop (F_seg: restarted at every stripe) and reaches later stripes only through the lazy-F loop, which repairs H but not E
+// (k_rescue.h has the closed form: H_main = max(hnf, F_seg) feeds E and the row maximum, H' = max(hnf, F_full) is what the next row sees).
+// Here a job is a SYSTOLIC ARRAY of the same 16 stripes: 16 lanes, lane L works on row s - L at step s, its slen columns one after the
+// other in registers — F_seg and F_full are two running values, F_full and the diagonal H enter from lane L - 1 (one DPP row shift
+// each per step), nothing is scanned and nothing goes through LDS but the target base.  All cells are 16-bit halves of packed words
+// (v_pk_max_u16, v_pk_sub_u16 clamp = the saturating arithmetic of the SSE code): a lane carries TWO jobs, a wave 8.
+// Rows before a job's first and after its last are fed a target base that matches nothing: every cell of such a row is at most the
+// value of an earlier cell, so neither "first row that beats the maximum" nor "first row that reaches endsc" can fire there.
+#pragma once
+#include "k_rescue.h"
+
+#ifdef LH_EMU
+__device__ __forceinline__ uint32_t pk_lanes(uint32_t a, uint32_t b, int op) {
+    uint32_t r = 0;
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t x = (a >> (16 * h)) & 0xffffu, y = (b >> (16 * h)) & 0xffffu;
+        uint32_t v = op == 0 ? (x > y ? x : y) : op == 1 ? (x < y ? x : y) : op == 2 ? ((x + y) & 0xffffu) : op == 3 ? (x > y ? x - y : 0) : ((x - y) & 0xffffu);
+        r |= v << (16 * h);
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return pk_lanes(a, b, 0); }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return pk_lanes(a, b, 1); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_lanes(a, b, 2); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return pk_lanes(a, b, 3); }   // saturating at 0
+__device__ __forceinline__ uint32_t pk_subw(uint32_t a, uint32_t b) { return pk_lanes(a, b, 4); }   // wrapping
+__device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) { uint32_t o = __shfl_up(v, 1); return (LANE() & 15) == 0 ? 0u : o; }
+#else
+typedef unsigned short lh_us2 __attribute__((ext_vector_type(2)));
+#define LH_US2(x) __builtin_bit_cast(lh_us2, (uint32_t)(x))
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(LH_US2(a), LH_US2(b))); }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(LH_US2(a), LH_US2(b))); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (lh_us2)(LH_US2(a) + LH_US2(b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(LH_US2(a), LH_US2(b))); }
+__device__ __forceinline__ uint32_t pk_subw(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (lh_us2)(LH_US2(a) - LH_US2(b))); }
+__device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); }   // row_shr:1, lane 0 of a row: 0
+#endif
+__device__ __forceinline__ int grp16_min(int v) { for (int m = 8; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v < o ? v : o; } return v; }
+__device__ __forceinline__ int grp16_max(int v) { for (int m = 8; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v > o ? v : o; } return v; }
+
+#define LH_RJ_TMAX (LH_MAXLEN + 560)        // longest window: pes_high - pes_low + l_ms (lariat: 535 + l_ms)
+#define LH_RJ_TSLOT (16 + LH_RJ_TMAX + 16)  // a job's target bases in LDS: 16 non-matching rows in front and behind (the systolic skew)
+#define LH_RJ_NB 17                         // buckets: slen 0 .. 16
+
+struct RJob {
+    i64 t0;                          // window start (fwd||rev coordinate): target row i = base at t0 + i
+    int32_t q0;                      // index in seq[] of the mate's LAST base: query column k = complement of seq[q0 - k]
+    int32_t pair;
+    int16_t qlen, tlen, anchor;      // anchor: index of the anchoring region in the other mate's list
+    int16_t score, te, qe, tb, qb;   // ksw_align2's result; tb = qb = -1: no start
+    int16_t rows2, pad_;             // rows the reverse pass executed (its cells: 16 * slen(qe + 1) * rows2)
+};
+struct RMeta {   // per direction, on the device
+    int32_t hist[LH_RJ_NB], bstart[LH_RJ_NB + 1], bcur[LH_RJ_NB];       // forward jobs by slen; bstart: bucket starts in the order array, each padded to 8
+    int32_t hist2[LH_RJ_NB], bstart2[LH_RJ_NB + 1], bcur2[LH_RJ_NB];    // reverse jobs
+    int32_t list_count, pad_;
+};
+
+// which attempts of one pair and direction get past mem_matesw's first test ("a consistent pair exists; no need to perform SW") against the
+// mate's regions as they are now, and have a window (bns_fetch_seq's clamp leaves the anchor's contig, at least min_seed_len bases)
+struct RescWalk {
+    const DReg *from, *ma;
+    int nf, nm, bestf, l_ms, r_ms;
+    __device__ __forceinline__ void init(int dir, int p, const i64* seq_off, const i64* reg_off, const DReg* regs, const int32_t* n_regs, const int32_t* best_score) {
+        const int r1 = 2 * p, r2 = 2 * p + 1;
+        int l1 = (int)(seq_off[r2] - seq_off[r1]), l2 = (int)(seq_off[r2 + 1] - seq_off[r2]);
+        if (l1 > LH_MAXLEN) l1 = 0;
+        if (l2 > LH_MAXLEN) l2 = 0;
+        from = regs + reg_off[dir ? r1 : r2]; ma = regs + reg_off[dir ? r2 : r1];
+        nf = n_regs[dir ? r1 : r2]; nm = n_regs[dir ? r2 : r1];
+        bestf = best_score[dir ? r1 : r2]; l_ms = dir ? l2 : l1; r_ms = dir ? r2 : r1;
+    }
+};
+__device__ __forceinline__ int resc_window(const DIndex& ix, const DOpts& o, const DReg& a, int l_ms, i64* rb_out, i64* re_out) {
+    i64 rb = a.rb + o.pes_low - l_ms, re = a.rb + o.pes_high;
+    if (rb < 0) rb = 0;
+    if (re > ix.l_pac << 1) re = ix.l_pac << 1;
+    int rid = -1;
+    if (rb < re) rid = dev_fetch_clamp(ix, &rb, (rb + re) >> 1, &re);
+    *rb_out = rb; *re_out = re;
+    return a.rid == rid && re - rb >= o.min_seed_len;
+}
+// what the packed kernel holds: 8-bit scores next to an 8-bit column key, one-hot bases with a + b <= 16, windows of LH_RJ_TMAX rows, no N in the mate
+__device__ __forceinline__ int resc_fast_ok(const DOpts& o, int l_ms, i64 tlen) {
+    return l_ms * o.a < 250 && o.a + o.b <= 16 && o.a > 0 && o.b >= 0 && o.o_del + o.e_del < 256 && o.o_ins + o.e_ins < 256 && tlen <= LH_RJ_TMAX && l_ms >= 1;
+}
+
+// One lane per pair.  EMIT = false: count the pair's jobs (n_jobs[p]), their bucket's histogram, and list the pairs with any attempt to
+// replay.  EMIT = true (after the scan of n_jobs and k_resc_offsets): write the jobs and their places in the order array.
+template <int DIR, bool EMIT>
+__global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
+                                                    const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, const int32_t* __restrict__ best_score, int32_t* __restrict__ n_jobs,
+                                                    const i64* __restrict__ job_off, RJob* __restrict__ jobs, int32_t* __restrict__ order, RMeta* __restrict__ meta,
+                                                    int32_t* __restrict__ list) {
+    __shared__ int32_t sh_hist[LH_RJ_NB];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    if (!EMIT) { if (threadIdx.x < LH_RJ_NB) sh_hist[threadIdx.x] = 0; __syncthreads(); }
+    int nj = 0, need = 0, slen = 0, obase = 0;
+    if (EMIT) {   // the pair's places in the order array: one reservation per wave and bucket
+        const int want = p < n_pairs ? n_jobs[p] : 0;
+        if (want) { const i64 so = seq_off[DIR ? 2 * p + 1 : 2 * p]; int l = (int)(seq_off[(DIR ? 2 * p + 1 : 2 * p) + 1] - so); slen = ((l > LH_MAXLEN ? 0 : l) + 15) / 16; }
+        u64 todo = __ballot(want > 0);
+        while (todo) {
+            const int lead = __ffsll((unsigned long long)todo) - 1;
+            const int sl = wave_readlane(slen, lead);
+            const int mine = want > 0 && slen == sl;
+            const int incl = wave_scan_add_i32(mine ? want : 0);
+            const int tot = wave_readlane(incl, 63);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&meta->bcur[sl], tot);
+            base = wave_readlane(base, 0);
+            if (mine) obase = meta->bstart[sl] + base + incl - want;
+            todo &= ~__ballot(mine);
+        }
+    }
+    if (p < n_pairs) {
+        RescWalk w;
+        w.init(DIR, p, seq_off, reg_off, regs, n_regs, best_score);
+        slen = (w.l_ms + 15) / 16;
+        int has_n = -1;   // unknown
+        i64 jbase = EMIT ? job_off[p] : 0;
+        int num = 0;
+        for (int i = 0; i < w.nf && num < o.rescue_max_hits && w.l_ms > 0; ++i) {
+            const DReg a = w.from[i];
+            if (a.score < w.bestf - o.rescue_score_delta) continue;
+            num++;
+            int skip1 = 0;
+            for (int j = 0; j < w.nm && !skip1; ++j) {
+                i64 dist;
+                int r = dev_infer_dir(ix.l_pac, a.rb, w.ma[j].rb, &dist);
+                skip1 = (r == 1 && dist >= o.pes_low && dist <= o.pes_high);
+            }
+            if (skip1) continue;
+            i64 rb, re;
+            if (!resc_window(ix, o, a, w.l_ms, &rb, &re)) continue;
+            need = 1;
+            if (!resc_fast_ok(o, w.l_ms, re - rb)) continue;
+            if (has_n < 0) {   // an ambiguous base in the mate scores -1 against everything: left to the wave kernel (k_resc_apply)
+                has_n = 0;
+                const i64 so = seq_off[w.r_ms];
+                for (int k = 0; k < w.l_ms; ++k) has_n |= seq[so + k] > 3;
+            }
+            if (has_n) continue;
+            if (EMIT) {
+                RJob jb;
+                jb.t0 = rb; jb.q0 = (int32_t)(seq_off[w.r_ms] + w.l_ms - 1); jb.pair = p;
+                jb.qlen = (int16_t)w.l_ms; jb.tlen = (int16_t)(re - rb); jb.anchor = (int16_t)i;
+                jb.score = 0; jb.te = -1; jb.qe = -1; jb.tb = -1; jb.qb = -1; jb.rows2 = 0; jb.pad_ = 0;
+                jobs[jbase + nj] = jb;
+                order[obase + nj] = (int32_t)(jbase + nj);
+            }
+            nj++;
+        }
+        if (!EMIT) n_jobs[p] = nj;
+    }
+    if (!EMIT) {
+        if (nj) atomicAdd(&sh_hist[slen], nj);
+        u64 m = __ballot(need);
+        if (m) {
+            int basep = 0;
+            if (lane == 0) basep = atomicAdd(&meta->list_count, (int32_t)__popcll(m));
+            basep = wave_readlane(basep, 0);
+            if (need) list[basep + lanes_below(m, lane)] = p;
+        }
+        __syncthreads();
+        if (threadIdx.x < LH_RJ_NB && sh_hist[threadIdx.x]) atomicAdd(&meta->hist[threadIdx.x], sh_hist[threadIdx.x]);
+    }
+}
+
+// bucket starts (each bucket padded to a multiple of 8 jobs: a wave's 8 jobs share their striping); which = 0: forward, 1: reverse
+__global__ void k_resc_offsets(RMeta* __restrict__ meta, int which, i64* __restrict__ peek_host, const i64* __restrict__ total_jobs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t* h = which ? meta->hist2 : meta->hist;
+    int32_t* bs = which ? meta->bstart2 : meta->bstart;
+    int32_t* bc = which ? meta->bcur2 : meta->bcur;
+    int acc = 0;
+    for (int s = 0; s < LH_RJ_NB; ++s) { bs[s] = acc; bc[s] = 0; acc += (h[s] + 7) & ~7; }
+    bs[LH_RJ_NB] = acc;
+    if (peek_host) { peek_host[0] = *total_jobs; peek_host[1] = acc; peek_host[2] = meta->list_count; }
+}
+
+// the reverse passes (jobs whose forward pass reached minsc) by the striping of THEIR query, the prefix that ends at qe.  A block takes a
+// contiguous share of the jobs; SCATTER = false: histogram (one atomic per block and bucket), SCATTER = true (after k_resc_offsets): places.
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_resc_bucket2(i64 n_jobs, const RJob* __restrict__ jobs, int minsc, RMeta* __restrict__ meta, int32_t* __restrict__ order2) {
+    __shared__ int32_t sh_n[LH_RJ_NB], sh_base[LH_RJ_NB];
+    if (threadIdx.x < LH_RJ_NB) sh_n[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 per = (n_jobs + gridDim.x - 1) / gridDim.x, j0 = per * blockIdx.x, j1 = j0 + per < n_jobs ? j0 + per : n_jobs;
+    for (i64 j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const RJob& jb = jobs[j];
+        if (jb.score < minsc || jb.te < 0 || jb.qe < 0) continue;
+        atomicAdd(&sh_n[(jb.qe + 1 + 15) / 16], 1);
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        if (threadIdx.x < LH_RJ_NB && sh_n[threadIdx.x]) atomicAdd(&meta->hist2[threadIdx.x], sh_n[threadIdx.x]);
+        return;
+    }
+    if (threadIdx.x < LH_RJ_NB) { sh_base[threadIdx.x] = sh_n[threadIdx.x] ? meta->bstart2[threadIdx.x] + atomicAdd(&meta->bcur2[threadIdx.x], sh_n[threadIdx.x]) : 0; sh_n[threadIdx.x] = 0; }
+    __syncthreads();
+    for (i64 j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const RJob& jb = jobs[j];
+        if (jb.score < minsc || jb.te < 0 || jb.qe < 0) continue;
+        const int s2 = (jb.qe + 1 + 15) / 16;
+        order2[sh_base[s2] + atomicAdd(&sh_n[s2], 1)] = (int32_t)j;
+    }
+}
+
+// ksw_u8 for the 8 jobs ord[0..7] (-1: none), all of striping SLEN.  REV: the pass of KSW_XSTART over the reversed prefixes that end at
+// the forward pass's (te, qe), stopped at the first row that reaches the forward score.
+template <int SLEN, bool REV>
+__device__ __forceinline__ void resc_sw_run(const DIndex& ix, const DOpts& o, RJob* __restrict__ jobs, const int32_t* __restrict__ ord, const uint8_t* __restrict__ seq, uint8_t* tl,
+                                            RMeta* __restrict__ meta, int lane) {
+    const int g = lane >> 4, L = lane & 15;
+    // ---- the windows' bases into LDS, one-hot (16 << base): row i of slot u at tl[u * LH_RJ_TSLOT + 16 + i]
+    for (int i = lane; i < 8 * LH_RJ_TSLOT / 4; i += 64) ((uint32_t*)tl)[i] = 0;
+    WAVE_SYNC();
+    int max_t = 0;
+    for (int u = 0; u < 8; ++u) {
+        const int ju = ord[u];
+        if (ju < 0) continue;
+        const RJob& J = jobs[ju];
+        const int tlen = REV ? J.te + 1 : J.tlen;
+        const i64 t0 = REV ? J.t0 + J.te : J.t0;
+        for (int i = lane; i < tlen; i += 64) tl[u * LH_RJ_TSLOT + 16 + i] = (uint8_t)(16 << dev_ref_base(ix, REV ? t0 - i : t0 + i));
+        max_t = max_t > tlen ? max_t : tlen;
+    }
+    WAVE_SYNC();
+    // ---- this lane's two jobs (halves of every packed word) and its columns
+    const int jA = ord[2 * g], jB = ord[2 * g + 1];
+    int qlenA = 0, qlenB = 0, endA = 0x100, endB = 0x100;
+    i64 qbA = 0, qbB = 0;
+    if (jA >= 0) { const RJob& J = jobs[jA]; qlenA = REV ? J.qe + 1 : J.qlen; qbA = REV ? (i64)J.q0 - J.qe : (i64)J.q0; endA = J.score; }
+    if (jB >= 0) { const RJob& J = jobs[jB]; qlenB = REV ? J.qe + 1 : J.qlen; qbB = REV ? (i64)J.q0 - J.qe : (i64)J.q0; endB = J.score; }
+    uint32_t Hp[SLEN], E[SLEN], Q[SLEN], Bc[SLEN];
+#pragma unroll
+    for (int j = 0; j < SLEN; ++j) {
+        const int k = L * SLEN + j;
+        uint32_t q = 0, bc = 0;
+        if (k < qlenA) { const int v = seq[REV ? qbA + k : qbA - k]; q |= v < 4 ? 16u << (3 - v) : 0u; bc |= (uint32_t)(v < 4 ? o.b : 1); }
+        if (k < qlenB) { const int v = seq[REV ? qbB + k : qbB - k]; q |= (v < 4 ? 16u << (3 - v) : 0u) << 16; bc |= (uint32_t)(v < 4 ? o.b : 1) << 16; }
+        Hp[j] = 0; E[j] = 0; Q[j] = q; Bc[j] = bc;
+    }
+    const uint32_t c_ab = (uint32_t)(o.a + o.b) * 0x10001u, c_ed = (uint32_t)o.e_del * 0x10001u, c_oed = (uint32_t)(o.o_del + o.e_del) * 0x10001u;
+    const uint32_t c_ei = (uint32_t)o.e_ins * 0x10001u, c_oei = (uint32_t)(o.o_ins + o.e_ins) * 0x10001u;
+    uint32_t pubH = 0, pubF = 0, inH = 0, brow = 0, bkey = 0, fnd = 0;
+    uint32_t bestv = REV ? ((uint32_t)(endA - 1) << 8 | (uint32_t)(endB - 1) << 24) : 0u;   // REV: "greater than endsc - 1" = "reaches endsc"
+    const uint8_t* tA = tl + (2 * g) * LH_RJ_TSLOT + 16 - L;
+    const uint8_t* tB = tl + (2 * g + 1) * LH_RJ_TSLOT + 16 - L;
+    const int nsteps = max_t + 15;
+    for (int s = 0; s < nsteps; ++s) {
+        const uint32_t fin = dpp_row_shr1(pubF), hin = dpp_row_shr1(pubH);   // lane L - 1's row s - L: its last column's H', its F_full carry
+        uint32_t hd = inH;                                                   // ... and its row s - L - 1: the diagonal of this lane's first column
+        inH = hin;
+        const uint32_t t1h = (uint32_t)tA[s] | (uint32_t)tB[s] << 16;
+        uint32_t fseg = 0, ffull = fin, rowkey = 0;
+#pragma unroll
+        for (int j = 0; j < SLEN; ++j) {
+            const uint32_t m = pk_min(Q[j] & t1h, c_ab);                     // a + b where the bases match
+            uint32_t hnf = pk_subs(pk_add(hd, m), Bc[j]);                    // H'(i-1,k-1) + S, floored at 0 (S = a | -b | -1 | 0 past the query)
+            hnf = pk_max(hnf, E[j]);
+            const uint32_t hmain = pk_max(hnf, fseg), hfull = pk_max(hnf, ffull);
+            rowkey = pk_max(rowkey, hmain << 8 | (uint32_t)(255 - j) * 0x10001u);   // the row's maximum and, in its low byte, the smallest column that has it
+            E[j] = pk_max(pk_subs(E[j], c_ed), pk_subs(hmain, c_oed));
+            const uint32_t u = pk_subs(hnf, c_oei);
+            fseg = pk_max(pk_subs(fseg, c_ei), u);
+            ffull = pk_max(pk_subs(ffull, c_ei), u);
+            hd = Hp[j]; Hp[j] = hfull;
+        }
+        pubH = Hp[SLEN - 1]; pubF = ffull;
+        // the stripe's first row that beats its maximum so far (REV: that reaches endsc; then it is locked)
+        const uint32_t nb = pk_max(bestv, rowkey & 0xff00ff00u);
+        const uint32_t msk = pk_subw(0u, pk_min(nb ^ bestv, 0x10001u));     // 0xffff in the halves that improved
+        const uint32_t rowpk = ((uint32_t)(s - L) & 0xffffu) * 0x10001u;
+        brow = (brow & ~msk) | (rowpk & msk);
+        bkey = (bkey & ~msk) | (rowkey & msk);
+        bestv = REV ? (nb | (msk & 0xff00ff00u)) : nb;
+        if (REV) {
+            fnd |= msk;
+            if ((s & 7) == 7) {   // a job is settled once every stripe has passed the earliest row found: s - 15 >= that row
+                const int rA = (fnd & 0xffffu) ? (int)(brow & 0xffffu) : 0x7fff, rB = (fnd >> 16) ? (int)(brow >> 16) : 0x7fff;
+                const int mA = grp16_min(rA), mB = grp16_min(rB);
+                const int doneA = jA < 0 || mA + 15 <= s, doneB = jB < 0 || mB + 15 <= s;
+                if (__all(doneA && doneB)) break;
+            }
+        }
+    }
+    // ---- the 16 stripes' answers -> the job's
+    for (int h = 0; h < 2; ++h) {
+        const int jj = h ? jB : jA;
+        const int v = (int)((bkey >> (16 * h + 8)) & 0xffu), r = (int)((brow >> (16 * h)) & 0xffffu), kc = (int)((bkey >> (16 * h)) & 0xffu);
+        const int hit = REV ? (int)((fnd >> (16 * h)) & 1u) : (v > 0);
+        // FWD: te = the first row of the global maximum; REV: the first row that reached endsc, its maximum over the stripes that did so there
+        const int vmax = grp16_max(hit ? v : 0);
+        const int te = grp16_min(hit && (REV || v == vmax) ? r : 0x7fff);
+        const int gmax = REV ? grp16_max(hit && r == te ? v : 0) : vmax;
+        const int win = hit && v == gmax && r == te;
+        const int wl = grp16_min(win ? L : 16);   // the lowest stripe holds the smallest column
+        if (jj >= 0 && L == (wl < 16 ? wl : 0)) {
+            RJob& J = jobs[jj];
+            const int qe = wl < 16 ? L * SLEN + (255 - kc) : -1;
+            if (!REV) {
+                J.score = (int16_t)gmax; J.te = (int16_t)(wl < 16 ? te : -1); J.qe = (int16_t)qe;
+            } else {
+                const int tlen2 = J.te + 1;
+                J.rows2 = (int16_t)(wl < 16 ? te + 1 : tlen2);
+                if (wl < 16 && gmax == J.score) { J.tb = (int16_t)(J.te - te); J.qb = (int16_t)(J.qe - qe); }
+            }
+        }
+    }
+}
+
+template <bool REV>
+__global__ void __launch_bounds__(64) k_resc_sw(DIndex ix, DOpts o, RJob* __restrict__ jobs, const int32_t* __restrict__ order, const uint8_t* __restrict__ seq, RMeta* __restrict__ meta) {
+    __shared__ __attribute__((aligned(16))) uint8_t tl[8 * LH_RJ_TSLOT];
+    const int lane = LANE();
+    const int32_t* bs = REV ? meta->bstart2 : meta->bstart;
+    const int first = blockIdx.x * 8;
+    if (first >= bs[LH_RJ_NB]) return;
+    int slen = 0;
+    for (int s = 1; s < LH_RJ_NB; ++s) if (first >= bs[s]) slen = s;   // the bucket this wave's jobs are in
+    const int32_t* ord = order + first;
+    switch (slen) {
+#define LH_RSW(n) case n: resc_sw_run<n, REV>(ix, o, jobs, ord, seq, tl, meta, lane); break;
+        LH_RSW(1) LH_RSW(2) LH_RSW(3) LH_RSW(4) LH_RSW(5) LH_RSW(6) LH_RSW(7) LH_RSW(8) LH_RSW(9) LH_RSW(10) LH_RSW(11) LH_RSW(12) LH_RSW(13) LH_RSW(14) LH_RSW(15) LH_RSW(16)
+#undef LH_RSW
+        default: break;
+    }
+}
+
+// One wave per listed pair: mem_matesw's loop for one direction (gobwa.go:286-301 or 309-325) with the Smith-Waterman results of the pair's jobs.
+template <int DIR>
+__global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
+                                                    DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool, int32_t* __restrict__ n_regs,
+                                                    const int32_t* __restrict__ best_score, DCounters* __restrict__ ctr, const int32_t* __restrict__ list, const RMeta* __restrict__ meta,
+                                                    const int32_t* __restrict__ n_jobs, const i64* __restrict__ job_off, const RJob* __restrict__ jobs) {
+    __shared__ uint8_t qm[LH_MAXLEN + 6];
+    const int lane = LANE();
+    const int n_items = meta->list_count;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int p = list[item];
+        WAVE_SYNC();   // the previous pair's query is no longer in use
+        const int r1 = 2 * p, r2 = 2 * p + 1;
+        const int r_ms = DIR ? r2 : r1, r_from = DIR ? r1 : r2;
+        const i64 off_ms = seq_off[r_ms];
+        int l_ms = (int)(seq_off[r_ms + 1] - off_ms);
+        if (l_ms > LH_MAXLEN) l_ms = 0;
+        for (int i = lane; i < l_ms; i += 64) qm[i] = seq[off_ms + i];
+        WAVE_SYNC();
+        const i64 ro_ms = reg_off[r_ms];
+        DReg* ma = regs + ro_ms;
+        const DReg* from = regs + reg_off[r_from];
+        int n_ma = n_regs[r_ms];
+        const int nf = n_regs[r_from], bestf = best_score[r_from];
+        const RJob* pj = jobs + job_off[p];
+        const int npj = n_jobs[p];
+        int jp = 0;
+        u64 cells = 0;
+        int n_sw = 0, num = 0;
+        for (int i = 0; i < nf && num < o.rescue_max_hits && l_ms > 0; ++i) {
+            const DReg a = from[i];
+            if (a.score < bestf - o.rescue_score_delta) continue;
+            num++;
+            while (jp < npj && pj[jp].anchor < i) ++jp;             // (jobs of attempts that have become unnecessary are passed over)
+            int skip1 = 0;
+            for (int i0 = 0; i0 < n_ma; i0 += 64) {                 // which orientation has been found
+                int k = i0 + lane, f = 0;
+                if (k < n_ma) {
+                    i64 dist;
+                    int r = dev_infer_dir(ix.l_pac, a.rb, ma[k].rb, &dist);
+                    f = (r == 1 && dist >= o.pes_low && dist <= o.pes_high);
+                }
+                if (__any(f)) { skip1 = 1; break; }
+            }
+            if (skip1) continue;
+            i64 rb, re;
+            if (!resc_window(ix, o, a, l_ms, &rb, &re)) continue;
+            n_sw++;
+            KswR aln;
+            if (jp < npj && pj[jp].anchor == i) {
+                const RJob J = pj[jp];
+                aln.score = J.score; aln.te = J.te; aln.qe = J.qe; aln.tb = J.tb; aln.qb = J.qb;
+                cells += (u64)(16 * ((l_ms + 15) / 16)) * (u64)J.tlen;
+                if (J.score >= o.min_seed_len * o.a) cells += (u64)(16 * ((J.qe + 1 + 15) / 16)) * (u64)J.rows2;
+            } else {   // no job: an attempt the enumeration saw as unnecessary (or left to this kernel): k_rescue.h's wave-wide kernel
+                aln = wave_ksw_align2(ix, o, qm, l_ms - 1, -1, 1, l_ms, rb, 1, (int)(re - rb), o.min_seed_len * o.a, lane, &cells);
+            }
+            if (aln.score >= o.min_seed_len && aln.qb >= 0) {
+                DReg b;
+                b.rid = a.rid; b.is_alt = a.is_alt;
+                b.qb = l_ms - (aln.qe + 1); b.qe = l_ms - aln.qb;
+                b.rb = (ix.l_pac << 1) - (rb + aln.te + 1); b.re = (ix.l_pac << 1) - (rb + aln.tb);
+                b.score = aln.score; b.csub = 0; b.secondary = -1;
+                b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+                b.truesc = 0; b.sub = 0; b.w = 0; b.seedlen0 = 0; b.n_comp = 0; b.frac_rep = 0;
+                int pos = n_ma;   // before the first element with a smaller score
+                for (int i0 = 0; i0 < n_ma; i0 += 64) {
+                    int k = i0 + lane;
+                    u64 bm = __ballot(k < n_ma && ma[k].score < b.score);
+                    if (bm) { pos = i0 + __ffsll((unsigned long long)bm) - 1; break; }
+                }
+                for (int top = n_ma; top > pos; top -= 64) {
+                    int j = top - 1 - lane;
+                    DReg v;
+                    if (j >= pos) v = ma[j];
+                    WAVE_SYNC();
+                    if (j >= pos) ma[j + 1] = v;
+                    WAVE_SYNC();
+                }
+                if (lane == 0) ma[pos] = b;
+                n_ma++;
+                WAVE_SYNC();
+            }
+            n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells);
+        }
+        if (lane == 0) {
+            n_regs[r_ms] = n_ma;
+            if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); }
+        }
+    }
+}
