@@ -51,6 +51,39 @@ def parse():
     return ap.parse_args()
 
 
+def bind_to_device_numa_node(local_rank):
+    """pin this rank's host threads (read synthesis, the library's staging / BAM pools) to the NUMA node its GPU hangs off, BEFORE anything
+    touches HIP: the device's PCI address from the KFD topology in sysfs (GPU nodes in KFD order = HIP device order unless *_VISIBLE_DEVICES
+    re-maps them, which is honoured), its numa_node from the PCI device.  Returns what was done, for the line's per_rank."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(l.split()[:2] for l in open(os.path.join(base, n, "properties")) if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        if vis and all(v.strip().isdigit() for v in vis.split(",")):
+            gpus = [gpus[int(v)] for v in vis.split(",") if int(v) < len(gpus)]
+        g = gpus[local_rank]
+        loc, dom = int(g["location_id"]), int(g.get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return {"pci": bdf, "numa_node": None, "bound": False, "why": "the platform reports no NUMA node for the device"}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"pci": bdf, "numa_node": node, "bound": False, "why": "none of the node's CPUs are available to this process"}
+        os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "bound": True, "cpus": len(cpus)}
+    except Exception as e:   # no sysfs topology (a container without /sys/class/kfd): run unbound and say so
+        return {"bound": False, "why": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -63,6 +96,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # N > 1: every rank keeps to the NUMA node of its own GPU (8 ranks on a two-socket host would otherwise share one socket's memory
+    # controllers for their staging buffers); N = 1 keeps the whole host (its CPU-baseline leg uses every core)
+    numa = bind_to_device_numa_node(0 if os.environ.get("LH_BENCH_SHARE_GPU") == "1" else local_rank) if world > 1 else {"bound": False, "why": "single rank"}
+    n_cpus = len(os.sched_getaffinity(0))
+    host_threads = n_cpus if numa.get("bound") else max(1, n_cpus // max(1, world))   # host-side worker threads of this rank
     import numpy as np
     import torch
     dist = None
@@ -94,7 +132,7 @@ def main():
     t0 = time.time()
     ctg = workload.hg38_like_contigs(int(a.genome_mb * 1e6))
     l_pac = sum(c[1] for c in ctg)
-    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED, threads=max(1, (os.cpu_count() or 8) // max(1, world)))
+    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED, threads=host_threads)
     read_ctg = ctg
     if a.repeats:
         dups = workload.plant_segdups(pac, ctg, 1500, 20000, 0.99, seed=41, n_families=40, family_len=320, family_copies=60)
@@ -122,7 +160,7 @@ def main():
         if slot and lib.device_memory(local_rank)[0] < (16 << 30):   # leave room for the kernels' scratch: later steps reuse the resident batches in turn
             break
         r = lib.synth_reads(pac, l_pac, read_ctg, seed=workload.READS_SEED + g, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode,
-                            threads=max(1, (os.cpu_count() or 8) // max(1, world)))
+                            threads=host_threads)
         b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
         ctx.upload_slot(slot, b)
         n_slots = slot + 1
@@ -160,6 +198,10 @@ def main():
         dist.all_gather(allr, mine)   # a straggler (a slow index build, a slow rank) is visible in the line
         per_rank = [{"rank": i, "pairs_per_s": round(n_pairs * len(my_batches) / float(t[0]), 1), "timed_s": round(float(t[0]), 3), "index_build_s": round(float(t[1]), 2),
                      "genome_s": round(float(t[2]), 2), "reads_synth+upload_s": round(float(t[3]), 2)} for i, t in enumerate(allr)]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dict(numa, host_cpus=n_cpus))   # where every rank's host threads ran
+        for i, g in enumerate(gathered):
+            per_rank[i]["host_affinity"] = g
         te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())

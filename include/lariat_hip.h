@@ -356,6 +356,12 @@ int lh_synth_reads(const uint8_t* pac, int64_t l_pac, int32_t n_contigs, const i
  * each returns the permutation of every index space (position -> original index inside its space) */
 int lh_diag_gosort(int device, int32_t n_sorts, const int32_t* first, const int64_t* keys, int32_t* perm_serial, int32_t* perm_wave);
 int lh_diag_go_rand(int device, int64_t seed, int32_t n, uint64_t* out_fast, uint64_t* out_ring, double* out_f64);
+/* diagnostics: K6's exact shortcut for the mem_sort_dedup_patch(opt, 0, 0, 0, ...) that follows every mem_matesw attempt (gobwa.go:291,315 -> bwamem
+ * mem_matesw), against the call as written.  n_cases lists of regions [first[c], first[c+1]) (6 int64 each: rb, re, qb, qe, score, rid) and one region
+ * added[c] per case; verdict[c]: 0 = the incremental form and the full call agree on the resulting list, 1 = the incremental form declined (equal keys:
+ * the pipeline runs the full call), 2 = THEY DIFFER, 3 = the list itself has equal end positions (not eligible); n_out[c] = the full call's result length | the cleaned list's length << 16 */
+int lh_diag_rescue_dedup(int device, int32_t n_cases, const int32_t* first, const int64_t* regions, const int64_t* added, int32_t max_chain_gap, int32_t* verdict,
+                         int32_t* n_out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * N2 — 9-line barcode-sorted FASTQ ingest: go/src/fastqreader/reader.go (ReadOneLine :91-147,

@@ -391,6 +391,19 @@ class Library:
         self.check(self.L.lh_diag_random_read(device, int(table_bytes), int(granule_bytes), int(n_access), C.byref(g), C.byref(ms)))
         return g.value, ms.value
 
+    def diag_rescue_dedup(self, first, regions, added, max_chain_gap=10000, device=0):
+        """(verdict, n_out) per case — lh_diag_rescue_dedup"""
+        first = np.ascontiguousarray(first, dtype=np.int32)
+        regions = np.ascontiguousarray(regions, dtype=np.int64).reshape(-1, 6)
+        added = np.ascontiguousarray(added, dtype=np.int64).reshape(-1, 6)
+        nc = len(first) - 1
+        assert len(added) == nc and len(regions) == first[-1]
+        v, n = np.zeros(nc, dtype=np.int32), np.zeros(nc, dtype=np.int32)
+        self.L.lh_diag_rescue_dedup.argtypes = [C.c_int, C.c_int32, c_i32p, c_i64p, c_i64p, C.c_int32, c_i32p, c_i32p]
+        self.check(self.L.lh_diag_rescue_dedup(device, nc, first.ctypes.data_as(c_i32p), regions.ctypes.data_as(c_i64p), added.ctypes.data_as(c_i64p), int(max_chain_gap),
+                                               v.ctypes.data_as(c_i32p), n.ctypes.data_as(c_i32p)))
+        return v, n
+
     def diag_go_rand(self, seed, n, device=0):
         """(fast-path u64 draws, ring-path u64 draws, ring-path Float64 draws) of the device's Go math/rand source"""
         a, b, f = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.float64)
@@ -849,6 +862,6 @@ EXPORTED_SYMBOLS = [
     "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
     "lh_records_text", "lh_records_text_ex", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_set_flags", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
-    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_random_read", "lh_diag_go_rand",
+    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_random_read", "lh_diag_go_rand", "lh_diag_rescue_dedup",
     "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt", "lh_bam_set_level", "lh_bam_timings", "lh_result_download_begin", "lh_result_download_end", "lh_batch_stage_slot", "lh_host_alloc", "lh_host_free",
 ]

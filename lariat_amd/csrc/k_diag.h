@@ -100,3 +100,50 @@ __global__ void __launch_bounds__(64) k_diag_gosort(int n_sorts, const int32_t* 
     wave_gosort(n_sorts, first, [&](int i, int j) { return keys_b[i] < keys_b[j]; },
                 [&](int i, int j) { i64 t = keys_b[i]; keys_b[i] = keys_b[j]; keys_b[j] = t; int u = perm_wave[i]; perm_wave[i] = perm_wave[j]; perm_wave[j] = u; }, qa, qb, qd);
 }
+
+// K6's exact shortcut (k_rescue2.h: resc_dedup_incremental) against what it replaces, on arbitrary region lists: per case a list of regions
+// (6 values each: rb, re, qb, qe, score, rid) and one more region b.  The wave makes the list clean as the pipeline does (mem_sort_dedup_patch
+// once), then runs (a) the call as written on list + b in memory, (b) the incremental form on the list in LDS.  verdict[c]: 0 = equal, 1 = the
+// incremental form declined (equal keys), 2 = THEY DIFFER, 3 = the cleaned list has equal re (the pipeline would not use the LDS form).
+__global__ void __launch_bounds__(64) k_diag_resc_dedup(DIndex ix, DOpts o, int n_cases, const int32_t* __restrict__ first, const i64* __restrict__ vals, const i64* __restrict__ bvals,
+                                                        DReg* __restrict__ ra, DReg* __restrict__ rb_, DReg* __restrict__ tmp, int32_t* __restrict__ ia, int32_t* __restrict__ verdict,
+                                                        int32_t* __restrict__ n_out) {
+    __shared__ RescList W;
+    const int lane = LANE();
+    for (int c = blockIdx.x; c < n_cases; c += gridDim.x) {
+        WAVE_SYNC();
+        const int f0 = first[c], n0 = first[c + 1] - f0, stride = f0 + c;   // (room for one more entry per case)
+        DReg *A = ra + stride, *B = rb_ + stride, *T = tmp + stride;
+        int32_t* I = ia + stride + c;
+        auto mk = [&](const i64* v) { DReg g; g.rb = v[0]; g.re = v[1]; g.qb = (int)v[2]; g.qe = (int)v[3]; g.score = (int)v[4]; g.rid = (int)v[5]; g.truesc = 0; g.sub = 0; g.csub = 0; g.w = 0;
+                                      g.seedcov = 0; g.secondary = -1; g.seedlen0 = 0; g.n_comp = 0; g.is_alt = 0; g.frac_rep = 0; return g; };
+        for (int k = lane; k < n0; k += 64) A[k] = mk(vals + (size_t)(f0 + k) * 6);
+        WAVE_SYNC();
+        u64 cells = 0;
+        int n = wave_sort_dedup_patch(ix, o, nullptr, A, n0, I, T, 0, lane, &cells);   // the clean list
+        const DReg b = mk(bvals + (size_t)c * 6);
+        int eq = 0;
+        for (int k = lane; k < n; k += 64) for (int u = 0; u < k; ++u) eq |= A[u].re == A[k].re;
+        if (__any(eq) || n + 1 > LH_RA_CAP) { if (lane == 0) { verdict[c] = 3; n_out[c] = n; } continue; }
+        for (int k = lane; k < n; k += 64) { const DReg g = A[k]; B[k] = g; W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k; }
+        WAVE_SYNC();
+        // (a) as written: b goes in before the first entry with a smaller score (mem_matesw), then the call
+        int pos = n;
+        for (int k = 0; k < n; ++k) if (B[k].score < b.score) { pos = k; break; }
+        WAVE_SYNC();
+        if (lane == 0) { for (int k = n; k > pos; --k) B[k] = B[k - 1]; B[pos] = b; }
+        WAVE_SYNC();
+        const int n_full = wave_sort_dedup_patch(ix, o, nullptr, B, n + 1, I, T, 0, lane, &cells);
+        // (b) incremental
+        const int n_inc = resc_dedup_incremental(o, W, n, b, lane);
+        WAVE_SYNC();
+        int bad = 0;
+        if (n_inc >= 0) {
+            bad = n_inc != n_full;
+            for (int k = lane; k < n_full && k < n_inc; k += 64)
+                bad |= B[k].rb != W.rb[k] || B[k].re != W.re[k] || B[k].qb != W.qb[k] || B[k].qe != W.qe[k] || B[k].score != W.score[k] || B[k].rid != W.rid[k];
+        }
+        bad = __any(bad);
+        if (lane == 0) { verdict[c] = n_inc < 0 ? 1 : (bad ? 2 : 0); n_out[c] = n_full | n << 16; }
+    }
+}

@@ -344,18 +344,152 @@ __global__ void __launch_bounds__(64) k_resc_sw(DIndex ix, DOpts o, RJob* __rest
     }
 }
 
-// One wave per listed pair: mem_matesw's loop for one direction (gobwa.go:286-301 or 309-325) with the Smith-Waterman results of the pair's jobs.
+// ---- k_resc_apply: one wave per listed pair replays mem_matesw's loop for one direction (gobwa.go:286-301 or 309-325) with the results of
+// the pair's jobs.
+//
+// What the loop costs is not the Smith-Waterman any more but what follows every attempt: mem_sort_dedup_patch(opt, 0, 0, 0, n, a) — two
+// introsorts of the mate's whole region list and a scan in between, ~30 times per pair over ~100 regions.  After the FIRST of those calls the
+// list is in a state in which a further call is a function of the one region that has been added (nothing is patched with bns = 0):
+//   * the list L is sorted by (score desc, rb, qb) and no two of its entries are "redundant" (overlap > mask_level_redun of the shorter one on
+//     reference and query) within max_chain_gap of each other: every such pair was compared by the scan and one of the two excluded;
+//   * so with the new region b in place, the scan (entries by increasing re; each p against the entries to its left while they are within
+//     max_chain_gap and of p's contig) only does something in comparisons that involve b.  p = b: going left from b, every redundant q with
+//     score <= b's is excluded, until a redundant q with a higher score excludes b (and ends b's loop).  p to the right of b, by increasing
+//     re, while b is alive: redundant and p.score < b.score -> p is excluded, else b is;
+//   * the final sort puts the survivors back in (score desc, rb, qb) order, which they are in but for b: b is inserted at its place.
+// When all re are distinct and no entry has b's (score, rb, qb), the introsorts' handling of equal keys cannot matter, and the above IS the
+// call's result: a few reductions over the list, which lives in LDS.  A call after an attempt that added nothing changes nothing.  Anything
+// else — equal keys, a list that outgrows the LDS arrays — goes back to wave_sort_dedup_patch on the arrays in memory, for the rest of the pair.
+#define LH_RA_CAP 320
+struct RescList {
+    i64 rb[LH_RA_CAP], re[LH_RA_CAP];
+    int32_t qb[LH_RA_CAP], qe[LH_RA_CAP], score[LH_RA_CAP], rid[LH_RA_CAP], src[LH_RA_CAP];   // src: the entry's place in the memory arrays when the list was loaded; -1: rescued since
+};
+// "one of the hits is redundant": q = the entry with the smaller re (mem_sort_dedup_patch's a[j]), p = the one with the larger
+__device__ __forceinline__ int resc_redundant(const DOpts& o, i64 q_rb, i64 q_re, int q_qb, int q_qe, i64 p_rb, i64 p_re, int p_qb, int p_qe) {
+    const i64 orr = q_re - p_rb;
+    const i64 oq = q_qb < p_qb ? q_qe - p_qb : p_qe - q_qb;
+    const i64 mr = q_re - q_rb < p_re - p_rb ? q_re - q_rb : p_re - p_rb;
+    const i64 mq = q_qe - q_qb < p_qe - p_qb ? q_qe - q_qb : p_qe - p_qb;
+    return (float)orr > o.mask_level_redun * (float)mr && (float)oq > o.mask_level_redun * (float)mq;
+}
+
+// the list in LDS back into the memory arrays: entries that were there when it was loaded (src >= 0) keep their other fields, rescued ones get mem_matesw's
+__device__ __forceinline__ void resc_list_store(const DIndex& ix, const RescList& W, int n, DReg* ma, DReg* tmp, int lane) {
+    WAVE_SYNC();
+    for (int k = lane; k < n; k += 64) {
+        DReg g;
+        const int s = W.src[k];
+        if (s >= 0) g = ma[s];
+        else {
+            g.rid = W.rid[k]; g.is_alt = ix.contig_alt ? ix.contig_alt[g.rid] : 0;
+            g.csub = 0; g.secondary = -1; g.truesc = 0; g.sub = 0; g.w = 0; g.seedlen0 = 0; g.frac_rep = 0;
+        }
+        g.rb = W.rb[k]; g.re = W.re[k]; g.qb = W.qb[k]; g.qe = W.qe[k]; g.score = W.score[k];
+        if (s < 0) g.seedcov = (int)((g.re - g.rb < g.qe - g.qb ? g.re - g.rb : g.qe - g.qb) >> 1);
+        g.n_comp = 1;
+        tmp[k] = g;
+    }
+    WAVE_SYNC();
+    for (int k = lane; k < n; k += 64) ma[k] = tmp[k];
+    WAVE_SYNC();
+}
+
+// mem_sort_dedup_patch(opt, 0, 0, 0, n + 1, list + b) for a CLEAN list in W (see above) and a new region b, in place.  Returns the new length,
+// or -1 (W untouched) when equal keys make the introsorts' order matter or the list is full: the caller runs the call as written.
+__device__ __forceinline__ int resc_dedup_incremental(const DOpts& o, RescList& W, int n_ma, const DReg& b, int lane) {
+    i64 lo_bar = -0x7fffffffffffffffll, hi_bar = 0x7fffffffffffffffll;   // nearest entries of ANOTHER contig left and right of b (by re): the scans stop there
+    int tie = 0;
+    for (int i0 = 0; i0 < n_ma; i0 += 64) {
+        const int k = i0 + lane;
+        if (k < n_ma) {
+            const i64 e = W.re[k];
+            tie |= e == b.re || (W.score[k] == b.score && W.rb[k] == b.rb && W.qb[k] == b.qb);
+            if (W.rid[k] != b.rid) { if (e < b.re && e > lo_bar) lo_bar = e; if (e > b.re && e < hi_bar) hi_bar = e; }
+        }
+    }
+    tie = __any(tie) || n_ma + 1 > LH_RA_CAP;
+    if (tie) return -1;
+    {
+        lo_bar = wave_max_i64(lo_bar); hi_bar = wave_min_i64(hi_bar);
+        // p = b: to the left
+        i64 r_star = -0x7fffffffffffffffll;   // the nearest redundant entry with a higher score: it excludes b
+        for (int i0 = 0; i0 < n_ma; i0 += 64) {
+            const int k = i0 + lane;
+            if (k < n_ma) {
+                const i64 e = W.re[k];
+                if (e < b.re && e > lo_bar && W.rid[k] == b.rid && b.rb < e + o.max_chain_gap && b.score < W.score[k] &&
+                    resc_redundant(o, W.rb[k], e, W.qb[k], W.qe[k], b.rb, b.re, b.qb, b.qe) && e > r_star) r_star = e;
+            }
+        }
+        r_star = wave_max_i64(r_star);
+        const int b_dead_a = r_star != -0x7fffffffffffffffll;
+        // p right of b, while b is alive
+        i64 s_star = 0x7fffffffffffffffll;   // the nearest redundant entry to the right whose score is not below b's: it excludes b
+        if (!b_dead_a) {
+            for (int i0 = 0; i0 < n_ma; i0 += 64) {
+                const int k = i0 + lane;
+                if (k < n_ma) {
+                    const i64 e = W.re[k];
+                    if (e > b.re && e < hi_bar && W.rid[k] == b.rid && W.rb[k] < b.re + o.max_chain_gap && !(W.score[k] < b.score) &&
+                        resc_redundant(o, b.rb, b.re, b.qb, b.qe, W.rb[k], e, W.qb[k], W.qe[k]) && e < s_star) s_star = e;
+                }
+            }
+            s_star = wave_min_i64(s_star);
+        }
+        const int b_alive = !b_dead_a && s_star == 0x7fffffffffffffffll;
+        // the survivors, compacted in place (the order stays), and b's place among them
+        int n_new = 0, pos_b = 0;
+        for (int i0 = 0; i0 < n_ma; i0 += 64) {
+            const int k = i0 + lane;
+            int keep = 0, before = 0;
+            i64 e = 0, krb = 0; int kqb = 0, kqe = 0, ksc = 0, krid = 0, ksrc = 0;
+            if (k < n_ma) {
+                e = W.re[k]; krb = W.rb[k]; kqb = W.qb[k]; kqe = W.qe[k]; ksc = W.score[k]; krid = W.rid[k]; ksrc = W.src[k];
+                int dead = 0;
+                if (e < b.re && e > lo_bar && e > r_star && krid == b.rid && b.rb < e + o.max_chain_gap && !(b.score < ksc))
+                    dead = resc_redundant(o, krb, e, kqb, kqe, b.rb, b.re, b.qb, b.qe);
+                else if (!b_dead_a && e > b.re && e < hi_bar && e < s_star && krid == b.rid && krb < b.re + o.max_chain_gap && ksc < b.score)
+                    dead = resc_redundant(o, b.rb, b.re, b.qb, b.qe, krb, e, kqb, kqe);
+                keep = !dead;
+                before = keep && (ksc > b.score || (ksc == b.score && (krb < b.rb || (krb == b.rb && kqb < b.qb))));
+            }
+            const u64 mk = __ballot(keep), mb = __ballot(before);
+            WAVE_SYNC();   // every lane holds its entry before any is moved
+            if (keep) { const int d = n_new + lanes_below(mk, lane); W.re[d] = e; W.rb[d] = krb; W.qb[d] = kqb; W.qe[d] = kqe; W.score[d] = ksc; W.rid[d] = krid; W.src[d] = ksrc; }
+            n_new += __popcll(mk); pos_b += __popcll(mb);
+            WAVE_SYNC();
+        }
+        n_ma = n_new;
+        if (b_alive) {
+            for (int top = n_ma; top > pos_b; top -= 64) {   // make room at pos_b
+                const int j = top - 1 - lane;
+                i64 e = 0, krb = 0; int kqb = 0, kqe = 0, ksc = 0, krid = 0, ksrc = 0;
+                if (j >= pos_b) { e = W.re[j]; krb = W.rb[j]; kqb = W.qb[j]; kqe = W.qe[j]; ksc = W.score[j]; krid = W.rid[j]; ksrc = W.src[j]; }
+                WAVE_SYNC();
+                if (j >= pos_b) { W.re[j + 1] = e; W.rb[j + 1] = krb; W.qb[j + 1] = kqb; W.qe[j + 1] = kqe; W.score[j + 1] = ksc; W.rid[j + 1] = krid; W.src[j + 1] = ksrc; }
+                WAVE_SYNC();
+            }
+            if (lane == 0) { W.re[pos_b] = b.re; W.rb[pos_b] = b.rb; W.qb[pos_b] = b.qb; W.qe[pos_b] = b.qe; W.score[pos_b] = b.score; W.rid[pos_b] = b.rid; W.src[pos_b] = -1; }
+            n_ma++;
+            WAVE_SYNC();
+        }
+        return n_ma;
+    }
+}
+
 template <int DIR>
 __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
                                                     DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool, int32_t* __restrict__ n_regs,
                                                     const int32_t* __restrict__ best_score, DCounters* __restrict__ ctr, const int32_t* __restrict__ list, const RMeta* __restrict__ meta,
                                                     const int32_t* __restrict__ n_jobs, const i64* __restrict__ job_off, const RJob* __restrict__ jobs) {
     __shared__ uint8_t qm[LH_MAXLEN + 6];
+    __shared__ RescList W;
     const int lane = LANE();
     const int n_items = meta->list_count;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int p = list[item];
-        WAVE_SYNC();   // the previous pair's query is no longer in use
+        WAVE_SYNC();   // the previous pair's query and list are no longer in use
         const int r1 = 2 * p, r2 = 2 * p + 1;
         const int r_ms = DIR ? r2 : r1, r_from = DIR ? r1 : r2;
         const i64 off_ms = seq_off[r_ms];
@@ -373,6 +507,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
         int jp = 0;
         u64 cells = 0;
         int n_sw = 0, num = 0;
+        int mode = 0;   // 0: the list is in memory, no dedup call yet; 1: in LDS (W), clean; 2: in memory for good (equal re left behind / too long); 3: in memory for this call
         for (int i = 0; i < nf && num < o.rescue_max_hits && l_ms > 0; ++i) {
             const DReg a = from[i];
             if (a.score < bestf - o.rescue_score_delta) continue;
@@ -383,7 +518,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 int k = i0 + lane, f = 0;
                 if (k < n_ma) {
                     i64 dist;
-                    int r = dev_infer_dir(ix.l_pac, a.rb, ma[k].rb, &dist);
+                    int r = dev_infer_dir(ix.l_pac, a.rb, mode == 1 ? W.rb[k] : ma[k].rb, &dist);
                     f = (r == 1 && dist >= o.pes_low && dist <= o.pes_high);
                 }
                 if (__any(f)) { skip1 = 1; break; }
@@ -401,14 +536,28 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
             } else {   // no job: an attempt the enumeration saw as unnecessary (or left to this kernel): k_rescue.h's wave-wide kernel
                 aln = wave_ksw_align2(ix, o, qm, l_ms - 1, -1, 1, l_ms, rb, 1, (int)(re - rb), o.min_seed_len * o.a, lane, &cells);
             }
-            if (aln.score >= o.min_seed_len && aln.qb >= 0) {
-                DReg b;
+            const int hit = aln.score >= o.min_seed_len && aln.qb >= 0;
+            DReg b;
+            if (hit) {
                 b.rid = a.rid; b.is_alt = a.is_alt;
                 b.qb = l_ms - (aln.qe + 1); b.qe = l_ms - aln.qb;
                 b.rb = (ix.l_pac << 1) - (rb + aln.te + 1); b.re = (ix.l_pac << 1) - (rb + aln.tb);
                 b.score = aln.score; b.csub = 0; b.secondary = -1;
                 b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
                 b.truesc = 0; b.sub = 0; b.w = 0; b.seedlen0 = 0; b.n_comp = 0; b.frac_rep = 0;
+            }
+            if (mode == 1) {
+                if (!hit) continue;   // a clean list and nothing new: the call changes nothing
+                {   // the call as a function of b
+                    const int n_inc = resc_dedup_incremental(o, W, n_ma, b, lane);
+                    if (n_inc >= 0) { n_ma = n_inc; continue; }
+                }
+                // equal keys: this call as written, on the list in memory (mode 3: it may come back if the call leaves no equal re behind)
+                resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane);
+                mode = 3;
+            }
+            // ---- the list in memory: insert, then mem_sort_dedup_patch as written
+            if (hit) {
                 int pos = n_ma;   // before the first element with a smaller score
                 for (int i0 = 0; i0 < n_ma; i0 += 64) {
                     int k = i0 + lane;
@@ -428,7 +577,24 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 WAVE_SYNC();
             }
             n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells);
+            if (mode != 2 && n_ma + o.rescue_max_hits <= LH_RA_CAP) {   // (back) into LDS if the list fits with everything that may still come and no two re are equal
+                for (int k = lane; k < n_ma; k += 64) {
+                    const DReg& g = ma[k];
+                    W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k;
+                }
+                WAVE_SYNC();
+                int eq = 0;
+                if (mode == 0) {   // the first call is behind: any pair
+                    for (int k = lane; k < n_ma; k += 64) { const i64 e = W.re[k]; for (int u = 0; u < k; ++u) eq |= W.re[u] == e; }
+                } else if (hit) {  // the list was clean before b came: only b can share its re with another entry
+                    int nb_ = 0;
+                    for (int k = lane; k < n_ma; k += 64) nb_ += W.re[k] == b.re;
+                    eq = wave_sum_i32(nb_) > 1;
+                }
+                mode = __any(eq) ? 2 : 1;
+            } else mode = 2;
         }
+        if (mode == 1) resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane);
         if (lane == 0) {
             n_regs[r_ms] = n_ma;
             if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); }

@@ -245,6 +245,27 @@ __device__ __forceinline__ u64 dev_mix64(u64 x) {
     return x;
 }
 
+// tagBestAlignments for one pair, as written (lariat.go:1474-1543): the combinations one after the other, one draw each
+__device__ __forceinline__ void dev_tag_pair_serial(const DCand& R, const DInf& S, double improper, u64 seed, int p, int nA, int nM, u64* ring) {
+    const int ra = 2 * p, rb = 2 * p + 1;
+    DGoRng rng;
+    dev_go_seed(rng, seed, ring);
+    double best = -1.7976931348623157e308;
+    i64 ba = -1, bm = -1;
+    for (i64 a = R.cand_off[ra]; a < R.cand_off[ra + 1]; ++a) {
+        if (!R.in_filtered[a]) continue;
+        for (i64 m = R.cand_off[rb]; m < R.cand_off[rb + 1]; ++m) {
+            if (!R.in_filtered[m]) continue;
+            double total = dev_score_aln(R, S, improper, a, m, 0.0) + (dev_go_f64(rng) / 2.0);
+            if (total > best) { best = total; ba = a; bm = m; }
+        }
+    }
+    S.active[ba] = 1; S.bwa_pick[ba] = 1;
+    if (dev_is_pair(R, ba, bm)) { S.is_proper[ba] = 1; S.is_proper[bm] = 1; }
+    S.active[bm] = 1; S.bwa_pick[bm] = 1;
+    (void)nA; (void)nM;
+}
+#define LH_RFA_TAG_WAVE 128   // combinations of a pair from which on the wave scores it together
 #ifdef LH_RFA_PROF   // development aid: per-phase wall-clock (100 MHz ticks -> us) summed over waves into lh_dbg[16..]
 #define RFA_T(k) { if (lane == 0) { u64 now_ = wall_clock64(); atomicAdd(&o.wd[16 + (k)], (int)((now_ - t_prof) / 100)); t_prof = now_; } }
 #else
@@ -323,26 +344,97 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             if (__ballot(big) && (size_t)slab_bytes < LH_GO_RING_BYTES) RFA_OVERFLOW()
         }
-        for (int p = p0 + lane; p < p1; p += 64) {
-            int ra = 2 * p, rb = 2 * p + 1;
-            int nA = 0, nM = 0;
-            for (i64 a = R.cand_off[ra]; a < R.cand_off[ra + 1]; ++a) nA += R.in_filtered[a] != 0;
-            for (i64 m = R.cand_off[rb]; m < R.cand_off[rb + 1]; ++m) nM += R.in_filtered[m] != 0;
-            DGoRng rng;
-            dev_go_seed(rng, name_seed[p], (i64)nA * nM > LH_GO_FAST_DRAWS ? (u64*)slab + lane : (u64*)nullptr);
-            double best = -1.7976931348623157e308;
-            i64 ba = -1, bm = -1;
-            for (i64 a = R.cand_off[ra]; a < R.cand_off[ra + 1]; ++a) {
-                if (!R.in_filtered[a]) continue;
-                for (i64 m = R.cand_off[rb]; m < R.cand_off[rb + 1]; ++m) {
-                    if (!R.in_filtered[m]) continue;
-                    double total = dev_score_aln(R, S, improper, a, m, 0.0) + (dev_go_f64(rng) / 2.0);
-                    if (total > best) { best = total; ba = a; bm = m; }
-                }
+        // Pairs with few combinations: one lane per pair, the state-free generator.  The others (a read on a repeat family has tens of
+        // candidates, its mate as many: thousands of combinations, each with its own draw) are listed and scored by the whole wave, below.
+        int n_heavy = 0;
+        int32_t* const heavy = (int32_t*)(slab + (size_t)slab_bytes) - (p1 - p0);   // the slab's last words: free until the carve's tables fill up (bestT, much later)
+        for (int pb = p0; pb < p1; pb += 64) {
+            const int p = pb + lane;
+            int hv = 0;
+            if (p < p1) {
+                int ra = 2 * p, rb = 2 * p + 1;
+                int nA = 0, nM = 0;
+                for (i64 a = R.cand_off[ra]; a < R.cand_off[ra + 1]; ++a) nA += R.in_filtered[a] != 0;
+                for (i64 m = R.cand_off[rb]; m < R.cand_off[rb + 1]; ++m) nM += R.in_filtered[m] != 0;
+                hv = (i64)nA * nM > LH_RFA_TAG_WAVE && (size_t)(p1 - p0) * 4 + LH_GO_RING_BYTES < (size_t)slab_bytes;
+                if (!hv) dev_tag_pair_serial(R, S, improper, name_seed[p], p, nA, nM, (i64)nA * nM > LH_GO_FAST_DRAWS ? (u64*)slab + lane : (u64*)nullptr);
             }
-            S.active[ba] = 1; S.bwa_pick[ba] = 1;
-            if (dev_is_pair(R, ba, bm)) { S.is_proper[ba] = 1; S.is_proper[bm] = 1; }
-            S.active[bm] = 1; S.bwa_pick[bm] = 1;
+            const u64 mh = __ballot(hv);
+            if (hv) heavy[n_heavy + lanes_below(mh, lane)] = p;
+            n_heavy += __popcll(mh);
+        }
+        WAVE_SYNC();
+        for (int hi = 0; hi < n_heavy; ++hi) {
+            const int p = heavy[hi];
+            // the pair's filtered candidates and their single-read scores (scoreAlignment's two sums: exact multiples of 0.5), compacted in the slab
+            const i64 a0 = R.cand_off[2 * p], a1 = R.cand_off[2 * p + 1], m1 = R.cand_off[2 * p + 2];
+            int32_t* const fa = (int32_t*)slab;                                   // [nA | nM] candidate ids
+            double* const fs = (double*)(slab + (((size_t)(m1 - a0) * 4 + 7) & ~(size_t)7));   // [nA | nM] scores
+            int nA = 0, nM = 0;
+            for (int side = 0; side < 2; ++side) {   // read 1's candidates, then read 2's behind them
+                const i64 lo = side ? a1 : a0, hi = side ? m1 : a1;
+                int cnt = 0;
+                for (i64 cb = lo; cb < hi; cb += 64) {
+                    const i64 c = cb + lane;
+                    const int ok = c < hi && R.in_filtered[c];
+                    const u64 mk = __ballot(ok);
+                    if (ok) {
+                        double sc = (double)(R.mismatches[c] * -2 + R.indels[c] * -3);
+                        if (R.soft_clipped[c] > 0) { sc -= 5.0 * (double)R.soft_clipped[c]; sc -= (double)R.soft_clipped_length[c] * 0.5; }
+                        const int at = nA + cnt + lanes_below(mk, lane);
+                        fa[at] = (int32_t)(c - c_lo); fs[at] = sc;
+                    }
+                    cnt += __popcll(mk);
+                }
+                if (side) nM = cnt; else nA = cnt;
+            }
+            WAVE_SYNC();
+            // Go's generator, 64 draws per turn: x[n] = x[n - 607] + x[n - 273]; the last 1024 values in LDS, the seeded state from its definition
+            u64* const xb = (u64*)lds_raw;
+            i64 sd = (i64)name_seed[p] % 2147483647ll;
+            if (sd < 0) sd += 2147483647ll;
+            if (sd == 0) sd = 89482311;
+            const uint32_t x0 = (uint32_t)sd;
+            const i64 K = (i64)nA * nM;
+            double best = -1.7976931348623157e308;
+            i64 bk = 0x7fffffffffffffffll;
+            int redraw = 0;
+            for (i64 k0 = 0; k0 < K; k0 += 64) {
+                const i64 k = k0 + lane, n = k + 1;
+                const u64 va = n > LH_GO_LEN ? xb[(n - LH_GO_LEN) & 1023] : dev_go_vec0(x0, (int)(n <= 334 ? 334 - n : 941 - n));
+                const u64 vb = n > LH_GO_TAP ? xb[(n - LH_GO_TAP) & 1023] : dev_go_vec0(x0, (int)(LH_GO_LEN - n));
+                const u64 x = va + vb;
+                xb[n & 1023] = x;
+                if (k < K) {
+                    const double f = (double)(i64)(x & 0x7fffffffffffffffull) * (1.0 / 9223372036854775808.0);
+                    redraw |= f == 1.0;   // Float64 draws again then (once in 2^53 draws): every later draw moves: the serial form
+                    const int ia = (int)(k / nM), im = (int)(k - (i64)ia * nM);
+                    const i64 a = c_lo + fa[ia], m = c_lo + fa[nA + im];
+                    double t = fs[ia] + fs[nA + im];
+                    if (!dev_is_pair(R, a, m)) t += improper;
+                    t += 0.0;   // (scoreAlignment adds log_molecule_penalty = 0.0 for an alignment outside an active molecule)
+                    const double total = t + f / 2.0;
+                    if (total > best) { best = total; bk = k; }
+                }
+                WAVE_SYNC();
+            }
+            if (__any(redraw)) {
+                if (lane == 0) dev_tag_pair_serial(R, S, improper, name_seed[p], p, nA, nM, (u64*)slab + lane);
+                WAVE_SYNC();
+                continue;
+            }
+            for (int msk = 32; msk >= 1; msk >>= 1) {   // the first maximum in draw order
+                const double ob = __shfl_xor(best, msk);
+                const i64 ok = shfl_xor_i64(bk, msk);
+                if (ob > best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+            }
+            if (lane == 0) {
+                const i64 ba = c_lo + fa[(int)(bk / nM)], bm = c_lo + fa[nA + (int)(bk % nM)];
+                S.active[ba] = 1; S.bwa_pick[ba] = 1;
+                if (dev_is_pair(R, ba, bm)) { S.is_proper[ba] = 1; S.is_proper[bm] = 1; }
+                S.active[bm] = 1; S.bwa_pick[bm] = 1;
+            }
+            WAVE_SYNC();
         }
         WAVE_SYNC();
         RFA_T(1)

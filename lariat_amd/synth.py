@@ -95,7 +95,7 @@ def _name_seeds(names):
 
 
 def make_reads(contigs, contig_names, n_barcodes, pairs_per_barcode=100, seed=20261004, len1=143, len2=150, sub_lo=0.001, sub_hi=0.01,
-               indel_rate=0.0001, mol_min=4, mol_max=10, with_names=True, junk_frac=0.0):
+               indel_rate=0.0001, mol_min=4, mol_max=10, with_names=True, junk_frac=0.0, ins_mean=350.0, ins_sd=50.0, ins_max=700):
     rng = np.random.default_rng(seed)
     n_pairs = n_barcodes * pairs_per_barcode
     clen = np.array([len(c) for c in contigs], dtype=np.int64)
@@ -118,7 +118,7 @@ def make_reads(contigs, contig_names, n_barcodes, pairs_per_barcode=100, seed=20
         pair_mol_start[k:k + pairs_per_barcode] = ms[which]
         pair_mol_end[k:k + pairs_per_barcode] = ms[which] + mlen[which]
         k += pairs_per_barcode
-    insert = np.clip(rng.normal(350, 50, size=n_pairs), max(200, len1, len2), 700).astype(np.int64)
+    insert = np.clip(rng.normal(ins_mean, ins_sd, size=n_pairs), max(200, len1, len2), ins_max).astype(np.int64)
     span = np.maximum(pair_mol_end - pair_mol_start - insert, 1)
     frag_s = pair_mol_start + (rng.random(n_pairs) * span).astype(np.int64)
     flip = rng.random(n_pairs) < 0.5

@@ -23,3 +23,26 @@ def test_bench_two_ranks_on_one_device():
     assert len(d["per_rank"]) == 2 and all(r["pairs_per_s"] > 0 and r["index_build_s"] > 0 for r in d["per_rank"])
     # weak scaling: the job aligned 2 ranks x 2 steps x 200,000 pairs
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 2 / (2 * 2 * 200000) - 1) < 0.05
+
+
+def run_bench(args, env=None, launcher=False):
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29611"]
+    cmd += [os.path.join(helpers.ROOT, "bench.py")] + args
+    p = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", **(env or {})), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_under_the_launcher_equals_plain_run():
+    """the driver starts N > 1 runs as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: the same path with one rank (RCCL
+    process group on the one device, barrier + all_reduce around the timed region) must report what the plain `python bench.py` reports"""
+    args = ["--gpus", "1", "--steps", "30", "--warmup", "3", "--genome-mb", "400", "--barcodes", "5000", "--no-cpu-baseline", "--no-extras"]
+    plain = run_bench(args)
+    launched = run_bench(args, launcher=True)
+    assert plain["n_gpus"] == launched["n_gpus"] == 1 and launched["steps"] == 30
+    assert plain["work_per_step"] == launched["work_per_step"]   # the same batches, the same work
+    rel = abs(launched["value"] / plain["value"] - 1)
+    print("bench.py plain %.0f pairs/s, under torch.distributed.run %.0f pairs/s (%.1f %% apart)" % (plain["value"], launched["value"], 100 * rel))
+    assert rel < 0.03

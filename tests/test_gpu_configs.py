@@ -184,3 +184,56 @@ def test_config4_like_segdup_biased(lib, oracle):
     helpers.assert_same_result(got, ref, inference=True)
     again = ctx.align_barcodes(b)
     helpers.assert_same_result(again, res, inference=True, mapq_tol=0, rel=0)
+
+
+def test_hg38_scale_index_from_files(lib, oracle, tmp_path_factory):
+    """the reference's only way to an index is bwa_idx_load(path, BWA_IDX_ALL) (gobwa.go:128-147): an hg38-scale index — with .amb holes and 40
+    ALT contigs — is built on the device, saved in the layout of `bwa index`'s files (suffix array at interval 32), loaded again from
+    those files, and must be the same index: the side tables derived from the loaded BWT and text (dense SA, inverse SA, LCP / PLCP, k-mer
+    tree) digest to what the builder left, ALT flags and holes survive, and 40 k pairs align to the same results"""
+    import shutil
+    import tempfile
+    ctg = workload.hg38_like_contigs(3060000000)
+    l_pac = sum(c[1] for c in ctg)
+    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED + 7)
+    pac, l_pac, ctg_all, alt_flags, alts = workload.add_alt_contigs(pac, ctg, 40, 1000000, 0.997, seed=47)
+    holes = [(int(ctg_all[k][2] + 1000 * (k + 1)), 50000 + 1000 * k, "N") for k in range(0, 24, 3)]   # (what bns_fasta2bntseq records for runs of N; their bases are random in .pac)
+    built = lib.index_build_device(pac, l_pac, ctg_all)
+    built.set_alt(alt_flags)
+    built.set_holes(holes)
+    r = lib.synth_reads(pac, l_pac, ctg_all, seed=workload.READS_SEED + 9, n_barcodes=400, pairs_per_barcode=100)
+    b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
+    ctx = built.context(r["n_pairs"])
+    want = ctx.align_barcodes(b)
+    ctx.close()
+    want_digest = built.digest()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (8 << 30) else None
+    d = tempfile.mkdtemp(prefix="lh_idx_", dir=base)
+    try:
+        prefix = os.path.join(d, "ref.fa")
+        t0 = time.time()
+        built.save(prefix)
+        t_save = time.time() - t0
+        sizes = {e: os.path.getsize(prefix + e) for e in (".bwt", ".sa", ".pac", ".ann", ".amb", ".alt")}
+        assert sizes[".sa"] == 56 + (2 * l_pac // 32) * 8 and sizes[".bwt"] > 2 * l_pac // 4
+        built.close()   # two resident hg38-scale indexes do not fit one device
+        t0 = time.time()
+        loaded = lib.index_load(prefix)
+        t_load = time.time() - t0
+        print("hg38-scale index: saved in %.1f s (%.1f GB of files), loaded from files in %.1f s" % (t_save, sum(sizes.values()) / 1e9, t_load))
+        assert loaded.sa_interval == 1 and loaded.l_pac == l_pac
+        assert [c[0] for c in loaded.contigs()] == [c[0] for c in ctg_all]
+        assert loaded.alt() == list(alt_flags)
+        assert loaded.digest() == want_digest
+        rows, bad_order, bad_lf = loaded.check(stride=4999)
+        assert rows > 1000000 and bad_order == 0 and bad_lf == 0
+        ctx = loaded.context(r["n_pairs"])
+        got = ctx.align_barcodes(b)
+        ctx.close()
+        helpers.assert_same_result(got, want, inference=True, mapq_tol=0, rel=0)
+        loaded.save(os.path.join(d, "again.fa"))   # holes and ALT names round-trip
+        for e in (".amb", ".alt", ".ann"):
+            assert open(prefix + e, "rb").read() == open(os.path.join(d, "again.fa") + e, "rb").read()
+        loaded.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
