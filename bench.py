@@ -42,8 +42,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=1, help="lh_context_opts.lanes: 1 = one pipeline, every kernel with the device to itself (per-kernel times and the roofline "
                                                           "are then execution times); 2 = every batch is cut at a barcode boundary and its halves are aligned side by side "
                                                           "inside ONE lh_align_resident call (+5 %: reported under two_lanes_pairs_per_s)")
-    ap.add_argument("--repeats", action="store_true", help="configs[4]-like input on this GPU: segmental duplications and repeat families planted in the genome, every read drawn "
-                                                              "from on and around them (several candidates per read; informational, not the headline workload)")
+    ap.add_argument("--repeats", action="store_true", help="only the configs[4] leg (repeat families, every read on the copies: tens to hundreds of candidates per read)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --steps batches in total, split over the ranks (default weak: --steps per rank)")
     ap.add_argument("--cpu-sample-barcodes", type=int, default=10000, help="barcodes of the first batch timed on the host cores (cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,16 +127,15 @@ def main():
     if lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: liblariat_hip has no CPU fallback")
 
+    if a.repeats:   # development: the configs[4] leg alone
+        print(json.dumps({"repeats": repeats_leg(lib, a, local_rank, lib.opts())}), flush=True)
+        return
     # ---- synthetic genome + FM-index, built in this rank's HBM (lh_index_build_device; nothing persists between runs) ----
     t0 = time.time()
     ctg = workload.hg38_like_contigs(int(a.genome_mb * 1e6))
     l_pac = sum(c[1] for c in ctg)
     pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED, threads=host_threads)
     read_ctg = ctg
-    if a.repeats:
-        dups = workload.plant_segdups(pac, ctg, 1500, 20000, 0.99, seed=41, n_families=40, family_len=320, family_copies=60)
-        dups += workload.plant_segdups(pac, ctg, 300, 20000, 1.0, seed=42)
-        read_ctg = workload.repeat_windows(ctg, dups[:1500] + dups[-300:], flank=50000)
     t_genome = time.time() - t0
     t0 = time.time()
     idx = lib.index_build_device(pac, l_pac, ctg, device=local_rank)
@@ -218,8 +216,7 @@ def main():
             "value": round(value, 1), "unit": "read-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / max(1, len(my_batches)) * 1e3, 3), "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": "u64/i32 (FM-index + integer DP), f64 (RFA scores)", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[4]-like on one GPU: 1,800 planted 20-kb segmental duplications (99 % / 100 %) + 40 repeat families, reads drawn from on and around them; "
-                                    if a.repeats else "BASELINE.json configs[2]: ") +
+            "config": {"workload": "BASELINE.json configs[2]: "
                                    "hg38-scale synthetic genome (%.0f Mb in 24 contigs, seed %d, index built in HBM by lh_index_build_device), "
                                    "%d steps x %d pairs 2x150 (143+150 post-trim) / %d barcodes per step per GPU, every step a different batch, RFA on device"
                                    % (l_pac / 1e6, workload.GENOME_SEED, a.steps, n_pairs, a.barcodes),
@@ -241,7 +238,7 @@ def main():
             out.update(extras(lib, idx, first[1], n_pairs, opts, elapsed / max(1, len(my_batches))))
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, idx, pac, first[0])
-        if not a.no_extras and world == 1 and not a.repeats:
+        if not a.no_extras and world == 1:
             idx.close()   # the repeat-rich leg builds its own index: the two do not fit HBM side by side
             del pac
             out["repeats"] = repeats_leg(lib, a, local_rank, opts)
@@ -413,29 +410,27 @@ def host_to_host(lib, idx, reads_list, n_pairs, opts):
             "how": "one context; a second host thread stages batch k+1 (lh_batch_stage_slot) under batch k's kernels; batch k's result is copied out under batch k+1's (lh_result_download_begin/_end)"}
 
 
-def repeats_leg(lib, a, local_rank, opts, steps=4):
-    """configs[4]'s regime on this GPU, in the default run: a second hg38-scale genome with planted segmental duplications (1,500 x 20 kb at
-    99 %, 300 identical), 40 repeat families and 40 ALT contigs (1 Mb copies at 99.7 %, is_alt set), every read drawn from on and around
-    them.  Its own index (the headline index has been freed by now)."""
+def repeats_leg(lib, a, local_rank, opts, steps=3):
+    """BASELINE.json configs[4] on this GPU, in the default run: the hg38-scale genome of workload.config4_genome — 120 segmental-duplication
+    families of 50-200 copies x 20 kb at 98-99.5 %, 40 LINE-like and 80 SINE-like families, 40 ALT contigs (is_alt) — with EVERY read drawn on
+    the copies (flank <= 2 kb): tens to hundreds of candidates per read, up to 50 + 50 mate-rescue Smith-Watermans per pair (gobwa.go:286-325),
+    n_a x n_m pair scores per read in tagBestAlignments / estimateMapQualities.  Its own index (the headline index has been freed by now);
+    batches of a tenth of the headline's size (a pair costs ~500 times the DP cells of a pair on unique sequence)."""
+    import numpy as np
     from lariat_amd import capi, workload
     t0 = time.time()
-    ctg = workload.hg38_like_contigs(int(a.genome_mb * 1e6 * 0.987))
-    l_pac = sum(c[1] for c in ctg)
-    pac = lib.synth_genome(l_pac, seed=workload.GENOME_SEED + 4)
-    dups = workload.plant_segdups(pac, ctg, 1500, 20000, 0.99, seed=41, n_families=40, family_len=320, family_copies=60)
-    dups += workload.plant_segdups(pac, ctg, 300, 20000, 1.0, seed=42)
-    pac, l_pac, ctg_all, alt_flags, alts = workload.add_alt_contigs(pac, ctg, 40, min(1000000, l_pac // 200 // 4 * 4), 0.997, seed=43)
-    win = workload.repeat_windows(ctg_all, dups[:1500] + dups[-300:], flank=50000) + workload.repeat_windows(ctg_all, alts, flank=20000)
-    idx = lib.index_build_device(pac, l_pac, ctg_all, device=local_rank)
-    idx.set_alt(alt_flags)
-    n_pairs = a.barcodes * a.pairs_per_barcode
+    g = workload.config4_genome(lib, a.genome_mb * 1e6 * 0.987)
+    idx = lib.index_build_device(g["pac"], g["l_pac"], g["contigs"], device=local_rank)
+    idx.set_alt(g["alt_flags"])
+    n_bc = max(1, a.barcodes // 10)
+    n_pairs = n_bc * a.pairs_per_barcode
     ctx = idx.context(n_pairs)
     for slot in range(steps):
-        r = lib.synth_reads(pac, l_pac, win, seed=workload.READS_SEED + 400 + slot, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode)
+        r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400 + slot, n_barcodes=n_bc, pairs_per_barcode=a.pairs_per_barcode)
         ctx.upload_slot(slot, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
     t_setup = time.time() - t0
     ctx.select(0)
-    ctx.align_resident(opts)   # warm-up: pools grow to this workload's seed counts
+    ctx.align_resident(opts)   # warm-up: pools grow to this workload's seed, region and job counts
     kern = {}
     t0 = time.perf_counter()
     for s in range(steps):
@@ -445,11 +440,20 @@ def repeats_leg(lib, a, local_rank, opts, steps=4):
             kern.setdefault(name, []).append(ms)
     dt = time.perf_counter() - t0
     res = ctx.download()
-    out = {"value": round(steps * n_pairs / dt, 1), "unit": "read-pairs/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+    nc = np.diff(res.cand_off)
+    mol = np.maximum.reduceat(res.molecule_id, res.cand_off[:-1][::2 * a.pairs_per_barcode]) + 1   # molecules that survive scrapMolecules, per barcode
+    cnt = res.counters
+    out = {"value": round(steps * n_pairs / dt, 1), "unit": "read-pairs/s", "steps": steps, "pairs_per_step": n_pairs, "ms_per_step": round(dt / steps * 1e3, 3),
            "kernel_ms": {k: round(sum(v) / len(v), 3) for k, v in kern.items()},
-           "candidates_per_read": round(res.n_cand / res.n_reads, 2), "setup_s": round(t_setup, 1),
-           "workload": "configs[4]-like on one GPU: %d Mb genome, 1,800 planted 20-kb segmental duplications, 40 repeat families, 40 ALT contigs (is_alt), reads drawn from on and around them, %d steps x %d pairs"
-                       % (l_pac // 1000000, steps, n_pairs)}
+           "candidates_per_read": {"mean": round(float(nc.mean()), 2), "median": int(np.median(nc)), "p99": int(np.percentile(nc, 99)), "max": int(nc.max())},
+           "per_pair": {"rescue_attempts": round(cnt["n_rescue"] / n_pairs, 2), "rescue_cells": round(cnt["rescue_cells"] / n_pairs), "extension_cells": round(cnt["ext_cells"] / n_pairs),
+                        "global_cells": round(cnt["glob_cells"] / n_pairs), "bwt_extend": round(cnt["n_ext"] / n_pairs)},
+           "molecules_per_barcode": {"mean": round(float(mol.mean()), 1), "max": int(mol.max())},
+           "n_rescue": cnt["n_rescue"], "rescue_cells": cnt["rescue_cells"],
+           "rescue_GCUPS": round(cnt["rescue_cells"] / (sum(kern["k_rescue"]) / len(kern["k_rescue"]) * 1e-3) / 1e9, 1),
+           "setup_s": round(t_setup, 1),
+           "workload": "BASELINE.json configs[4] on one GPU: %d Mb genome with 120 segmental-duplication families (50-200 copies x 20 kb, 98-99.5 %%), 40 x 6-kb and 80 x 300-bp "
+                       "repeat families, 40 ALT contigs (is_alt); every read drawn on the copies (+- 2 kb); %d steps x %d pairs" % (g["l_pac"] // 1000000, steps, n_pairs)}
     ctx.close()
     idx.close()
     return out

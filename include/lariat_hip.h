@@ -342,6 +342,10 @@ int lh_diag_index_digest(const lh_index* idx, uint64_t* lcp_digest, uint64_t* kt
  * sub_lo -> sub_hi along each read, indels at indel_rate per base (1-3 bases), junk_frac of the reads replaced by random
  * bases.  Output arrays as an lh_batch wants them; truth_pos (forward-strand start of read 1 / read 2's fragment end) may be NULL. */
 int lh_synth_genome(uint64_t seed, double gc, int64_t l_pac, uint8_t* pac, int32_t threads);
+/* the reads of lh_synth_reads as the reference's input file: 9-line barcode-sorted FASTQ (README.md:34-48), gzip'ed when gz_level > 0; read 1 gets `trim`
+ * random bases in front; barcode b is the 16-mer of first_barcode + b in base 4 + "-1" (ascending = sorted); names mol:<bc>:<rid>:0:0:<pos1>:<pos2> */
+int lh_synth_write_fastq9(const char* path, const uint8_t* seq, const int64_t* seq_off, const int32_t* bc_pair_off, int32_t n_barcodes, int64_t first_barcode,
+                          int32_t trim, int32_t gz_level, uint64_t seed, const int32_t* truth_rid, const int64_t* truth_pos1, const int64_t* truth_pos2);
 int lh_synth_reads(const uint8_t* pac, int64_t l_pac, int32_t n_contigs, const int64_t* contig_off, const int32_t* contig_len, uint64_t seed,
                    int32_t n_barcodes, int32_t pairs_per_barcode, int32_t len1, int32_t len2, double sub_lo, double sub_hi, double indel_rate,
                    double junk_frac, int32_t mol_min, int32_t mol_max, int32_t threads,

@@ -495,6 +495,16 @@ class Library:
                                          ns.ctypes.data_as(c_u64p), trid.ctypes.data_as(c_i32p), tp1.ctypes.data_as(c_i64p), tp2.ctypes.data_as(c_i64p)))
         return dict(seq=seq[:seq_off[-1]], seq_off=seq_off, bc_pair_off=bco, name_seed=ns, truth_rid=trid, truth_pos1=tp1, truth_pos2=tp2, n_pairs=n_pairs)
 
+    def write_fastq9(self, path, reads, first_barcode=0, trim=7, gz_level=1, seed=7):
+        """`reads` (a dict from synth_reads) as a 9-line barcode-sorted FASTQ file — the reference's input format (gzip when gz_level > 0)"""
+        self.L.lh_synth_write_fastq9.argtypes = [C.c_char_p, c_u8p, c_i64p, c_i32p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, c_i32p, c_i64p, c_i64p]
+        seq, so, bco = (np.ascontiguousarray(reads["seq"], dtype=np.uint8), np.ascontiguousarray(reads["seq_off"], dtype=np.int64),
+                        np.ascontiguousarray(reads["bc_pair_off"], dtype=np.int32))
+        tr, t1, t2 = reads.get("truth_rid"), reads.get("truth_pos1"), reads.get("truth_pos2")
+        self.check(self.L.lh_synth_write_fastq9(path.encode(), seq.ctypes.data_as(c_u8p), so.ctypes.data_as(c_i64p), bco.ctypes.data_as(c_i32p), len(bco) - 1, int(first_barcode),
+                                                int(trim), int(gz_level), int(seed), tr.ctypes.data_as(c_i32p) if tr is not None else None,
+                                                t1.ctypes.data_as(c_i64p) if t1 is not None else None, t2.ctypes.data_as(c_i64p) if t2 is not None else None))
+
     def index_from_arrays(self, arrs, device=0, **index_opts):
         """arrs: dict(primary, L2, bwt, sa, sa_intv, pac, l_pac, contigs=[(name,len,off)])"""
         n = len(arrs["contigs"])
@@ -863,5 +873,5 @@ EXPORTED_SYMBOLS = [
     "lh_records_text", "lh_records_text_ex", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_set_flags", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
     "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_random_read", "lh_diag_go_rand", "lh_diag_rescue_dedup",
-    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt", "lh_bam_set_level", "lh_bam_timings", "lh_result_download_begin", "lh_result_download_end", "lh_batch_stage_slot", "lh_host_alloc", "lh_host_free",
+    "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_synth_write_fastq9", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt", "lh_bam_set_level", "lh_bam_timings", "lh_result_download_begin", "lh_result_download_end", "lh_batch_stage_slot", "lh_host_alloc", "lh_host_free",
 ]

@@ -265,7 +265,12 @@ __device__ __forceinline__ void dev_tag_pair_serial(const DCand& R, const DInf& 
     S.active[bm] = 1; S.bwa_pick[bm] = 1;
     (void)nA; (void)nM;
 }
+#ifndef LH_RFA_TAG_WAVE
 #define LH_RFA_TAG_WAVE 128   // combinations of a pair from which on the wave scores it together
+#define LH_RFA_MAPQ_WAVE 128  // ... and from which on the wave estimates the read's map qualities together (candidate counts, filtered or not)
+#define LH_RFA_MQ_CHUNK 384   // mate alignments staged per turn (24 B each in lds_raw)
+#endif
+static_assert(24 * LH_RFA_MQ_CHUNK <= LH_RFA_LDS_BYTES, "mate staging of estimateMapQualities");
 #ifdef LH_RFA_PROF   // development aid: per-phase wall-clock (100 MHz ticks -> us) summed over waves into lh_dbg[16..]
 #define RFA_T(k) { if (lane == 0) { u64 now_ = wall_clock64(); atomicAdd(&o.wd[16 + (k)], (int)((now_ - t_prof) / 100)); t_prof = now_; } }
 #else
@@ -835,10 +840,23 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         }
         WAVE_SYNC();
         RFA_T(11)
-        // ---- estimateMapQualities per read (lariat.go:887-990), one lane per read ----
+        // ---- estimateMapQualities per read (lariat.go:887-990).  A read with few (alignment, mate alignment) combinations: one lane; the others
+        // (a read on a repeat family and its mate: thousands) are listed and done by the whole wave below, a lane per alignment ----
+        int n_heavy_r = 0;
+        int32_t* const heavy_r = T.tdel;   // [nR] free after the optimizer
+        for (int rb_ = 0; rb_ < nR; rb_ += 64) {
+            const int r = rb_ + lane;
+            int hv = 0;
+            if (r < nR) hv = (R.cand_off[r0 + r + 1] - R.cand_off[r0 + r]) * (R.cand_off[r0 + (r ^ 1) + 1] - R.cand_off[r0 + (r ^ 1)]) > LH_RFA_MAPQ_WAVE;
+            const u64 mh = __ballot(hv);
+            if (hv) heavy_r[n_heavy_r + lanes_below(mh, lane)] = r;
+            n_heavy_r += __popcll(mh);
+        }
+        WAVE_SYNC();
         for (int r = lane; r < nR; r += 64) {
             int gr = r0 + r, gm = r0 + (r ^ 1);
             i64 a0 = R.cand_off[gr], a1 = R.cand_off[gr + 1], m0 = R.cand_off[gm], m1 = R.cand_off[gm + 1];
+            if ((a1 - a0) * (m1 - m0) > LH_RFA_MAPQ_WAVE) continue;
             double* const top = (double*)lds_raw;   // the read's 15 best scores, lane-strided in LDS (the phases that staged things there are over): no scratch
 #define TOPV(k_) top[(k_) * 64 + lane]
             int ntop = 0;
@@ -905,6 +923,133 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
 #undef TOPV
         }
         WAVE_SYNC();
+        for (int hi = 0; hi < n_heavy_r; ++hi) {
+            const int r = heavy_r[hi];
+            const int gr = r0 + r, gm = r0 + (r ^ 1);
+            const i64 a0 = R.cand_off[gr], a1 = R.cand_off[gr + 1], m0 = R.cand_off[gm], m1 = R.cand_off[gm + 1];
+            // the mate's filtered alignments staged in LDS, LH_RFA_MQ_CHUNK at a time: single-read score, strand, contig, position
+            double* const ms = (double*)lds_raw;                                    // [CH]
+            i64* const mp = (i64*)(lds_raw + 8 * LH_RFA_MQ_CHUNK);                  // [CH]
+            int32_t* const mi = (int32_t*)(lds_raw + 16 * LH_RFA_MQ_CHUNK);         // [CH] candidate (global - c_lo)
+            int32_t* const mr = (int32_t*)(lds_raw + 20 * LH_RFA_MQ_CHUNK);         // [CH] rid << 1 | reversed
+            // pass over this read's alignments, 64 at a time: best pair score of each (and where), with the mate chunks as the inner loop
+            double pseudo = 0.0, g_sb = -1000.0;   // second best: the running maximum over the inactive alignments before this lane's
+            i64 sb_aln = -1;
+            double sb_raw = 0.0;
+            double* const sc_all = T.sval;   // the read's scores (free after markBest): the pseudo-count entry, then one per alignment
+            int n_sc = 0;
+            i64 first = -1;
+            for (i64 ab = a0; ab < a1; ab += 64) {
+                const i64 a = ab + lane;
+                const int ok = a < a1 && R.in_filtered[a];
+                double sa = 0.0, best = -1.7976931348623157e308, best0 = 0.0;
+                i64 bm = -1;
+                int a_rev = 0, a_rid = 0, a_am = 0;
+                i64 a_pos = 0;
+                if (ok) {
+                    sa = (double)(R.mismatches[a] * -2 + R.indels[a] * -3);
+                    if (R.soft_clipped[a] > 0) { sa -= 5.0 * (double)R.soft_clipped[a]; sa -= (double)R.soft_clipped_length[a] * 0.5; }
+                    a_rev = R.reversed[a]; a_rid = R.rid[a]; a_pos = R.pos[a]; a_am = S.active_molecule[a];
+                }
+                double bsingle = -1.7976931348623157e308;
+                for (i64 mb = m0; mb < m1; mb += LH_RFA_MQ_CHUNK) {
+                    WAVE_SYNC();   // the previous chunk has been read
+                    int nch = 0;
+                    for (i64 cb = mb; cb < m1 && cb < mb + LH_RFA_MQ_CHUNK; cb += 64) {   // stage (filtered ones only, compacted, in order)
+                        const i64 c = cb + lane;
+                        const int okm = c < m1 && c < mb + LH_RFA_MQ_CHUNK && R.in_filtered[c];
+                        const u64 mk = __ballot(okm);
+                        if (okm) {
+                            double sc = (double)(R.mismatches[c] * -2 + R.indels[c] * -3);
+                            if (R.soft_clipped[c] > 0) { sc -= 5.0 * (double)R.soft_clipped[c]; sc -= (double)R.soft_clipped_length[c] * 0.5; }
+                            const int at = nch + lanes_below(mk, lane);
+                            ms[at] = sc; mp[at] = R.pos[c]; mi[at] = (int32_t)(c - c_lo); mr[at] = R.rid[c] << 1 | (R.reversed[c] ? 1 : 0);
+                        }
+                        nch += __popcll(mk);
+                    }
+                    WAVE_SYNC();
+                    for (int j = 0; j < nch; ++j) {
+                        const double sm = ms[j];
+                        const int rr = mr[j];
+                        const i64 pm = mp[j];
+                        if (ab == a0) { const double s1 = (0.0 + sm) + improper; if (s1 > bsingle) bsingle = s1; }   // scoreAlignment(nil, mate, lmp)
+                        if (ok) {
+                            int pair = 0;
+                            if ((rr & 1) != a_rev && (rr >> 1) == a_rid) { const i64 dist = a_rev ? a_pos - pm : pm - a_pos; pair = dist >= -35 && dist < 750; }
+                            double t = sa + sm;
+                            if (!pair) t += improper;
+                            const double t0 = t + 0.0;
+                            if (!a_am) t += lmp;
+                            if (t > best) { best = t; best0 = t0; bm = c_lo + mi[j]; }
+                        }
+                    }
+                }
+                // (the read's first filtered alignment, for the pseudo-count entry: in the first 64-chunk that has one)
+                { const u64 fk = __ballot(ok); if (first < 0 && fk) first = ab + (__ffsll((unsigned long long)fk) - 1); }
+                if (ab == a0) pseudo = bsingle;
+                // this chunk's scores into the list
+                { const u64 mk = __ballot(ok); if (ok) sc_all[1 + n_sc + lanes_below(mk, lane)] = best; n_sc += __popcll(mk); }
+                // second best (lariat.go:917-943): inactive alignments in order, a strict running maximum; every alignment that raises it gets its mate link
+                {
+                    const int cand = ok && !S.active[a];
+                    double v = cand ? best : -1.7976931348623157e308;
+                    double pm_ = v;   // inclusive prefix maximum over the lanes
+                    for (int d = 1; d < 64; d <<= 1) { const double o_ = __shfl_up(pm_, d); if (lane >= d && o_ > pm_) pm_ = o_; }
+                    double ex = __shfl_up(pm_, 1);
+                    if (lane == 0) ex = -1.7976931348623157e308;
+                    const double before = ex > g_sb ? ex : g_sb;
+                    const int raises = cand && v > before;
+                    if (raises) S.mate[a] = bm;
+                    const u64 rk = __ballot(raises);
+                    if (rk) {
+                        const int last = 63 - __clzll((unsigned long long)rk);
+                        sb_aln = shfl_i64(a, last);
+                        sb_raw = __shfl(best0, last);
+                        g_sb = __shfl(v, last);
+                    }
+                }
+            }
+            WAVE_SYNC();
+            pseudo = __shfl(pseudo, 0) + dev_pseudo_score(R, first, lmp);
+            if (lane == 0) sc_all[0] = pseudo;
+            n_sc += 1;
+            WAVE_SYNC();
+            if (sb_aln < 0) sb_raw = pseudo;
+            // the 15 best scores, largest first (sort.Float64s, then the last 15 from the top)
+            double total = 0.0;
+            for (int k = 0; k < 15 && k < n_sc; ++k) {
+                double v = -1.7976931348623157e308;
+                int at = -1;
+                for (int i = lane; i < n_sc; i += 64) { const double x = sc_all[i]; if (x > v || (x == v && at < 0)) { v = x; at = i; } }
+                for (int msk = 32; msk >= 1; msk >>= 1) {
+                    const double ov = __shfl_xor(v, msk);
+                    const int oa = __shfl_xor(at, msk);
+                    if (oa >= 0 && (at < 0 || ov > v || (ov == v && oa < at))) { v = ov; at = oa; }
+                }
+                total += pow(10.0, v);
+                WAVE_SYNC();
+                if (lane == 0) sc_all[at] = -1.7976931348623157e308;   // taken
+                WAVE_SYNC();
+            }
+            const i64 act = S.active_idx[gr];
+            if (lane == 0) {
+                S.second_best_idx[gr] = sb_aln; S.second_best_score[gr] = sb_raw;
+                S.as_score[gr] = dev_score_aln(R, S, improper, act, S.mate[act], 0.0);
+            }
+            for (i64 a = a0 + lane; a < a1; a += 64) {
+                if (!R.in_filtered[a]) continue;
+                double score = dev_score_aln(R, S, improper, a, S.mate[a], lmp);
+                double mapq = -10.0 * log10(1.0 - pow(10.0, score) / total);
+                double mmq = -10.0 * log10(1.0 - (1.0 / S.sum_move[a]));
+                mapq = (mapq != mapq || mmq != mmq) ? mapq + mmq : (mapq < mmq ? mapq : mmq);   // math.Min propagates NaN
+                mapq = (mapq != mapq) ? mapq : (60.0 < mapq ? 60.0 : mapq);
+                i64 cs = -1, ce = -1;
+                if (R.rid[a] >= 0 && cen_start[R.rid[a]] >= 0) { cs = cen_start[R.rid[a]]; ce = cen_end[R.rid[a]]; }
+                if (R.pos[a] > cs && R.pos[a] <= ce) mapq = 0.0;
+                S.mapq[a] = (mapq != mapq) ? (int)0x80000000 : (int)mapq;
+            }
+            WAVE_SYNC();
+        }
         RFA_T(12)
         // ---- markDuplicates: first-seen wins on (read1?, reversed, contig, pos, mate contig, mate pos) in read order ----
         {   // open-addressing table over the keys; a slot ends up holding the smallest read index of its key

@@ -4,6 +4,8 @@
 // The read model is lariat_amd/synth.py's (linked reads: a few long molecules per barcode, FR pairs, an error ramp along
 // the read, rare indels) at the speed a 50 M-pair run needs; names are not materialised, name_seed is a hash of the pair index.
 #include <math.h>
+#include <stdio.h>
+#include <zlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -166,4 +168,62 @@ extern "C" int lh_synth_reads(const uint8_t* pac, int64_t l_pac, int32_t n_conti
     for (int b = 0; b <= n_barcodes; ++b) bc_pair_off[b] = b * pairs_per_barcode;
     (void)l_pac;
     return LH_OK;
+}
+
+// The reads of lh_synth_reads as the reference's input: 9-line barcode-sorted FASTQ records (README.md:34-48 of the reference), gzip'ed when
+// gz_level > 0.  Read 1 gets `trim` random bases in front (the run trims them again: -trim_length); qualities are 'I'; barcode b of the batch is
+// the 16-mer of first_barcode + b in base 4 (sorted as the reference needs them) + "-1"; names are mol:<barcode>:<pair> (seven colon-separated
+// fields as -simulated wants: mol:bc:chrom:ms:me:pos1:pos2, with the truth positions when given).
+extern "C" int lh_synth_write_fastq9(const char* path, const uint8_t* seq, const int64_t* seq_off, const int32_t* bc_pair_off, int32_t n_barcodes, int64_t first_barcode,
+                                     int32_t trim, int32_t gz_level, uint64_t seed, const int32_t* truth_rid, const int64_t* truth_pos1, const int64_t* truth_pos2) {
+    if (!path || !seq || !seq_off || !bc_pair_off || n_barcodes <= 0 || trim < 0 || trim > 64) return lh_set_error_(LH_E_ARG, "lh_synth_write_fastq9: bad argument");
+    gzFile gz = nullptr;
+    FILE* fp = nullptr;
+    if (gz_level > 0) {
+        char mode[8];
+        snprintf(mode, sizeof mode, "wb%d", gz_level > 9 ? 9 : gz_level);
+        gz = gzopen(path, mode);
+        if (gz) gzbuffer(gz, 1 << 20);
+    } else fp = fopen(path, "wb");
+    if (!gz && !fp) return lh_set_error_(LH_E_IO, "lh_synth_write_fastq9: cannot open the output file");
+    std::vector<char> buf;
+    buf.reserve(1 << 22);
+    static const char B[5] = {'A', 'C', 'G', 'T', 'N'};
+    Rng g(seed, 0x9f);
+    bool ok = true;
+    auto flush = [&]() {
+        if (buf.empty()) return;
+        if (gz) ok = ok && gzwrite(gz, buf.data(), (unsigned)buf.size()) == (int)buf.size();
+        else ok = ok && fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+        buf.clear();
+    };
+    char tmp[256];
+    for (int32_t b = 0; b < n_barcodes && ok; ++b) {
+        char bc[20];
+        i64 v = first_barcode + b;
+        for (int k = 15; k >= 0; --k) { bc[k] = B[v & 3]; v >>= 2; }
+        bc[16] = '-'; bc[17] = '1'; bc[18] = 0;
+        for (int32_t p = bc_pair_off[b]; p < bc_pair_off[b + 1]; ++p) {
+            const i64 o1 = seq_off[2 * p], o2 = seq_off[2 * p + 1], o3 = seq_off[2 * p + 2];
+            int n = snprintf(tmp, sizeof tmp, "@mol:%s:%d:0:0:%lld:%lld\n", bc, truth_rid ? truth_rid[p] : 0, (long long)(truth_pos1 ? truth_pos1[p] : p), (long long)(truth_pos2 ? truth_pos2[p] : p));
+            buf.insert(buf.end(), tmp, tmp + n);
+            for (int k = 0; k < trim; ++k) buf.push_back(B[g.next() & 3]);
+            for (i64 i = o1; i < o2; ++i) buf.push_back(B[seq[i] > 4 ? 4 : seq[i]]);
+            buf.push_back('\n');
+            buf.insert(buf.end(), (size_t)(trim + (o2 - o1)), 'I');
+            buf.push_back('\n');
+            for (i64 i = o2; i < o3; ++i) buf.push_back(B[seq[i] > 4 ? 4 : seq[i]]);
+            buf.push_back('\n');
+            buf.insert(buf.end(), (size_t)(o3 - o2), 'I');
+            buf.push_back('\n');
+            buf.insert(buf.end(), bc, bc + 18);
+            static const char tail[] = "\nIIIIIIIIIIIIIIII\nACGTACGT\nIIIIIIII\n";
+            buf.insert(buf.end(), tail, tail + sizeof tail - 1);
+            if (buf.size() > (3u << 20)) flush();
+        }
+    }
+    flush();
+    if (gz) ok = (gzclose(gz) == Z_OK) && ok;
+    if (fp) ok = (fclose(fp) == 0) && ok;
+    return ok ? LH_OK : lh_set_error_(LH_E_IO, "lh_synth_write_fastq9: write failed");
 }

@@ -237,3 +237,46 @@ def test_hg38_scale_index_from_files(lib, oracle, tmp_path_factory):
         loaded.close()
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_config4_repeat_families_at_its_multiplicity(lib, oracle):
+    """configs[4] as SURVEY 8d defines it: 120 segmental-duplication families of 50-200 copies x 20 kb at 98-99.5 %, LINE- and SINE-like families,
+    40 ALT contigs, every read drawn ON the copies (workload.config4_genome) — tens to hundreds of candidates per read, up to 50 + 50 mate-rescue
+    attempts per pair (gobwa.go:286-325), thousands of raw molecules per barcode (lariat.go:1370-1408).  200 ordinary barcodes and one of 2,500
+    pairs whose reads come from 1,200 molecules (more than 1,000 candidate molecules survive scrapMolecules: the optimizer's 8 M^2 fastScore
+    calls) against the oracle on the same index, every field; no capacity error anywhere."""
+    g = workload.config4_genome(lib, 3060000000)
+    idx = lib.index_build_device(g["pac"], g["l_pac"], g["contigs"])
+    idx.set_alt(g["alt_flags"])
+    small = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 40, n_barcodes=200, pairs_per_barcode=100)
+    big = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 41, n_barcodes=1, pairs_per_barcode=2500, mol_min=1200, mol_max=1200)
+    seq = np.concatenate([small["seq"], big["seq"]])
+    seq_off = np.concatenate([small["seq_off"], big["seq_off"][1:] + small["seq_off"][-1]])
+    bco = np.concatenate([small["bc_pair_off"], big["bc_pair_off"][1:] + small["bc_pair_off"][-1]]).astype(np.int32)
+    seeds = np.concatenate([small["name_seed"], big["name_seed"]])
+    b = capi.Batch.from_arrays(seq, seq_off, bco, seeds)
+    n_pairs = int(bco[-1])
+    ctx = idx.context(n_pairs)
+    t0 = time.time()
+    res = ctx.align_barcodes(b)
+    dt = time.time() - t0
+    nc = np.diff(res.cand_off)
+    cnt = res.counters
+    print("configs[4]: %d pairs in %.2f s; candidates per read: mean %.1f, median %d, 99th percentile %d, max %d; %.1f rescue attempts per pair (%.1f M cells per pair)"
+          % (n_pairs, dt, nc.mean(), np.median(nc), np.percentile(nc, 99), nc.max(), cnt["n_rescue"] / n_pairs, cnt["rescue_cells"] / n_pairs / 1e6))
+    assert nc.mean() >= 10 and np.percentile(nc, 99) >= 100
+    # the 50-hit cap of the rescue loops binds: reads with more than 50 hits within rescue_score_delta of their best
+    best = np.maximum.reduceat(res.score, res.cand_off[:-1])
+    near = np.add.reduceat((res.score >= np.repeat(best, nc) - 25).astype(np.int64), res.cand_off[:-1])
+    assert (near > 50).mean() > 0.05
+    c0 = int(res.cand_off[2 * int(bco[-2])])
+    n_mol_big = int(res.molecule_id[c0:].max()) + 1
+    print("the 2,500-pair barcode: %d candidates, %d molecules after scrapMolecules" % (res.n_cand - c0, n_mol_big))
+    assert n_mol_big >= 1000
+    oidx = oracle.index_from_arrays(idx.export(), g["pac"])
+    oidx.set_alt(g["alt_flags"])
+    t0 = time.time()
+    ref = oidx.align_barcodes(b, threads=THREADS)
+    print("oracle: %.1f s on %d threads" % (time.time() - t0, THREADS))
+    helpers.assert_same_result(res, ref, inference=True)
+    assert cnt["n_rescue"] == ref.counters["n_rescue"] and cnt["rescue_cells"] == ref.counters["rescue_cells"]
