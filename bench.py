@@ -50,6 +50,21 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_quota_cores():
+    """the container's CPU-time quota in cores (cgroup v2 cpu.max / v1 cfs_quota_us), None when there is none: a box can show 256 CPUs and grant 32"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 1)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 1)
+    except Exception:
+        return None
+
+
 def bind_to_device_numa_node(local_rank):
     """pin this rank's host threads (read synthesis, the library's staging / BAM pools) to the NUMA node its GPU hangs off, BEFORE anything
     touches HIP: the device's PCI address from the KFD topology in sysfs (GPU nodes in KFD order = HIP device order unless *_VISIBLE_DEVICES
@@ -235,6 +250,10 @@ def main():
         ctx.close()   # its pools and the resident batches (~70 GB next to the 131 GB index) make room for the other legs
         if not a.no_extras and world == 1:   # the other legs and the CPU baseline: on the single-GPU run only
             out["host_to_host"] = host_to_host(lib, idx, keep_reads, n_pairs, opts)
+            try:
+                out["end_to_end"] = end_to_end(lib, idx, a, pac, l_pac, ctg, opts, local_rank)
+            except Exception as e:   # (informational leg: a full tmp directory must not cost the headline line)
+                out["end_to_end"] = {"failed": "%s: %s" % (type(e).__name__, e)}
             out.update(extras(lib, idx, first[1], n_pairs, opts, elapsed / max(1, len(my_batches))))
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, idx, pac, first[0])
@@ -410,6 +429,145 @@ def host_to_host(lib, idx, reads_list, n_pairs, opts):
             "how": "one context; a second host thread stages batch k+1 (lh_batch_stage_slot) under batch k's kernels; batch k's result is copied out under batch k+1's (lh_result_download_begin/_end)"}
 
 
+def end_to_end(lib, idx, a, pac, l_pac, ctg, opts, local_rank):
+    """the whole drop-in path, files to files: 9-line barcode-sorted FASTQ.gz chunk files (written by this run: no input exists offline) ->
+    lh_ingest_* (fastqreader/reader.go:176-260, one reader thread per chunk file, as Long Ranger runs one lariat per chunk) -> staged upload ->
+    lh_align_resident -> overlapped download -> lh_bam_append / lh_bam_close (bamwriter.go:618-657: bc_sorted_bam.bam + the position buckets; one
+    writer per chunk, driven by a pool of host threads).  One context: batch k + 1 is staged and batch k - 1's result collected under batch k's
+    kernels, as in host_to_host.  Reports the rate of the whole pipe and each stage's own rate (its pairs over the busiest thread's busy time)."""
+    import queue
+    import shutil
+    import tempfile
+    import threading
+    from lariat_amd import capi, workload
+    cores = len(os.sched_getaffinity(0))
+    n_chunks, chunk_bc = 8, max(1, a.barcodes // 4)          # 8 chunk files of a quarter of a headline batch: 4 M pairs at the defaults
+    chunk_pairs = chunk_bc * a.pairs_per_barcode
+    n_readers = min(n_chunks, max(1, cores // 4))
+    n_bam = min(n_chunks, max(1, cores // 8))
+    bam_inner = max(1, (cores - n_readers - 2) // n_bam)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (24 << 30) else None
+    d = tempfile.mkdtemp(prefix="lh_e2e_", dir=base)
+    try:
+        t0 = time.time()
+        paths = [os.path.join(d, "chunk%02d.fastq.gz" % k) for k in range(n_chunks)]
+
+        def write(k):
+            r = lib.synth_reads(pac, l_pac, ctg, seed=workload.READS_SEED + 900 + k, n_barcodes=chunk_bc, pairs_per_barcode=a.pairs_per_barcode, threads=max(1, cores // n_chunks))
+            lib.write_fastq9(paths[k], r, first_barcode=k * chunk_bc, trim=7, gz_level=1, seed=k)
+        th = [threading.Thread(target=write, args=(k,)) for k in range(n_chunks)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        t_write = time.time() - t0
+        fq_bytes = sum(os.path.getsize(p) for p in paths)
+        cont = idx.contigs()
+        names, lens = [c[0] for c in cont], [c[1] for c in cont]
+        ctx = idx.context(chunk_pairs)
+        q_in, q_out = queue.Queue(maxsize=2 * n_readers), [queue.Queue() for _ in range(n_bam)]
+        busy = {"read": [0.0] * n_readers, "bam": [0.0] * n_bam, "align": 0.0}
+        errs = []
+
+        def reader(t):
+            try:
+                for k in range(t, n_chunks, n_readers):
+                    rd = lib.ingest(paths[k], trim=7, max_pairs=chunk_pairs)
+                    while True:
+                        ts = time.perf_counter()
+                        b = rd.next(views_only=True)
+                        busy["read"][t] += time.perf_counter() - ts
+                        if b.n_pairs == 0:
+                            break
+                        q_in.put((k, b))
+                        if b.at_eof:
+                            break
+                    rd.close()
+            except Exception as e:   # noqa
+                errs.append(e)
+            q_in.put(None)
+
+        def bam(t):
+            writers = {}
+            try:
+                while True:
+                    item = q_out[t].get()
+                    if item is None:
+                        break
+                    k, res, b = item
+                    ts = time.perf_counter()
+                    if k not in writers:
+                        os.makedirs(os.path.join(d, "out%02d" % k))
+                        writers[k] = lib.bam_writer(os.path.join(d, "out%02d" % k), names, lens, first_chunk=(k == 0), command_line="bench.py end_to_end", threads=bam_inner)
+                    writers[k].append(res, b)
+                    b.close()
+                    busy["bam"][t] += time.perf_counter() - ts
+                ts = time.perf_counter()
+                for w in writers.values():
+                    w.close()
+                busy["bam"][t] += time.perf_counter() - ts
+            except Exception as e:   # noqa
+                errs.append(e)
+
+        t_start = time.perf_counter()
+        rth = [threading.Thread(target=reader, args=(t,)) for t in range(n_readers)]
+        bth = [threading.Thread(target=bam, args=(t,)) for t in range(n_bam)]
+        [t.start() for t in rth + bth]
+        done_readers, n_pairs, n_batches = 0, 0, 0
+        prev = None      # the batch whose result is still on the device
+        cur = None
+
+        def next_batch():
+            nonlocal done_readers
+            while done_readers < n_readers:
+                item = q_in.get()
+                if item is None:
+                    done_readers += 1
+                    continue
+                return item
+            return None
+        cur = next_batch()
+        if cur is not None:
+            ctx.upload_slot(1, cur[1])
+        slot = 1
+        while cur is not None and not errs:
+            ctx.select(slot)
+            nxt = next_batch()
+            st = None
+            if nxt is not None:
+                st = threading.Thread(target=lambda: ctx.stage_slot(3 - slot, nxt[1]))
+                st.start()
+            ts = time.perf_counter()
+            ctx.align_resident(opts)
+            busy["align"] += time.perf_counter() - ts
+            if prev is not None:
+                res = ctx.download_end()
+                q_out[prev[0] % n_bam].put((prev[0], res, prev[1]))
+            ctx.download_begin()
+            if st is not None:
+                st.join()
+            n_pairs += cur[1].n_pairs
+            n_batches += 1
+            prev, cur, slot = cur, nxt, 3 - slot
+        if prev is not None:
+            res = ctx.download_end()
+            q_out[prev[0] % n_bam].put((prev[0], res, prev[1]))
+        for q in q_out:
+            q.put(None)
+        [t.join() for t in rth + bth]
+        dt = time.perf_counter() - t_start
+        ctx.close()
+        if errs:
+            raise errs[0]
+        bam_bytes = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(d) for f in fs if f.endswith(".bam"))
+        rates = {"ingest": n_pairs / max(busy["read"]), "align": n_pairs / busy["align"], "bam": n_pairs / max(busy["bam"])}
+        return {"pairs_per_s": round(n_pairs / dt, 1), "pairs": n_pairs, "batches": n_batches, "wall_s": round(dt, 2), "bound_by": min(rates, key=rates.get),
+                "stage_pairs_per_s": {k: round(v, 1) for k, v in rates.items()}, "reader_threads": n_readers, "bam_threads": n_bam, "bam_compress_threads_per_writer": bam_inner,
+                "host_cores": cores, "cpu_quota_cores": cpu_quota_cores(), "fastq_gz_MB": round(fq_bytes / 1e6, 1), "bam_MB": round(bam_bytes / 1e6, 1), "files_written_in_s": round(t_write, 1),
+                "how": "%d chunk files of %d pairs (9-line FASTQ.gz, %s) -> %d reader threads (lh_ingest_*) -> one context (staged upload, overlapped download) -> %d writer threads "
+                       "(lh_bam_append: bc_sorted_bam.bam + position buckets per chunk)" % (n_chunks, chunk_pairs, "tmpfs" if base else "tmp", n_readers, n_bam)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def repeats_leg(lib, a, local_rank, opts, steps=3):
     """BASELINE.json configs[4] on this GPU, in the default run: the hg38-scale genome of workload.config4_genome — 120 segmental-duplication
     families of 50-200 copies x 20 kb at 98-99.5 %, 40 LINE-like and 80 SINE-like families, 40 ALT contigs (is_alt) — with EVERY read drawn on
@@ -503,7 +661,7 @@ def cpu_baseline(a, idx, pac, reads):
     t0 = time.perf_counter()
     oidx.time_align(sub, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(p1 / dt, 1), "unit": "read-pairs/s", "cores": cores, "kind": "port",
+    return {"value": round(p1 / dt, 1), "unit": "read-pairs/s", "cores": cores, "cpu_quota_cores": cpu_quota_cores(), "kind": "port",
             "sample": "first %d barcodes (%d pairs) of step 0's batch against the same hg38-scale index, %.1f s wall on %d threads" % (nb, p1, dt, cores)}
 
 

@@ -765,13 +765,15 @@ class LhIngestBatch(C.Structure):
 class IngestBatch:
     """one lh_ingest_batch: `.c_batch` goes to Context.upload / align_barcodes; text columns are exposed as lists of bytes"""
 
-    def __init__(self, lib, ptr):
+    def __init__(self, lib, ptr, views_only=False):
         self.lib, self.ptr = lib, ptr
         b = ptr.contents
         self.c_batch = b.batch
         self.c = b.batch   # so that an IngestBatch can be handed to Context.upload / align_barcodes like a Batch
         self.n_pairs, self.n_sets = int(b.batch.n_pairs), int(b.n_sets)
         self.first_set_index, self.at_eof = int(b.first_set_index), bool(b.at_eof)
+        if views_only:   # (a host that only passes the batch on: no numpy copies of its arrays)
+            return
         self.bc_pair_off = _view(b.batch.bc_pair_off, self.n_sets + 1, np.int32).copy()
         self.bc_do_rfa = _view(b.batch.bc_do_rfa, self.n_sets, np.uint8).copy()
         self.set_complete = _view(b.set_complete, self.n_sets, np.uint8).copy()
@@ -840,10 +842,10 @@ class Ingest:
         self.h = C.c_void_p()
         lib.check(lib.L.lh_ingest_open(path.encode(), int(trim), int(cap), int(chunk), C.byref(self.h)))
 
-    def next(self, max_pairs=None):
+    def next(self, max_pairs=None, views_only=False):
         p = C.POINTER(LhIngestBatch)()
         self.lib.check(self.lib.L.lh_ingest_next(self.h, int(max_pairs or self.max_pairs), C.byref(p)))
-        return IngestBatch(self.lib, p)
+        return IngestBatch(self.lib, p, views_only)
 
     def __iter__(self):
         while True:

@@ -186,13 +186,33 @@ bool flush(lh_bam_writer* w, bool all) {
     for (int t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (auto& t : th) t.join();
-    std::vector<size_t> done(w->outs.size(), 0);
-    for (Job& j : jobs) {
-        if (!j.ok) return false;
-        Out& o = w->outs[(size_t)j.out];
-        if (fwrite(j.z.data(), 1, j.z.size(), o.f) != j.z.size()) return false;
-        done[(size_t)j.out] = j.off + j.n;
+    // the compressed blocks go out file by file, the files side by side (jobs are grouped by file, in order): the first file, bc_sorted_bam.bam,
+    // holds half of the bytes, the position buckets share the rest
+    std::vector<size_t> done(w->outs.size(), 0), first_job(w->outs.size() + 1, jobs.size());
+    for (size_t i = jobs.size(); i-- > 0;) first_job[(size_t)jobs[i].out] = i;
+    for (size_t o = w->outs.size(); o-- > 0;) if (first_job[o] == jobs.size()) first_job[o] = first_job[o + 1];
+    std::atomic<size_t> next_out{0};
+    std::atomic<bool> all_ok{true};
+    auto write_out = [&]() {
+        for (size_t o = next_out++; o < w->outs.size(); o = next_out++) {
+            Out& out = w->outs[o];
+            for (size_t i = first_job[o]; i < jobs.size() && (size_t)jobs[i].out == o; ++i) {
+                Job& j = jobs[i];
+                if (!j.ok || fwrite(j.z.data(), 1, j.z.size(), out.f) != j.z.size()) { all_ok = false; return; }
+                done[o] = j.off + j.n;
+                std::string().swap(j.z);
+            }
+        }
+    };
+    {
+        int wt = w->threads < 1 ? 1 : (w->threads > 16 ? 16 : w->threads);
+        if ((size_t)wt > w->outs.size()) wt = (int)w->outs.size();
+        std::vector<std::thread> wth;
+        for (int t = 1; t < wt; ++t) wth.emplace_back(write_out);
+        write_out();
+        for (auto& t : wth) t.join();
     }
+    if (!all_ok) return false;
     for (size_t o = 0; o < w->outs.size(); ++o) if (done[o]) w->outs[o].pending.erase(0, done[o]);
     return true;
 }

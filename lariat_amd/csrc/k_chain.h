@@ -15,6 +15,9 @@ struct DChainTmp {
     i64 pos, last_rbeg;
     int32_t first_qbeg, last_qbeg, last_len, rid, n, head, tail, w, kept, first, beg, end;
 };
+#ifndef LH_CHAIN_LDS
+#define LH_CHAIN_LDS 256   // seeds (and so chains) of a read whose tables k_chain keeps in LDS
+#endif
 struct DChain {
     i64 pos;
     int32_t rid, n, seed_start, w, kept, is_alt;
@@ -28,6 +31,12 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
                                                int32_t* __restrict__ ord, int32_t* __restrict__ srt, DChain* __restrict__ chains,
                                                DSeed* __restrict__ cseeds, int32_t* __restrict__ n_chains, int32_t* __restrict__ status,
                                                const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
+    // a read's chain table, its two index arrays and its seeds live in LDS while they fit (reads on repeat families have dozens of chains and a
+    // hundred seeds: every step of the loops below is a dependent access, ~1 us from HBM); larger reads use the HBM scratch as before
+    __shared__ DChainTmp Cs[LH_CHAIN_LDS];
+    __shared__ int32_t ods[LH_CHAIN_LDS + 1], sts[LH_CHAIN_LDS + 1], nxs[LH_CHAIN_LDS], rids[LH_CHAIN_LDS];
+    __shared__ DSeed sds[LH_CHAIN_LDS];
+    __shared__ int32_t sh_n;
     const int lane = LANE();
     const int n_items = list ? *list_count : n_reads;   // with a list: the reads k_chain_lane left to this kernel
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -40,12 +49,17 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
         continue;
     }
     int len = (int)(seq_off[r + 1] - seq_off[r]);
-    const DSeed* sd_ = seeds + base;
-    const int32_t* rid_ = s_rid + base;
-    int32_t* nx = s_next + base;
-    DChainTmp* C = ct + base;
-    int32_t* od = ord + base;
-    int32_t* st = srt + base;
+    const bool in_lds = S <= LH_CHAIN_LDS;
+    const DSeed* sd_ = in_lds ? sds : seeds + base;
+    const int32_t* rid_ = in_lds ? rids : s_rid + base;
+    int32_t* nx = in_lds ? nxs : s_next + base;
+    DChainTmp* C = in_lds ? Cs : ct + base;
+    int32_t* od = in_lds ? ods : ord + base;
+    int32_t* st = in_lds ? sts : srt + base;
+    if (in_lds) {
+        for (int s = lane; s < S; s += 64) { sds[s] = seeds[base + s]; rids[s] = s_rid[base + s]; }
+        WAVE_SYNC();
+    }
     int nch = 0;
     for (int s = 0; s < S; ++s) {
         int rid = rid_[s];
@@ -122,40 +136,62 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
         C[k].end = c.last_qbeg + c.last_len;
     }
     WAVE_SYNC();
-    // mem_chain_flt (order dependent): lane 0
+    // mem_chain_flt (order dependent): the unstable introsort by weight on lane 0; the greedy scan chain by chain, every chain against the
+    // kept ones so far by the whole wave (the reference's inner loop stops at the first kept chain that shadows it: the lowest set bit)
+    int n = 0;
     if (lane == 0) {
-        int n = 0;
         for (int k = 0; k < nch; ++k) {   // chains in position order (B-tree traversal), dropping light ones
             int id = od[k];
             C[id].first = -1; C[id].kept = 0;
             if (C[id].w < o.min_chain_weight) continue;
             st[n++] = id;
         }
-        int nk = 0;   // kept-chain list reuses od[]
         if (n > 0) {
             dev_introsort(n, st, [&](int x, int y) { return C[x].w > C[y].w; }, o.wd);
             C[st[0]].kept = 3;
-            od[nk++] = 0;
-            for (int i = 1; i < n; ++i) {
-                int large_ovlp = 0, k;
-                DChainTmp ai = C[st[i]];
-                for (k = 0; k < nk; ++k) {
-                    int j = od[k];
-                    DChainTmp aj = C[st[j]];
+            od[0] = 0;
+        }
+        sh_n = n;
+    }
+    WAVE_SYNC();
+    n = sh_n;
+    if (n > 0) {
+        int nk = 1;   // kept-chain list reuses od[]
+        for (int i = 1; i < n; ++i) {
+            const DChainTmp ai = C[st[i]];
+            const int ai_alt = ix.contig_alt && ix.contig_alt[ai.rid];
+            int large_ovlp = 0, shadowed = 0;
+            for (int k0 = 0; k0 < nk && !shadowed; k0 += 64) {
+                const int k = k0 + lane;
+                int ov = 0, brk = 0, j = 0;
+                if (k < nk) {
+                    j = od[k];
+                    const DChainTmp aj = C[st[j]];
                     int b_max = aj.beg > ai.beg ? aj.beg : ai.beg;
                     int e_min = aj.end < ai.end ? aj.end : ai.end;
-                    if (e_min > b_max && (!(ix.contig_alt && ix.contig_alt[aj.rid]) || (ix.contig_alt && ix.contig_alt[ai.rid]))) {   // have overlap; don't consider ovlp where the kept chain is ALT while the current chain is primary
+                    if (e_min > b_max && (!(ix.contig_alt && ix.contig_alt[aj.rid]) || ai_alt)) {   // have overlap; don't consider ovlp where the kept chain is ALT while the current chain is primary
                         int li = ai.end - ai.beg, lj = aj.end - aj.beg;
                         int min_l = li < lj ? li : lj;
                         if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {   // significant overlap
-                            large_ovlp = 1;
-                            if (aj.first < 0) C[st[j]].first = i;
-                            if (ai.w < aj.w * o.drop_ratio && aj.w - ai.w >= o.min_seed_len << 1) break;
+                            ov = 1;
+                            brk = ai.w < aj.w * o.drop_ratio && aj.w - ai.w >= o.min_seed_len << 1;
                         }
                     }
                 }
-                if (k == nk) { od[nk++] = i; C[st[i]].kept = large_ovlp ? 2 : 3; }
+                const u64 mbrk = __ballot(brk);
+                const int kb = mbrk ? __ffsll((unsigned long long)mbrk) - 1 : 64;   // the scan ends AT the first shadowing chain
+                if (ov && lane <= kb && C[st[j]].first < 0) C[st[j]].first = i;
+                large_ovlp |= __any(ov && lane <= kb);
+                shadowed = mbrk != 0;
             }
+            WAVE_SYNC();
+            if (!shadowed) {
+                if (lane == 0) { od[nk] = i; C[st[i]].kept = large_ovlp ? 2 : 3; }
+                nk++;
+                WAVE_SYNC();
+            }
+        }
+        if (lane == 0) {
             for (int i = 0; i < nk; ++i) {
                 int f = C[st[od[i]]].first;
                 if (f >= 0) C[st[f]].kept = 1;
@@ -169,6 +205,9 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
             for (; i < n; ++i)
                 if (C[st[i]].kept < 3) C[st[i]].kept = 0;
         }
+    }
+    WAVE_SYNC();
+    if (lane == 0) {
         // emit kept chains in sorted order
         int m = 0, sstart = 0;
         for (int i = 0; i < n; ++i) {

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64) k_diag_gosort(int n_sorts, const int32_t* 
         i64* kp = keys_a + first[k];
         int32_t* ip = perm_serial + first[k];
         dev_gosort(first[k + 1] - first[k], [&](int i, int j) { return kp[i] < kp[j]; },
-                   [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; });
+                   [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; }, qa + lane, 64);
     }
     WAVE_SYNC();
     wave_gosort(n_sorts, first, [&](int i, int j) { return keys_b[i] < keys_b[j]; },

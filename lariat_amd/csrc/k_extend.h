@@ -171,6 +171,9 @@ __device__ __forceinline__ ExtRes wave_ksw_extend2(const DIndex& ix, const DOpts
     return r;
 }
 
+#ifndef LH_WAVE_NARROW_MAX_LOSS
+#define LH_WAVE_NARROW_MAX_LOSS 61   // diagonal loss up to which the wave kernel runs its DP in a provably sufficient band (12 mismatches with the default scoring: band 55)
+#endif
 // K4, one wavefront per read.  Without a list: grid = n_reads waves.  With a list (k_extend2.h hands over the reads that
 // do not suit its lane-per-read kernel): the waves stride over list[range[0] .. range[1]).
 __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, const int32_t* __restrict__ list, const int32_t* __restrict__ range,
@@ -296,22 +299,31 @@ __global__ void __launch_bounds__(64) k_extend(DIndex ix, DOpts o, int n_reads, 
                 int aw = o.w;
                 // ksw_extend2 without the DP when it is provably the ungapped extension (the argument is in k_extend2.h, ext_control):
                 // every lane walks the diagonal (the same walk: no divergence), eight bases per step against the 4-bit text
-                int proven = 0;
+                // ... and in a provably sufficient band when the diagonal loses more than one gap's cost but less than zdrop and never drops to
+                // zero (same argument, ext_control: with a loss P over the whole query, cells further than B off the diagonal, gap_cost(B + 1) > P,
+                // and cells that depend on them stay strictly below their row's diagonal cell: ksw_extend2(w) and ksw_extend2(B) return the same).
+                // A read on a repeat family is extended on dozens of copies that differ from it in a handful of bases: the band is ~10 wide, not 100.
+                int proven = 0, narrow = 0;
                 if (tlen >= qlen) {
                     const int thr = (o.o_ins + o.e_ins) < (o.o_del + o.e_del) ? (o.o_ins + o.e_ins) : (o.o_del + o.e_del);
-                    const DiagScan ds = dev_diag_scan(ix, o, seq + off, q4, off, qoff, qstep, qlen, tc0, tstep, h0, thr);
-                    if (ds.done) {   // (the walk stops at a loss of thr: done means P < thr)
+                    const int p_cap = o.zdrop > 0 && o.zdrop < LH_WAVE_NARROW_MAX_LOSS ? o.zdrop : LH_WAVE_NARROW_MAX_LOSS;
+                    const DiagScan ds = dev_diag_scan(ix, o, seq + off, q4, off, qoff, qstep, qlen, tc0, tstep, h0, p_cap > thr ? p_cap : thr);
+                    if (ds.done && ds.P < thr) {
                         e.score = ds.mx; e.qle = ds.mxk + 1; e.tle = ds.mxk + 1; e.gscore = ds.sc_run; e.gtle = qlen; e.max_off = 0;
                         a.score = e.score;
                         proven = 1;
+                    } else if (ds.done && p_cap > thr) {
+                        narrow = 1;
+                        while (o.o_ins + o.e_ins * (narrow + 1) <= ds.P || o.o_del + o.e_del * (narrow + 1) <= ds.P) ++narrow;
                     }
                 }
                 for (int i = 0; i < 2 && !proven; ++i) {   // MAX_BAND_TRY
                     int prev = a.score;
                     aw = o.w << i;
-                    if (qlen <= 64) e = wave_ksw_extend2<1>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, aw, bonus, o.zdrop, h0, lane, &cells);
-                    else if (qlen <= 128) e = wave_ksw_extend2<2>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, aw, bonus, o.zdrop, h0, lane, &cells);
-                    else e = wave_ksw_extend2<4>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, aw, bonus, o.zdrop, h0, lane, &cells);
+                    const int band = narrow && narrow < aw ? narrow : aw;
+                    if (qlen <= 64) e = wave_ksw_extend2<1>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, band, bonus, o.zdrop, h0, lane, &cells);
+                    else if (qlen <= 128) e = wave_ksw_extend2<2>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, band, bonus, o.zdrop, h0, lane, &cells);
+                    else e = wave_ksw_extend2<4>(ix, o, q, qoff, qstep, qlen, tc0, tstep, tlen, band, bonus, o.zdrop, h0, lane, &cells);
                     a.score = e.score;
                     if (a.score == prev || e.max_off < (aw >> 1) + (aw >> 2)) break;
                 }

@@ -159,6 +159,7 @@ struct RfaTab {   // carved from the wave's slab
     double* P;           // [M]
     u64 *dk0, *dk1, *dk2, *dk3;   // [R] markDuplicates keys
     int32_t* htab;       // [<= 4R] open-addressing table over the keys
+    int32_t* gstk;       // [3 * LH_GOSORT_STK * 64] the lanes' stacks of dev_gosort
     int32_t* bestT;      // [R*M] best_alignment_for_read of molecule m for local read r at [r*M + m]; bit 30: it pairs with
                          // the molecule's best alignment of the mate read (static after markBest); -1: nil
 };
@@ -458,6 +459,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         CARVE(act_store, int32_t, NC) CARVE(act_cand, int32_t, nR) CARVE(act_slot, int32_t, nR) CARVE(tdel, int32_t, nR) CARVE(tset, int32_t, nR)
         CARVE(mflag, int32_t, NC) CARVE(P, double, NC)
         CARVE(dk0, u64, nR) CARVE(dk1, u64, nR) CARVE(dk2, u64, nR) CARVE(dk3, u64, nR) CARVE(htab, int32_t, (size_t)1 << hbits)
+        CARVE(gstk, int32_t, 3 * LH_GOSORT_STK * 64)
         so = (so + 7) & ~(size_t)7;
         T.bestT = (int32_t*)(slab + so);
         size_t best_cap = ((size_t)slab_bytes > so) ? ((size_t)slab_bytes - so) / 4 : 0;
@@ -546,7 +548,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     WAVE_SYNC();
                     if (lane == 0)
                         dev_gosort(n, [&](int i, int j) { return kp[i] < kp[j]; },
-                                   [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; });
+                                   [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; }, T.gstk + lane, 64);
                     WAVE_SYNC();
                     for (int e = lane; e < n; e += 64) T.plist[b0 + e] = ip[e];
                 }
@@ -559,7 +561,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 i64* kp = spos + b0;
                 int32_t* ip = sidx + b0;
                 dev_gosort(n, [&](int i, int j) { return kp[i] < kp[j]; },
-                           [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; });
+                           [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = ip[i]; ip[i] = ip[j]; ip[j] = u; }, T.gstk + lane, 64);
             }
             WAVE_SYNC();
             for (int i = lane; i < NCf; i += 64) T.plist[i] = sidx[i];
@@ -1116,7 +1118,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             if (ovf) status[gr] |= LH_ST_POOL_OVERFLOW;
             if (ncand == 0) continue;
-            dev_gosort(ncand, [&](int i, int j) { return R.score[cidx[i]] > R.score[cidx[j]]; }, [&](int i, int j) { i64 t = cidx[i]; cidx[i] = cidx[j]; cidx[j] = t; });
+            dev_gosort(ncand, [&](int i, int j) { return R.score[cidx[i]] > R.score[cidx[j]]; }, [&](int i, int j) { i64 t = cidx[i]; cidx[i] = cidx[j]; cidx[j] = t; }, T.gstk + lane, 64);
             i64 c = cidx[0];
             double mapq;
             double second_best = dev_score_aln(R, S, improper, P, -1, 0.0) + dev_pseudo_score(R, c, 0.0);

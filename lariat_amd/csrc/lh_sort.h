@@ -32,9 +32,12 @@ template <class T, class Lt> __device__ inline void dev_combsort(int n, T* a, Lt
     if (gap != 1) dev_insertsort(a, a + n, lt);
 }
 
+// (its stack lives in LDS: one lane of a single-wave block runs it; a private array would be 1.7 KB of scratch in every kernel that sorts)
+#define LH_ISORT_STK 64
 template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, Lt lt, int32_t* wdp) {
-    struct Stk { T *left, *right; int depth; };
-    Stk stack[72];
+    struct Stk { int32_t left, right, depth; };
+    __shared__ Stk lh_isort_stack[LH_ISORT_STK];
+    Stk* const stack = lh_isort_stack;
     int d;
     T rp, swap_tmp;
     T *s, *t, *i, *j, *k;
@@ -69,17 +72,17 @@ template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, L
             }
             swap_tmp = *i; *i = *t; *t = swap_tmp;
             if (LH_UNI(i - s > t - i)) {
-                if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
+                if (i - s > 16) { if (top - stack >= LH_ISORT_STK) { wdp[1] = 1; return; } top->left = (int32_t)(s - a); top->right = (int32_t)(i - 1 - a); top->depth = d; ++top; }
                 s = t - i > 16 ? i + 1 : t;
             } else {
-                if (t - i > 16) { top->left = i + 1; top->right = t; top->depth = d; ++top; }
+                if (t - i > 16) { if (top - stack >= LH_ISORT_STK) { wdp[1] = 1; return; } top->left = (int32_t)(i + 1 - a); top->right = (int32_t)(t - a); top->depth = d; ++top; }
                 t = i - s > 16 ? i - 1 : s;
             }
         } else {
             if (LH_UNI(top == stack)) {
                 dev_insertsort(a, a + n, lt);
                 return;
-            } else { --top; s = top->left; t = top->right; d = top->depth; }
+            } else { --top; s = a + top->left; t = a + top->right; d = top->depth; }
         }
     }
 }
@@ -150,17 +153,20 @@ template <class L, class S> __device__ inline void gs_pivot(L& less, S& swp, int
     swp(pivot, b - 1);
     *midlo = b - 1; *midhi = c;
 }
-template <class L, class S> __device__ inline void dev_gosort(int n, L less, S swp) {
+// stk: LH_GOSORT_STK frames of three words for THIS lane, word w of frame f at stk[(3 * f + w) * stride] (the caller's memory: a private array
+// would be scratch; the smaller side is finished first, so at most log2(n) + 1 frames are ever waiting)
+#define LH_GOSORT_STK 40
+template <class L, class S> __device__ inline void dev_gosort(int n, L less, S swp, int32_t* stk, int stride) {
     // quickSort(data, 0, n, maxDepth(n)) with the recursion on the smaller side turned into an explicit stack
-    struct Fr { int a, b, depth; };
-    Fr st[72];
     int sp = 0;
     int depth = 0;
     for (int i = n; i > 0; i >>= 1) depth++;
-    st[sp++] = Fr{0, n, depth * 2};
+#define GS_PUSH(a_, b_, d_) { if (sp < LH_GOSORT_STK) { stk[(3 * sp) * stride] = (a_); stk[(3 * sp + 1) * stride] = (b_); stk[(3 * sp + 2) * stride] = (d_); } ++sp; }
+    GS_PUSH(0, n, depth * 2)
     while ((sp > 0)) {
-        Fr f = st[--sp];
-        int a = f.a, b = f.b, maxDepth = f.depth;
+        --sp;
+        if (sp >= LH_GOSORT_STK) return;   // (cannot happen for n < 2^39; the result would be unsorted rather than memory overwritten)
+        int a = stk[(3 * sp) * stride], b = stk[(3 * sp + 1) * stride], maxDepth = stk[(3 * sp + 2) * stride];
         bool done = false;
         while ((b - a > 12)) {
             if ((maxDepth == 0)) { gs_heapsort(less, swp, a, b); done = true; break; }
@@ -169,8 +175,8 @@ template <class L, class S> __device__ inline void dev_gosort(int n, L less, S s
             gs_pivot(less, swp, a, b, &mlo, &mhi);
             // Go recurses into the smaller side FIRST and then loops on the larger one.  The two sides are disjoint
             // index ranges, so finishing the larger side later (explicit stack) issues the same Less/Swap calls per range.
-            if (mlo - a < b - mhi) { st[sp++] = Fr{mhi, b, maxDepth}; b = mlo; }
-            else { st[sp++] = Fr{a, mlo, maxDepth}; a = mhi; }
+            if (mlo - a < b - mhi) { GS_PUSH(mhi, b, maxDepth) b = mlo; }
+            else { GS_PUSH(a, mlo, maxDepth) a = mhi; }
         }
         if (done) continue;
         if (b - a > 1) {
@@ -180,6 +186,8 @@ template <class L, class S> __device__ inline void dev_gosort(int n, L less, S s
         }
     }
 }
+
+#undef GS_PUSH
 
 // ---- the same sort by a whole wave ----
 // quickSort's two sides after a doPivot are disjoint index ranges, and so are the index spaces of separate sorts: whichever lane works
