@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 3
+#define LH_ABI_VERSION 4
 
 /* status codes */
 #define LH_OK 0

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LARIAT_HIP_LIB") or os.path.join(_HERE, "_build", "liblariat_hip.so")
 
 LH_OK = 0
-LH_ABI_VERSION = 3
+LH_ABI_VERSION = 4
 LH_E_ARG, LH_E_IO, LH_E_HIP, LH_E_CAPACITY, LH_E_NODEVICE, LH_E_LIMIT = 1, 2, 3, 4, 5, 6
 # lh_opts.flags
 LH_REC_DEBUG_TAGS = 1

@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
                         w = w > min_w ? w : min_w;
                         const int n_col_ = lq < 2 * w + 1 ? lq : 2 * w + 1;
                         uint8_t* const z = rlen * n_col_ <= LH_ZLDS ? zl : zg;
-                        score = wave_ksw_global2(ix, o, q, qoff, qstep, lq, t0, tstep, rlen, w, z, lane, &cells);
+                        score = 2 * w + 1 <= 64 ? wave_ksw_global2_band(ix, o, q, qoff, qstep, lq, t0, tstep, rlen, w, z, lane, &cells)
+                                               : wave_ksw_global2(ix, o, q, qoff, qstep, lq, t0, tstep, rlen, w, z, lane, &cells);
                         WAVE_SYNC();
                         if (lane == 0) {   // backtrack
                             const int n_col = n_col_;

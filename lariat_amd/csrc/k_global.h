@@ -92,6 +92,78 @@ __device__ __forceinline__ int wave_ksw_global2(const DIndex& ix, const DOpts& o
     return wave_readlane(v, src);
 }
 
+// The same for a band of at most 64 columns (2w + 1 <= 64: the usual case, a read against a copy that differs in a handful of bases), in BAND
+// coordinates: lane d holds column j = i - w + d of row i.  eh[j].h for the next row is the H this lane has just computed (column j + 1 of row
+// i + 1 reads H(i, j)): it stays where it is; E(i + 1, j) is needed one lane to the left; F is a scan over the lanes as above.  One pass over 64
+// lanes per row whatever the query length, no slab loop.  The direction bytes keep ksw_global2's layout (row i: columns from beg = max(0, i - w)).
+#ifdef LH_EMU
+__device__ __forceinline__ int wave_shl1_i32(int v, int fill) { int o = __shfl_down(v, 1); return LANE() == 63 ? fill : o; }   // lane i <- lane i+1
+#else
+__device__ __forceinline__ int wave_shl1_i32(int v, int fill) { return LH_DPP(fill, v, 0x130, 0xF); }   // wave_shl:1
+#endif
+__device__ __forceinline__ int wave_ksw_global2_band(const DIndex& ix, const DOpts& o, const uint8_t* qarr, int qoff, int qstep, int qlen, i64 tcoord0, int tstep,
+                                                     int tlen, int w, uint8_t* z, int lane, u64* cells) {
+    const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const int d = lane;
+    int H, E = LH_MINUS_INF;
+    {   // eh[] before the first row: lane d = column d - w
+        const int j = d - w;
+        H = j == 0 ? 0 : ((j >= 1 && j <= qlen && j <= w) ? -(o_ins + e_ins * j) : LH_MINUS_INF);
+    }
+    int last = qlen <= w ? -(o_ins + e_ins * qlen) : LH_MINUS_INF;   // eh[qlen].h
+    int tchunk = 4;
+    u64 ncell = 0;
+    if (tlen > 100000) { o.wd[5] = 1; o.wd[6] = tlen; tlen = 0; }
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) {
+            int ii = i + lane;
+            tchunk = ii < tlen ? dev_ref_base(ix, tcoord0 + (i64)tstep * ii) : 4;
+        }
+        const int tb = wave_readlane(tchunk, i & 63);
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int j = i - w + d;
+        const int in = j >= beg && j < end;
+        int mm = LH_MINUS_INF, tins = LH_MINUS_INF, dir = 0;
+        if (in) {
+            const int qv = qarr[qoff + qstep * j];
+            const int sc = (tb > 3 || qv > 3) ? -1 : (tb == qv ? a_ : -b_);
+            mm = (j == 0 ? (i == 0 ? 0 : -(o_del + e_del * i)) : H) + sc;   // eh[0].h of row i is the first-column value row i - 1 left there
+            tins = mm - oe_ins;
+        }
+        const int bj = in ? tins + (j + 1) * e_ins : -0x7fffffff;
+        const int incl = wave_scan_max_i32(bj, lane);
+        const int excl = wave_shr1_i32(incl, -0x7fffffff);
+        const int gc = LH_MINUS_INF + beg * e_ins;
+        const int G = gc > excl ? gc : excl;
+        const int f = G - j * e_ins;
+        int h = LH_MINUS_INF, enew = LH_MINUS_INF;
+        if (in) {
+            const int e = E;
+            dir = mm >= e ? 0 : 1;
+            h = mm >= e ? mm : e;
+            dir = h >= f ? dir : 2;
+            h = h >= f ? h : f;
+            const int t_ = mm - oe_del;
+            enew = e - e_del;
+            dir |= enew > t_ ? 1 << 2 : 0;
+            enew = enew > t_ ? enew : t_;
+            const int fd = f - e_ins;
+            dir |= fd > tins ? 2 << 4 : 0;
+            if (z) z[(size_t)i * n_col + (j - beg)] = (uint8_t)dir;
+        }
+        // the next row: H stays (column j + 1 of row i + 1 reads H(i, j)); E(i + 1, j) moves to the lane that holds column j in row i + 1: d - 1
+        H = in ? h : LH_MINUS_INF;
+        E = wave_shl1_i32(in ? enew : LH_MINUS_INF, LH_MINUS_INF);
+        if (end == qlen && end > beg) last = wave_readlane(H, qlen - 1 - i + w);   // eh[end].h = the row's last H
+        if (end > beg) ncell += (u64)(end - beg);
+    }
+    if (cells) *cells += ncell;
+    return last;
+}
+
 // bwa_gen_cigar2 without traceback: global score of query[qb_..qe_) against the fwd||rev reference interval [rb,re).
 // Returns 0 and sets *ok=0 when upstream would reject the interval.
 __device__ __forceinline__ int wave_gen_score(const DIndex& ix, const DOpts& o, const uint8_t* q, int qb_, int l_query, int w_, i64 rb, i64 re, int lane, int* ok,
