@@ -27,7 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")   # HBM-side counters of this workload (tools/pmc_summary.py), per kernel
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")   # HBM-side counters of this workload (tools/pmc_summary.py), per kernel
 HBM_PEAK_GBPS = 8000.0
 
 

@@ -14,7 +14,7 @@ cd $REPO
 DB=$(find $OUT/kt -name "*.db" | head -1)
 python3 tools/rocpd_stats.py $DB 0.05 > $OUT/kernel_stats.csv
 python3 tools/pmc_summary.py --out $OUT/pmc.json --commit $1 --command "rocprofv3 --pmc {FETCH_SIZE TCC_HIT_sum | WRITE_SIZE TCC_MISS_sum | SQ_*} --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras (one pipeline, 2 M-pair batches: 5 dispatches of each hot-path kernel = 1 warm-up + 4 steps; one pass per counter group)" --ceiling 50.5 --note "ceiling = independent random 32-B reads from a 3 GiB table (hg38 occurrence table); 36.8 G/s from a 48 GiB table (dense SA / ISA): profiles/r02_random_read_ceiling.log" $(find $OUT/p1 $OUT/p2 $OUT/p3 -name "*counter_collection.csv")
-tail -n 1 $OUT/kt.log > $OUT/kt_bench.json
+grep "^{" $OUT/kt.log | tail -n 1 > $OUT/kt_bench.json
 rm -rf $OUT/kt $OUT/p1 $OUT/p2 $OUT/p3
 ls -la $OUT
 # the configs[4] leg alone (repeat families, every read on the copies): kernel-trace statistics of `bench.py --repeats`
@@ -23,5 +23,5 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt4 -- python3 $REPO/bench.py --repeats
 cd $REPO
 DB=$(find $OUT/kt4 -name "*.db" | head -1)
 python3 tools/rocpd_stats.py $DB 0.05 > $OUT/kernel_stats_repeats.csv
-tail -n 1 $OUT/kt_repeats.log > $OUT/kt_repeats.json
+grep "^{" $OUT/kt_repeats.log | tail -n 1 > $OUT/kt_repeats.json
 rm -rf $OUT/kt4
