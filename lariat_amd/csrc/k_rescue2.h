@@ -90,10 +90,22 @@ __device__ __forceinline__ int resc_window(const DIndex& ix, const DOpts& o, con
     i64 rb = a.rb + o.pes_low - l_ms, re = a.rb + o.pes_high;
     if (rb < 0) rb = 0;
     if (re > ix.l_pac << 1) re = ix.l_pac << 1;
-    int rid = -1;
-    if (rb < re) rid = dev_fetch_clamp(ix, &rb, (rb + re) >> 1, &re);
+    int ok = 0;
+    if (rb < re) {   // bns_fetch_seq clamps the window to the contig that holds its middle: the attempt goes on only if that is the anchor's contig, so its
+        // bounds are all that is needed (no search for the contig of the middle: two dependent table reads per attempt)
+        int is_rev;
+        const i64 pm = dev_depos(ix, (rb + re) >> 1, &is_rev);
+        const i64 coff = ix.contig_off[a.rid], cend = coff + ix.contig_len[a.rid];
+        if (pm >= coff && pm < cend) {
+            i64 far_beg = coff, far_end = cend;
+            if (is_rev) { far_beg = (ix.l_pac << 1) - cend; far_end = (ix.l_pac << 1) - coff; }
+            rb = rb > far_beg ? rb : far_beg;
+            re = re < far_end ? re : far_end;
+            ok = 1;
+        }
+    }
     *rb_out = rb; *re_out = re;
-    return a.rid == rid && re - rb >= o.min_seed_len;
+    return ok && re - rb >= o.min_seed_len;
 }
 // what the packed kernel holds: 8-bit scores next to an 8-bit column key, one-hot bases with a + b <= 16, windows of LH_RJ_TMAX rows, no N in the mate
 __device__ __forceinline__ int resc_fast_ok(const DOpts& o, int l_ms, i64 tlen) {
@@ -360,7 +372,7 @@ __global__ void __launch_bounds__(64) k_resc_sw(DIndex ix, DOpts o, RJob* __rest
 // When all re are distinct and no entry has b's (score, rb, qb), the introsorts' handling of equal keys cannot matter, and the above IS the
 // call's result: a few reductions over the list, which lives in LDS.  A call after an attempt that added nothing changes nothing.  Anything
 // else — equal keys, a list that outgrows the LDS arrays — goes back to wave_sort_dedup_patch on the arrays in memory, for the rest of the pair.
-#define LH_RA_CAP 320
+#define LH_RA_CAP 256
 struct RescList {
     i64 rb[LH_RA_CAP], re[LH_RA_CAP];
     int32_t qb[LH_RA_CAP], qe[LH_RA_CAP], score[LH_RA_CAP], rid[LH_RA_CAP], src[LH_RA_CAP];   // src: the entry's place in the memory arrays when the list was loaded; -1: rescued since
@@ -545,6 +557,30 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 b.score = aln.score; b.csub = 0; b.secondary = -1;
                 b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
                 b.truesc = 0; b.sub = 0; b.w = 0; b.seedlen0 = 0; b.n_comp = 0; b.frac_rep = 0;
+            }
+            if (mode == 0 && n_ma + o.rescue_max_hits <= LH_RA_CAP) {
+                // the first attempt that gets here: the list as k_dedup left it (sorted, no identical hits).  If it also holds no redundant pair and no
+                // two equal re — one pass over its pairs — the call that follows this attempt is already a function of the added region alone
+                for (int k = lane; k < n_ma; k += 64) {
+                    const DReg& g = ma[k];
+                    W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k;
+                }
+                WAVE_SYNC();
+                int dirty = 0;
+                for (int k0 = 0; k0 < n_ma; k0 += 64) {
+                    const int k = k0 + lane;
+                    if (k < n_ma) {
+                        const i64 pre = W.re[k], prb = W.rb[k];
+                        const int pqb = W.qb[k], pqe = W.qe[k], prid = W.rid[k], psc = W.score[k];
+                        for (int u = 0; u < n_ma; ++u) {
+                            const i64 qre = W.re[u];
+                            if (u != k && qre == pre) dirty = 1;
+                            if (qre < pre && W.rid[u] == prid && prb < qre + o.max_chain_gap && resc_redundant(o, W.rb[u], qre, W.qb[u], W.qe[u], prb, pre, pqb, pqe)) dirty = 1;
+                            if (u < k && (W.score[u] < psc || (W.score[u] == psc && (W.rb[u] > prb || (W.rb[u] == prb && W.qb[u] >= pqb))))) dirty = 1;   // (not in the call's final order)
+                        }
+                    }
+                }
+                mode = __any(dirty) ? 0 : 1;
             }
             if (mode == 1) {
                 if (!hit) continue;   // a clean list and nothing new: the call changes nothing
