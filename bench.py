@@ -43,7 +43,6 @@ def parse():
                                                           "are then execution times); 2 = every batch is cut at a barcode boundary and its halves are aligned side by side "
                                                           "inside ONE lh_align_resident call (+5 %: reported under two_lanes_pairs_per_s)")
     ap.add_argument("--repeats", action="store_true", help="only the configs[4] leg (repeat families, every read on the copies: tens to hundreds of candidates per read)")
-    ap.add_argument("--k1-rounds", type=int, default=0, help="lh_context_opts.k1_lock_rounds (development: 0 = the library's default, -1 = none)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --steps batches in total, split over the ranks (default weak: --steps per rank)")
     ap.add_argument("--cpu-sample-barcodes", type=int, default=10000, help="barcodes of the first batch timed on the host cores (cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,7 +163,7 @@ def main():
     else:
         my_batches = list(range(rank * a.steps, (rank + 1) * a.steps))
     n_pairs = a.barcodes * a.pairs_per_barcode
-    ctx = idx.context(n_pairs, lanes=a.lanes, k1_lock_rounds=a.k1_rounds)
+    ctx = idx.context(n_pairs, lanes=a.lanes)
     opts = lib.opts()
     t0 = time.time()
     first = None

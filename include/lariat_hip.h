@@ -102,8 +102,7 @@ typedef struct lh_context_opts {
                            * that one part's kernels fill the idle tails of the others'; results are merged.  No stage dumps then. */
     int32_t big_slots;    /* K1: slots of the slab for reads with more than 64 SMEM intervals (max_pairs / 128, at least 64); the slab grows when a
                            * batch needs more, tests force that with a small value */
-    int32_t k1_lock_rounds; /* K1 pass 1: launches of the lockstep kernel that makes ONE bwt_smem1a call per read (k_smem_rest) between the first calls and the
-                           * state machine; 0 = default (1), -1 = none */
+    int32_t reserved;
 } lh_context_opts;
 void lh_context_opts_init(lh_context_opts* co);
 

@@ -54,7 +54,7 @@ class LhIndexOpts(C.Structure):
 
 class LhContextOpts(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("smem_grid", C.c_int32), ("aln_grid", C.c_int32), ("rfa_grid", C.c_int32), ("rfa_slab_kb", C.c_int32),
-                ("lanes", C.c_int32), ("big_slots", C.c_int32), ("k1_lock_rounds", C.c_int32)]
+                ("lanes", C.c_int32), ("big_slots", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LhBatch(C.Structure):

@@ -189,278 +189,12 @@ __global__ void __launch_bounds__(256) k_smem_first(DIndex ix, DOpts o, int n_re
     }
 }
 
-// ONE MORE CALL PER READ IN LOCKSTEP (written in r03, measured with four rounds and dropped; back in r04 with ONE round, see run_front):
-// bwt_smem1a as a plain per-thread program, one thread per read k_smem_first listed.
-// Measured (profiles/r03_pmc_bench.json, set a): the two lockstep kernels run at the memory system's request ceiling with a tenth of the
-// state machine's instructions, while the state machine's pass 1 (17 of 64 lanes active) reaches 0.6 of it.  The calls after the first
-// are short programs too: a call by text (two comparisons with the text, two PLCP bytes — START_SMEM1), or a walk from a base that
-// differs from the read's locus (tree levels and filter words, a few occurrence steps, a list of one to three intervals, a sweep of a few
-// rows).  Same arithmetic, same filters and shortcuts as the state machine (whose comments carry the arguments); the forward list lives in
-// LDS (LH_K1B_CAP entries per thread).  A call whose list outgrows that is handed to the state machine BEFORE it has any effect
-// (K1Resume: position, locus, previous call), like a read this kernel cannot take (too long, too short).
-#define LH_K1B_CAP 8
-#ifndef LH_K1B_ROUNDS
-#define LH_K1B_ROUNDS 1     // launches of k_smem_rest (each: one call as written per listed read); what is left after them is the state machine's
-#endif
-#define LH_K1B_BLOCK 128
-__device__ __forceinline__ uint32_t k1b_q8(const uint32_t* __restrict__ q4, i64 off, int len, int p) {   // eight read bases from position p on; outside the read: 4
-    if (p >= len || p <= -8) return 0x44444444u;
-    uint32_t w;
-    if (p >= 0) w = dev_nib8(q4, off + p);
-    else { const int s = -p * 4; w = dev_nib8(q4, off) << s | (0x44444444u & ((1u << s) - 1u)); }
-    const int keep = len - p;
-    if (keep < 8) w = (w & ((1u << (4 * keep)) - 1u)) | (0x44444444u << (4 * keep));
-    return w;
-}
-__device__ __forceinline__ uint32_t k1b_sq8(uint32_t a) {   // eight 4-bit bases -> 2 bits each
-    a &= 0x33333333u;
-    a = (a | a >> 2) & 0x0f0f0f0fu; a = (a | a >> 4) & 0x00ff00ffu; a = (a | a >> 8) & 0xffffu;
-    return a;
-}
-// first k >= from with read[k] != text[P0 + k] (the read's end at the latest: bases outside the read never match)
-__device__ __forceinline__ int k1b_fwd_cmp(const DIndex& ix, const uint32_t* __restrict__ q4, i64 off, int len, int from, i64 P0) {
-    for (int k = from;; k += 8) {
-        const uint32_t xr = k1b_q8(q4, off, len, k) ^ dev_nib8(ix.tn, P0 + k);
-        if (xr) return k + ((__ffs((int)xr) - 1) >> 2);
-    }
-}
-// smallest u <= from + 1 with read[u .. from] == text[P0 + u ..] (from + 1: read[from] already differs)
-__device__ __forceinline__ int k1b_bwd_cmp(const DIndex& ix, const uint32_t* __restrict__ q4, i64 off, int len, int from, i64 P0) {
-    for (int k = from;; k -= 8) {
-        const uint32_t xr = k1b_q8(q4, off, len, k - 7) ^ dev_nib8(ix.tn, P0 + k - 7);
-        if (xr) return k - 7 + ((31 - __clz((int)xr)) >> 2) + 1;
-    }
-}
-__global__ void __launch_bounds__(LH_K1B_BLOCK) k_smem_rest(DIndex ix, DOpts o, const uint32_t* __restrict__ q4, const i64* __restrict__ seq_off, DIntv* __restrict__ intv_out,
-                                                             int32_t* __restrict__ n_intv, int32_t* __restrict__ status, K1Resume* __restrict__ resume, const int32_t* __restrict__ todo,
-                                                             const int32_t* __restrict__ todo_count, int32_t* __restrict__ todo2, int32_t* __restrict__ todo2_count,
-                                                             DCounters* __restrict__ ctr) {
-    __shared__ PEnt lst[(LH_K1B_CAP + 1) * LH_K1B_BLOCK];
-    const int t = threadIdx.x, lane = LANE();
-    const int idx = blockIdx.x * LH_K1B_BLOCK + t;
-    const PEnt* const kt = (const PEnt*)ix.ktree;
-    const int ktl = ix.ktree_levels;
-    unsigned n_ext = 0, n_exec = 0, n_kt = 0, n_bt = 0;
-    int listed = 0, r = -1;
-#define LST(e_) lst[(e_) * LH_K1B_BLOCK + t]
-    if (idx < *todo_count) {
-        r = todo[idx];
-        const i64 off = seq_off[r];
-        const int len = (int)(seq_off[r + 1] - off);
-        K1Resume rs = resume[r];
-        DIntv* const out = intv_out + (size_t)r * LH_MAX_INTV;
-        int x = rs.x, on = x > 0 ? n_intv[r] : 0, ovf = 0;
-        i64 Pk = rs.Pk;
-        int pk_len = rs.pk & 0xff, x_prev = ((rs.pk >> 8) & 0xff) - 2, bt_skip = ((rs.pk >> 16) & 0xff) - 1;
-        bool bail = len > LH_MAXLEN || len < o.min_seed_len, fm_done = false;
-#define QN(i_) ((int)(dev_nib8(q4, off + (i_)) & 0xf))
-#define K1B_EMIT(x0_, x1_, x2_, s_, e_)                                                                      \
-    {                                                                                                        \
-        if ((e_) - (s_) >= o.min_seed_len) {                                                                 \
-            if (on >= LH_MAX_INTV) ovf = 1;                                                                  \
-            else { DIntv m_; m_.x0 = (x0_); m_.x1 = (x1_); m_.x2 = (x2_); m_.info = (u64)(uint32_t)(e_) | (u64)(s_) << 32; out[on++] = m_; } \
-        }                                                                                                    \
-        last_mem_start = (s_);                                                                               \
-    }
-        // one bwt_extend (tree entry for a match of at most ktl bases, occurrence table otherwise); code_ = the matched string, base k at bits 2k
-#define K1B_EXT(ok_, c_, base_, back_, lnew_, code_)                                                         \
-    {                                                                                                        \
-        if ((lnew_) <= ktl) {                                                                                \
-            const PEnt te_ = kt[(((1ull << (2 * (lnew_))) - 4) / 3) + ((code_) & ((lnew_) >= 16 ? 0xffffffffu : (1u << (2 * (lnew_))) - 1u))]; \
-            ok_.x0 = PE_X0(te_); ok_.x1 = PE_X1(te_); ok_.x2 = PE_X2(te_); ok_.info = 0;                     \
-            ++n_kt;                                                                                          \
-        } else { ok_ = dev_extend_c(ix, c_, (back_) ? (base_) : 3 - (base_), (back_)); ++n_exec; }          \
-        ++n_ext;                                                                                             \
-    }
-        while (!bail && !ovf) {
-            while (x < len && QN(x) > 3) ++x;
-            if (x >= len) break;
-            int ret = -1, last_mem_start = -1;
-            // ---- the call by text (START_SMEM1: (A), (B), (B')) ----
-            if (pk_len > 0 && x != bt_skip && Pk + x >= 0 && (u64)(Pk + x) < ix.seq_len) {
-                const int bb = k1b_fwd_cmp(ix, q4, off, len, x, Pk);
-                const int ec = ix.plcp[Pk + x];
-                bt_skip = x;
-                if (ec < bb - x) {   // (A)
-                    int u = x;
-                    bool ok_b = true;
-                    if (x > 0 && QN(x - 1) <= 3) {
-                        u = k1b_bwd_cmp(ix, q4, off, len, x - 1, Pk);
-                        const bool edge = u - 1 < 0 || QN(u - 1) > 3;
-                        if (!edge && u - 1 != x_prev) ok_b = (int)ix.plcp[Pk + u] <= x - u;   // (B)
-                    }
-                    if (ok_b) {
-                        K1B_EMIT(LH_POSF | (u64)(Pk + u), 0, 1, u, bb)
-                        ++n_bt;
-                        ret = bb; bt_skip = bb;
-                    }
-                }
-            }
-            // ---- the call as written: ONE per read and launch (the threads of a wave stay in step; the read goes on in the next round) ----
-            if (ret < 0 && fm_done) { bail = true; break; }
-            if (ret < 0) {
-                fm_done = true;
-                u64 wkey;
-                int filt_from;
-                {   // the filter key of the LH_BLOOM_K bases that end at x, and the first interval end whose window is all bases (WKEY_AT)
-                    const uint32_t w0 = k1b_q8(q4, off, len, x - 18), w1 = k1b_q8(q4, off, len, x - 10), w2 = k1b_q8(q4, off, len, x - 2) & 0xfffu;
-                    const uint32_t n0 = w0 & 0x44444444u, n1 = w1 & 0x44444444u, n2 = w2 & 0x444u;
-                    const int last = n2 ? x - 2 + ((31 - __clz((int)n2)) >> 2) : n1 ? x - 10 + ((31 - __clz((int)n1)) >> 2) : n0 ? x - 18 + ((31 - __clz((int)n0)) >> 2) : x - 19;
-                    uint32_t t2 = w2 & 0x333u;
-                    t2 = (t2 | t2 >> 2) & 0x0f0fu; t2 = (t2 | t2 >> 4) & 0x3fu;
-                    wkey = (u64)k1b_sq8(w0) | (u64)k1b_sq8(w1) << 16 | (u64)t2 << 32;
-                    filt_from = last + 1 + LH_BLOOM_K;
-                }
-                DIntv c = dev_set_intv(ix, QN(x));
-                int cinfo = x + 1, i = x + 1, nl = 0, emin = 0;
-                uint32_t fcode = (uint32_t)QN(x);
-                bool run = false;
-                i64 P0 = 0;   // a run's locus: text position of read base 0
-                {   // FORWARD JUMP
-                    const uint32_t qa = k1b_q8(q4, off, len, x), qb = k1b_q8(q4, off, len, x + 8);
-                    const uint32_t a = qa & 0x44444444u, b = qb & 0x44444444u;
-                    const int v = a ? (__ffs((int)a) - 1) >> 2 : 8 + (b ? (__ffs((int)b) - 1) >> 2 : 8);
-                    int J = ktl < v ? ktl : v;
-                    if (filt_from - x < J) J = filt_from - x;
-                    if (J >= 2) {
-                        const uint32_t cd = (k1b_sq8(qa) | k1b_sq8(qb) << 16) & (J >= 16 ? 0xffffffffu : (1u << (2 * J)) - 1u);
-                        const PEnt te = kt[(((1ull << (2 * J)) - 4) / 3) + cd];
-                        ++n_kt;
-                        if (PE_X2(te) >= 1) {
-                            c.x0 = PE_X0(te); c.x1 = PE_X1(te); c.x2 = PE_X2(te);
-                            n_ext += (unsigned)(J - 1);
-                            i = x + J; cinfo = i; fcode = cd;
-                            const int p = i - 1;   // the key again: the interval's end moved
-                            const uint32_t w0 = k1b_q8(q4, off, len, p - 18), w1 = k1b_q8(q4, off, len, p - 10), w2 = k1b_q8(q4, off, len, p - 2) & 0xfffu;
-                            uint32_t t2 = w2 & 0x333u;
-                            t2 = (t2 | t2 >> 2) & 0x0f0fu; t2 = (t2 | t2 >> 4) & 0x3fu;
-                            wkey = (u64)k1b_sq8(w0) | (u64)k1b_sq8(w1) << 16 | (u64)t2 << 32;
-                        }
-                    }
-                }
-                for (;;) {   // the forward walk
-                    if (c.x2 == 1) {   // UNIQUE RUN: one occurrence left, followed through the text; it ends the list
-                        P0 = (i64)ix.sa[c.x0] - x;
-                        const int bnd = k1b_fwd_cmp(ix, q4, off, len, i, P0);
-                        n_ext += (unsigned)(bnd - i) + ((bnd < len && QN(bnd) <= 3) ? 1u : 0u);
-                        cinfo = bnd; i = bnd; run = true;
-                        if (bnd - x > pk_len) { Pk = P0; pk_len = bnd - x; bt_skip = bnd; }   // the longest unique match so far names the read's locus
-                        else if (pk_len > 0 && P0 == Pk) bt_skip = bnd;
-                        break;
-                    }
-                    bool pass = false;   // sweep filter: may the current interval yield a seed at all?
-                    if (cinfo >= filt_from) {
-                        uint32_t w_; u64 bm_;
-                        dev_bloom_slot(wkey, ix.bloom1_words, &w_, &bm_);
-                        pass = (ix.bloom1[w_] & bm_) == bm_;
-                    }
-                    const int b = i < len ? QN(i) : 4;
-                    if (b > 3) break;   // the current interval closes the list
-                    const int lnew = i + 1 - x;
-                    if (lnew <= 16) fcode |= (uint32_t)b << (2 * (lnew - 1));
-                    DIntv ok;
-                    K1B_EXT(ok, c, b, 0, lnew, fcode)
-                    if (ok.x2 != c.x2) {
-                        if (ok.x2 < 1) break;
-                        if (pass) {
-                            if (nl == LH_K1B_CAP) { bail = true; break; }
-                            if (!nl) emin = cinfo;
-                            LST(nl) = pe_pack(c.x0, c.x1, c.x2, cinfo);
-                            ++nl;
-                        }
-                    }
-                    c = ok; cinfo = i + 1; ++i;
-                    wkey = wkey >> 2 | (u64)b << (2 * LH_BLOOM_K - 2);
-                }
-                if (bail) break;
-                ret = cinfo;
-                // ---- the backward sweep ----
-                int i2 = x - 1;
-                bool swept = false;
-                if (nl > 0 && run) {   // several entries, the longest unique: the collapsed sweep (BWD_ROW_BODY), or the sweep as written over all of them
-                    const int cb = i2 < 0 ? 4 : QN(i2);
-                    if (cb > 3) { K1B_EMIT(LH_POSF | (u64)(P0 + x), 0, 1, x, cinfo) swept = true; }
-                    else {
-                        const int u = k1b_bwd_cmp(ix, q4, off, len, i2, P0);
-                        n_ext += (unsigned)(x - u);
-                        const bool edge = u - 1 < 0 || QN(u - 1) > 3;
-                        if (edge || (int)ix.plcp[P0 + u] < emin - u) { K1B_EMIT(LH_POSF | (u64)(P0 + u), 0, 1, u, cinfo) swept = true; }
-                        else c.x1 = ix.isa[(i64)ix.seq_len - (P0 + cinfo)];   // the row of the reverse strand's copy, which the run did not keep
-                    }
-                }
-                if (!swept) {
-                    // prev = the list from its end (longest match first), in place in LDS
-                    LST(nl) = pe_pack(c.x0, c.x1, c.x2, cinfo);
-                    int n = nl + 1;
-                    for (int a = 0, b = n - 1; a < b; ++a, --b) { const PEnt ta = LST(a); LST(a) = LST(b); LST(b) = ta; }
-                    bool first_row = true;
-                    for (;;) {
-                        const int cb = i2 < 0 ? 4 : QN(i2);
-                        const PEnt p0 = LST(0);
-                        if (cb > 3) {   // nothing extends: only the longest entry can be a new MEM
-                            if (last_mem_start < 0 || i2 + 1 < last_mem_start) {
-                                if (first_row && run) { K1B_EMIT(LH_POSF | (u64)(P0 + x), 0, 1, x, PE_INFO(p0)) }
-                                else { K1B_EMIT(PE_X0(p0), PE_X1(p0), PE_X2(p0), i2 + 1, PE_INFO(p0)) }
-                            }
-                            break;
-                        }
-                        if (n == 1 && PE_X2(p0) == 1) {   // one unique match left: backward through the text
-                            const i64 Pb = (first_row && run) ? P0 : (i64)ix.sa[PE_X0(p0)] - (i2 + 1);
-                            const int u = k1b_bwd_cmp(ix, q4, off, len, i2, Pb);
-                            n_ext += (unsigned)(i2 + 1 - u) + ((u - 1 >= 0 && QN(u - 1) <= 3) ? 1u : 0u);
-                            if (last_mem_start < 0 || u < last_mem_start) { K1B_EMIT(LH_POSF | (u64)(Pb + u), 0, 1, u, PE_INFO(p0)) }
-                            break;
-                        }
-                        const uint32_t rcode = k1b_sq8(k1b_q8(q4, off, len, i2)) | k1b_sq8(k1b_q8(q4, off, len, i2 + 8)) << 16;
-                        int ncurr = 0;
-                        u64 last_size = 0;
-                        for (int j = 0; j < n; ++j) {
-                            const PEnt pj = LST(j);
-                            DIntv pc; pc.x0 = PE_X0(pj); pc.x1 = PE_X1(pj); pc.x2 = PE_X2(pj); pc.info = 0;
-                            const int pe = PE_INFO(pj);
-                            DIntv ok;
-                            K1B_EXT(ok, pc, cb, 1, pe - i2, rcode)
-                            if (ok.x2 < 1) {
-                                if (ncurr == 0 && (last_mem_start < 0 || i2 + 1 < last_mem_start)) { K1B_EMIT(pc.x0, pc.x1, pc.x2, i2 + 1, pe) }
-                            } else if (ncurr == 0 || ok.x2 != last_size) {
-                                LST(ncurr) = pe_pack(ok.x0, ok.x1, ok.x2, pe);
-                                ++ncurr;
-                                last_size = ok.x2;
-                            }
-                        }
-                        if (ncurr == 0) break;
-                        n = ncurr; --i2; first_row = false;
-                    }
-                }
-            }
-            x_prev = x; x = ret;
-        }
-#undef QN
-#undef K1B_EMIT
-#undef K1B_EXT
-        n_intv[r] = on;
-        if (bail && !ovf) {
-            rs.Pk = Pk; rs.x = x; rs.pk = (pk_len & 0xff) | ((x_prev + 2) & 0xff) << 8 | ((bt_skip + 1) & 0xff) << 16;
-            resume[r] = rs;
-            listed = 1;
-        } else status[r] = ovf ? LH_ST_INTV_OVERFLOW : 0;
-    }
-#undef LST
-    const u64 lm = __ballot(listed);
-    if (lm) {
-        int basep = 0;
-        if (lane == 0) basep = atomicAdd(todo2_count, (int32_t)__popcll(lm));
-        basep = wave_readlane(basep, 0);
-        if (listed) todo2[basep + lanes_below(lm, lane)] = r;
-    }
-    if (ctr) {
-        unsigned t1 = (unsigned)wave_sum_i32((int)n_ext), t2 = (unsigned)wave_sum_i32((int)n_exec), t3 = (unsigned)wave_sum_i32((int)n_kt), t4 = (unsigned)wave_sum_i32((int)n_bt);
-        if (lane == 0 && (t1 | t4)) {
-            atomicAdd(&LH_CTR(ctr)->n_ext, (u64)t1); atomicAdd(&LH_CTR(ctr)->n_ext_exec[0], (u64)t2); atomicAdd(&LH_CTR(ctr)->n_ktree[0], (u64)t3); atomicAdd(&LH_CTR(ctr)->n_bt, (u64)t4);
-        }
-    }
-}
-
+// (Measured and dropped in r03: the REST of pass 1 as a plain per-thread program as well — bwt_smem1a with the same filters and shortcuts,
+// forward list in LDS, one call per read and launch, four launches before the state machine took the remainder.  Bit-exact, but 13 of 64
+// lanes active (the calls after the first are not one program: calls by text, walks with and without pushes, three kinds of sweep) and
+// latency-bound at 4 waves per SIMD: 13.0 ms against the 10.5 ms of k_smem_first + the state machine.  Measured again in r04 with ONE, two and three
+// such launches before the state machine (a read with a single difference from its locus is finished by one): 10.83 / 11.27 / 12.40 ms against
+// 10.63 without: the state machine's share does not shrink by what the launch costs.  See the git history (4478681 of r03, bbe4586 of r04).)
 // (Also measured and dropped: the sweep filter's answers for a walk's first 16 levels read ahead, four per turn, so that a walk from
 // beyond position LH_BLOOM_K can jump to the tree's depth — 28 M fewer tree reads per launch, but the extra state costs every turn: 9.5 ms
 // against 8.8; and the reads with work in pass 2 listed by a thread-per-read kernel first: the state machine saves 0.5 ms, the list costs 0.8.)
