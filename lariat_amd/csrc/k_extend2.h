@@ -19,13 +19,6 @@
 #define EH_PACK(q, e, h) ((uint32_t)(q) << 29 | (uint32_t)(e) << 16 | (uint32_t)(h))
 
 // ksw_extend2 for one lane.  Column j's query base is q[qoff + qstep*j]; row i's target base is tg.base(i).
-#ifdef LH_K4_PROF   // development aid: wave-clock ticks per part of k_extend_lane, summed over lanes (lh_dbg[24 + part], in units of 2^16)
-#define K4_T0() long long k4t_ = wall_clock64();
-#define K4_T(s_) { long long n_ = wall_clock64(); atomicAdd(&lh_dbg[24 + (s_)], (int)((n_ - k4t_) >> 6)); k4t_ = n_; }
-#else
-#define K4_T0()
-#define K4_T(s_)
-#endif
 // circ_mask = 63: the band is narrow (w <= LH_EXT_CIRC_MAX_W), row i only touches columns i-w .. i+w+2, so eh[] lives in a
 // circular window of 64 words per lane whatever the query length; a column's first-row value (a closed form) and its query base
 // are written when the window reaches it — exactly the value the full array would still hold there.  circ_mask = -1: eh[] as is.
@@ -35,7 +28,6 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
     const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
 #define EHW(j_) ehl[((j_) & circ_mask) * 64 + lane]
-    K4_T0()
     int maxsc = a_ > 0 ? a_ : 0;   // max entry of mat (a, -b, -1)
     int max_ins = (int)((double)(qlen * maxsc + end_bonus - o_ins) / e_ins + 1.);
     max_ins = max_ins > 1 ? max_ins : 1;
@@ -53,7 +45,6 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
         EHW(n_mat) = EH_PACK(qv_ > 4 ? 4 : qv_, 0, v_);                                                      \
     }
     EH_MATERIALIZE(circ_mask >= 0 ? w + 2 : qlen)
-    K4_T(1)
     int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     int beg = 0, end = qlen;
     u64 ncell = 0;
@@ -112,7 +103,6 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2(const DOpts& o, const uint8_t
     }
 #undef EHW
 #undef EH_MATERIALIZE
-    K4_T(2)
     if (cells) *cells += ncell;
     ExtRes r;
     r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;

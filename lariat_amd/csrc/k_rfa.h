@@ -272,11 +272,6 @@ __device__ __forceinline__ void dev_tag_pair_serial(const DCand& R, const DInf& 
 #define LH_RFA_MQ_CHUNK 384   // mate alignments staged per turn (24 B each in lds_raw)
 #endif
 static_assert(24 * LH_RFA_MQ_CHUNK <= LH_RFA_LDS_BYTES, "mate staging of estimateMapQualities");
-#ifdef LH_RFA_PROF   // development aid: per-phase wall-clock (100 MHz ticks -> us) summed over waves into lh_dbg[16..]
-#define RFA_T(k) { if (lane == 0) { u64 now_ = wall_clock64(); atomicAdd(&o.wd[16 + (k)], (int)((now_ - t_prof) / 100)); t_prof = now_; } }
-#else
-#define RFA_T(k)
-#endif
 
 // One wavefront per barcode; barcodes are handed out through the device counter *bc_next (their costs differ widely).
 // A barcode whose tables do not fit the wave's slab (the reader caps a work unit at 30,000 pairs, fastqreader/reader.go:205,
@@ -323,9 +318,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         int nR = 2 * (p1 - p0), r0 = 2 * p0;
         i64 c_lo = R.cand_off[r0], c_hi = R.cand_off[r0 + nR];
         int NC = (int)(c_hi - c_lo);
-#ifdef LH_RFA_PROF
-        u64 t_prof = wall_clock64();
-#endif
         if (c_hi > cand_cap) continue;   // flagged by k_aln
         // ---- init per-candidate and per-read state (Alignment defaults, lariat.go:1655-1689) ----
         for (int r = lane; r < nR; r += 64) {
@@ -337,7 +329,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             S.split_second_best[r0 + r] = 0; S.split_score[r0 + r] = 0; S.split_mapq[r0 + r] = 0;
         }
         WAVE_SYNC();
-        RFA_T(0)
         // ---- tagBestAlignments: one lane per pair.  Read 2 of a pair is always "touched" by read 1 (every read has >= 1
         // filtered candidate), so only read 1's scan decides; its jitter stream is Go's, seeded from the read name. ----
         {   // a read that draws more often than the state-free path allows keeps its generator state in the (still unused) slab
@@ -443,7 +434,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             WAVE_SYNC();
         }
         WAVE_SYNC();
-        RFA_T(1)
         // ---- slab carve (sizes depend on NC, nR) ----
         size_t so = 0;
         RfaTab T;
@@ -525,7 +515,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
         }
         WAVE_SYNC();
-        RFA_T(2)
         // sort.Sort(ByPosition) per contig (lariat.go:1545-1547), one lane per contig; keys staged in LDS when they fit
         if (NCf <= LH_RFA_SORT_LDS && ncont <= 8) {
             // Few contigs: the wave sorts one contig at a time by ranking (every lane counts the smaller keys of its elements).
@@ -577,7 +566,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                         [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = pl[i]; pl[i] = pl[j]; pl[j] = u; }, T.molraw, T.rdl, T.firstf);
         }
         WAVE_SYNC();
-        RFA_T(3)
         int do_rfa = bc_do_rfa[bc] != 0;
         int M = 0;
         if (do_rfa) {
@@ -602,7 +590,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             if (lane == 0) T.mstart[Mraw] = NCf;
             WAVE_SYNC();
-            RFA_T(4)
             // ---- markBestAlignmentForReadInMolecule, step 1: best pair score of every entry inside its molecule; the
             // entry's read is counted once per molecule (its first occurrence); molecules with an active alignment ----
             int nfirst = 0, nactive = 0;
@@ -632,7 +619,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             if (lane == 0) { T.psum[NCf] = nfirst; T.actc[NCf] = nactive; }
             WAVE_SYNC();
-            RFA_T(5)
             // ---- scrapMolecules: keep molecules with an active alignment, renumber ----
             int ao = 0;
             for (int base = 0; base < Mraw; base += 64) {
@@ -694,7 +680,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             for (int m = lane; m < M; m += 64) T.alen[m] = T.psum[T.seg1[m]] - T.psum[T.seg0[m]];
             WAVE_SYNC();
-            RFA_T(6)
             // setMoleculeDifferences(candidate_molecules, false) before the optimizer (lariat.go:503): alignments that are
             // active NOW keep this value even if a later move deactivates them
             for (int m = lane; m < M; m += 64) {
@@ -704,7 +689,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 for (int k = 0; k < T.alen[m]; ++k) S.mol_diff[c_lo + T.act_store[T.aoff[m] + k]] = diff;
             }
             WAVE_SYNC();
-            RFA_T(7)
             // ---- optimizer.Optimize(opt, 1, 2, 4*M): 8*M greedy molecule moves ----
             // The optimizer is deterministic: once M consecutive turns (every molecule tried once as the source) accept no
             // move, the state can no longer change and the remaining turns are no-ops, so they are not executed.
@@ -752,7 +736,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 WAVE_SYNC();
                 source = (source + 1) % M;
             }
-            RFA_T(8)
             // ---- moleculeMapqProbabilitySums ----
             for (int s = 0; s < M; ++s) {
                 for (int sb = 0; sb < M; sb += 64) {
@@ -770,7 +753,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 }
                 WAVE_SYNC();
             }
-            RFA_T(9)
             // ---- updateAlignmentsMoleculeStatus: confidences, differences, active molecules ----
             for (int m = lane; m < M; m += 64) {
                 double conf = (double)T.alen[m] / (double)T.nbest[m];
@@ -794,7 +776,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             WAVE_SYNC();
         }
-        RFA_T(10)
         // ---- calculateLogMoleculePenalty (lariat.go:1061-1086) ----
         // Every term of dnaLength is an integer-valued double far below 2^53, so the sum is exact in any order: the lanes share a
         // molecule's alignments (it was one lane walking all of them, 16 % of the kernel's time), the wave adds up.
@@ -841,7 +822,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             S.mate[a] = m;
         }
         WAVE_SYNC();
-        RFA_T(11)
         // ---- estimateMapQualities per read (lariat.go:887-990).  A read with few (alignment, mate alignment) combinations: one lane; the others
         // (a read on a repeat family and its mate: thousands) are listed and done by the whole wave below, a lane per alignment ----
         int n_heavy_r = 0;
@@ -1052,7 +1032,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             WAVE_SYNC();
         }
-        RFA_T(12)
         // ---- markDuplicates: first-seen wins on (read1?, reversed, contig, pos, mate contig, mate pos) in read order ----
         {   // open-addressing table over the keys; a slot ends up holding the smallest read index of its key
             const int hmask = (1 << hbits) - 1;
@@ -1092,7 +1071,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
         }
         WAVE_SYNC();
-        RFA_T(13)
         // ---- CheckSplitReads / GetSplitAlignment over the unfiltered candidates (split.go) ----
         for (int r = lane; r < nR; r += 64) {
             int gr = r0 + r;
@@ -1132,7 +1110,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             S.split_idx[gr] = c; S.split_mapq[gr] = (int)mapq; S.split_second_best[gr] = second_best;
             S.split_score[gr] = dev_score_aln(R, S, improper, c, S.mate[P], 0.0);
         }
-        RFA_T(14)
         WAVE_SYNC();
     }
 }
