@@ -258,7 +258,11 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, idx, pac, first[0])
         if not a.no_extras and world == 1:
-            idx.close()   # the repeat-rich leg builds its own index: the two do not fit HBM side by side
+            try:   # the reference's own way to an index: bwa_idx_load from `bwa index`'s files (gobwa.go:128-147) — this index saved in that layout, loaded again
+                out["setup_s"].update(index_from_files(lib, idx, local_rank))
+            except Exception as e:
+                out["setup_s"]["index_from_files"] = "failed: %s: %s" % (type(e).__name__, e)
+            idx.close()   # (index_from_files has closed it already; the repeat-rich leg builds its own: two do not fit HBM side by side)
             del pac
             out["repeats"] = repeats_leg(lib, a, local_rank, opts)
         print(json.dumps(out), flush=True)
@@ -427,6 +431,31 @@ def host_to_host(lib, idx, reads_list, n_pairs, opts):
             "kernel_ms_under_transfers": {k: round(sum(v) / len(v), 2) for k, v in kern.items()},
             "per_round_ms": {k: [round(x, 1) for x in v] for k, v in kern.items() if max(v) > 2 * min(v) + 0.5},
             "how": "one context; a second host thread stages batch k+1 (lh_batch_stage_slot) under batch k's kernels; batch k's result is copied out under batch k+1's (lh_result_download_begin/_end)"}
+
+
+def index_from_files(lib, idx, local_rank):
+    """lh_index_save (the five files of `bwa index`, suffix array at interval 32) to a tmpfs directory, the resident index freed, lh_index_load from the
+    files: the dense suffix array, inverse suffix array, LCP / PLCP, Bloom filters and k-mer tree are derived on the device from the loaded BWT and text"""
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (24 << 30) else None
+    d = tempfile.mkdtemp(prefix="lh_idx_", dir=base)
+    try:
+        prefix = os.path.join(d, "ref.fa")
+        t0 = time.time()
+        idx.save(prefix)
+        t_save = time.time() - t0
+        nbytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+        digest = idx.digest()
+        idx.close()
+        t0 = time.time()
+        loaded = lib.index_load(prefix, device=local_rank)
+        t_load = time.time() - t0
+        same = loaded.digest() == digest
+        loaded.close()
+        return {"index_save_files": round(t_save, 2), "index_load_from_files": round(t_load, 2), "index_files_GB": round(nbytes / 1e9, 2), "loaded_index_equals_built": bool(same)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def end_to_end(lib, idx, a, pac, l_pac, ctg, opts, local_rank):
@@ -609,6 +638,9 @@ def repeats_leg(lib, a, local_rank, opts, steps=3):
            "molecules_per_barcode": {"mean": round(float(mol.mean()), 1), "max": int(mol.max())},
            "n_rescue": cnt["n_rescue"], "rescue_cells": cnt["rescue_cells"],
            "rescue_GCUPS": round(cnt["rescue_cells"] / (sum(kern["k_rescue"]) / len(kern["k_rescue"]) * 1e-3) / 1e9, 1),
+           # the stage against the VALU issue rate its recurrence allows: 9.25 packed-16 lane-instructions per ksw_u8 cell (k_rescue2.h), 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz;
+           # the whole K6 bracket (enumeration, both Smith-Waterman launches per direction, the replay); the Smith-Waterman launches alone: profiles/r04_*_repeats_*.csv
+           "rescue_stage_valu_frac": round(cnt["rescue_cells"] * 9.25 / (sum(kern["k_rescue"]) / len(kern["k_rescue"]) * 1e-3) / (256 * 4 * 16 * 2.4e9), 3),
            "setup_s": round(t_setup, 1),
            "workload": "BASELINE.json configs[4] on one GPU: %d Mb genome with 120 segmental-duplication families (50-200 copies x 20 kb, 98-99.5 %%), 40 x 6-kb and 80 x 300-bp "
                        "repeat families, 40 ALT contigs (is_alt); every read drawn on the copies (+- 2 kb); %d steps x %d pairs" % (g["l_pac"] // 1000000, steps, n_pairs)}

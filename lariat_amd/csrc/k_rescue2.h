@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pai
                                                     const i64* __restrict__ job_off, RJob* __restrict__ jobs, int32_t* __restrict__ order, RMeta* __restrict__ meta,
                                                     int32_t* __restrict__ list) {
     __shared__ int32_t sh_hist[LH_RJ_NB];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    // the counting pass looks at every pair; the emitting pass only at the pairs it listed (a few thousand of two million on unique sequence)
+    const int p = EMIT ? (slot < meta->list_count ? list[slot] : n_pairs) : slot;
     if (!EMIT) { if (threadIdx.x < LH_RJ_NB) sh_hist[threadIdx.x] = 0; __syncthreads(); }
     int nj = 0, need = 0, slen = 0, obase = 0;
     if (EMIT) {   // the pair's places in the order array: one reservation per wave and bucket
