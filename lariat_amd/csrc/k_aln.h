@@ -266,16 +266,203 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
     if (lane == 0 && ctr && cells) atomicAdd(&LH_CTR(ctr)->glob_cells, cells);
 }
 
-// ---- one lane per read: candidates without DP are finished here, the others are listed for k_aln ----
+// one candidate of a read without DP, by ONE lane: everything k_aln would write for it, or 1 = it needs the DP (nothing final written).
+// q = the read's bytes, off = its offset in the batch's 4-bit stream q4, best = the read's best region score
+__device__ __forceinline__ int aln_fast_cand(const DIndex& ix, const DOpts& o, const DCand& R, const uint8_t* q, const uint32_t* q4, i64 off, int l_query, const DReg& ar, i64 c,
+                                             int best, int32_t* status_r, unsigned* proven_cells) {
+        const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
+        const i64 rb = ar.rb, re = ar.re;
+        const int rlen = (int)(re - rb);
+        const int valid = lq > 0 && rb < re && !(rb < ix.l_pac && re > ix.l_pac) && rlen <= LH_MAXT;
+        int tmp = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_del, o.e_del);
+        int w2 = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_ins, o.e_ins);
+        w2 = w2 > tmp ? w2 : tmp;
+        if (w2 > o.w) w2 = w2 < ar.w ? w2 : ar.w;
+        w2 = w2 < o.w << 2 ? w2 : o.w << 2;
+        if (!(valid && lq == rlen)) return 1;
+        if (w2 != 0) {
+            // Equal spans but an inferred band > 0 (BWA's test is only "fewer than two gaps' worth of penalty lost").  The
+            // banded global alignment is still the plain diagonal whenever no path with gaps can beat it: such a path has
+            // g >= 1 inserted and g deleted bases, so it scores at most (L-g)*a - (o_ins + g*e_ins) - (o_del + g*e_del),
+            // largest at g = 1.  If the diagonal's own score S0 reaches that bound the DP ends on the diagonal (ties are
+            // resolved towards the diagonal in ksw_global2: d = M >= E ? 0 : 1, then h >= F), every retry of mem_reg2aln
+            // returns the same score, and the CIGAR is lq M.  With the default scoring this settles 3 mismatches
+            // (bound: mm*(a+b) <= a + oe_ins + oe_del).  S0 needs the bases, so it is checked after the compare loop.
+        }
+        // no gap: CIGAR = [clip] lq M [clip]; one pass over the bases gives NM and lariat's mismatch loci.
+        // The aligned pairs are q[qb + t] vs the base at fwd||rev coordinate rb + t (the wave kernel's oriented views
+        // pair the same bases in the opposite order on the reverse strand).
+        int is_rev;
+        const i64 posf = dev_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+        const i64 coff = ix.contig_off[ar.rid];
+        const i64 Offset = rb < ix.l_pac ? rb - coff : ix.l_pac * 2 - 1 - rb - coff;   // InterpretAlign (gobwa.go:339-371)
+        const i64 End = re < ix.l_pac ? re - coff : ix.l_pac * 2 - 1 - re - coff;
+        i64 refStart = Offset, refEnd = End;
+        if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
+        int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
+        int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
+        int nmm = 0, n_amb = 0, xo = -2;   // n_amb: mismatching pairs with an ambiguous base (scored -1, not -b)
+        int t_first = lq, t_last = -1;     // the first and the last mismatching pair
+        // 32 pairs per round trip, eight per XOR: the batch's 4-bit reads against the 4-bit text (both strands: rb + t is a text position);
+        // without those tables the same words are put together from the bytes and the 2-bit reference
+        LaneTgt tg;
+        const bool packed = ix.tn && q4;
+        tg.init(ix, rb, 1);
+        for (int t0 = 0; t0 < lq; t0 += 32) {
+            uint32_t qx[4], tx[4];
+            if (packed) {
+                const i64 qp = off + qb + t0, tp = rb + t0;
+                const uint32_t* qa = q4 + (qp >> 3);
+                const uint32_t* ta = ix.tn + (tp >> 3);
+                uint32_t qr[5], tr[5];
+                for (int k = 0; k < 5; ++k) { qr[k] = qa[k]; tr[k] = ta[k]; }   // (both streams are padded past their ends)
+                const int qs = (int)(qp & 7) * 4, ts = (int)(tp & 7) * 4;
+                for (int k = 0; k < 4; ++k) {
+                    qx[k] = qs ? (qr[k] >> qs) | (qr[k + 1] << (32 - qs)) : qr[k];
+                    tx[k] = ts ? (tr[k] >> ts) | (tr[k + 1] << (32 - ts)) : tr[k];
+                }
+            } else {
+                for (int k = 0; k < 4; ++k) {
+                    qx[k] = 0; tx[k] = 0;
+                    for (int u = 0; u < 8 && t0 + 8 * k + u < lq; ++u) { qx[k] |= (uint32_t)(q[qb + t0 + 8 * k + u] & 0xf) << (4 * u); tx[k] |= (uint32_t)tg.base(t0 + 8 * k + u) << (4 * u); }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int tb = t0 + 8 * k;
+                if (tb >= lq) break;
+                const uint32_t qw = qx[k];
+                uint32_t xw = (qw ^ tx[k]) & (lq - tb < 8 ? (1u << (4 * (lq - tb))) - 1u : 0xffffffffu);
+                while (xw) {
+                    const int u = (__ffs((int)xw) - 1) >> 2, t = tb + u;
+                    xw &= ~(0xfu << (4 * u));
+                    if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
+                    else {   // (rare: the pool, see DCand)
+                        if (xo == -2) {
+                            xo = atomicAdd(R.mm_xctr, l_query - LH_MAX_MM);
+                            if (xo + l_query - LH_MAX_MM > R.mm_xcap) xo = -1;
+                            R.mm_xoff[c] = xo;
+                        }
+                        if (xo >= 0) { R.mm_xref[xo + nmm - LH_MAX_MM] = is_rev ? (int)refEnd - t : t + (int)refStart; R.mm_xread[xo + nmm - LH_MAX_MM] = qb + t; }
+                    }
+                    nmm++;
+                    n_amb += ((qw >> (4 * u)) & 0xf) > 3;
+                    t_first = t_first < t ? t_first : t; t_last = t;
+                }
+            }
+        }
+        const int NM = nmm;
+        if (w2 != 0) {
+            const int S0 = lq * o.a - (nmm - n_amb) * (o.a + o.b) - n_amb * (o.a + 1);
+            const int bound = (lq - 1) * o.a - (o.o_ins + o.e_ins) - (o.o_del + o.e_del);
+            if (S0 < bound) {
+                // A FEW MORE MISMATCHES (new in r03: 37 % of the candidates that used to need the wave DP).  The diagonal still wins when no
+                // path with gaps reaches it at ANY diagonal cell: let D(t) be the diagonal's score up to pair t and G(t) the best score of a
+                // path to (t, t) with gaps; ksw_global2 picks M at (t, t) iff H(t-1,t-1) + s >= E, F (ties towards the diagonal), and
+                // E(t,t), F(t,t) <= G(t), so G(t) <= D(t) for all t leaves score S0 and the CIGAR lq M, in every band and every retry.
+                // A path back on the diagonal has as many inserted as deleted bases.  (1) Three or more gap runs: at least two runs on one
+                // side, so >= 2 bases each way, cost >= C3 and at most t + 1 - 2 aligned pairs: below D(t) whenever the diagonal's total
+                // loss is <= 2a + C3.  (2) One run each way of g bases, cost c(g) = o_ins + o_del + g (e_ins + e_del): the detour replaces
+                // the pairs [x, e + g) by the pairs of the diagonal shifted by g over [x, e); its gain is (a + b) x (mismatches of the main
+                // diagonal in [x, e + g) - mismatches of the shifted one in [x, e)) - g a - c(g) <= loss - g a - c(g): never positive
+                // for g >= g0.  (3) For g < g0, both shifts: the largest gain over all x <= e is a running maximum (Kadane) over the two
+                // mismatch patterns, compared eight bases per word against the 4-bit text — this is where low-complexity sequence, whose
+                // shifted diagonals do match, is told apart.  Reads with an ambiguous base in the span take the DP.
+                const int loss = lq * o.a - S0;
+                const int c3a = 2 * o.o_ins + 2 * o.e_ins + o.o_del + 2 * o.e_del, c3b = 2 * o.o_del + 2 * o.e_del + o.o_ins + 2 * o.e_ins;
+                int okd = packed && n_amb == 0 && loss <= 2 * o.a + (c3a < c3b ? c3a : c3b);
+                int g0 = 1;
+                while (okd && o.o_ins + o.o_del + g0 * (o.e_ins + o.e_del + o.a) < loss) { if (++g0 > 5) okd = 0; }
+                if (okd && g0 > 3) okd = 0;   // (shifts of one and two bases are checked below: enough for every loss the bound of (1) admits with BWA's usual penalties)
+                if (okd) {
+                    // shifts 1 and 2, both directions, in one sweep from the first to the last mismatch of the main diagonal (outside, every gain is
+                    // zero or falling): sixteen bases of read and text per step in two 64-bit words, the shifted diagonals are shifts of those
+                    const i64 qp0 = off + qb;
+                    int K[4] = {0, 0, 0, 0};   // running maxima: (g = 1, insertion first), (1, deletion first), (2, ins), (2, del)
+                    const int e_beg = (t_first - 1 > 0 ? t_first - 1 : 0) & ~7;
+                    for (int e8 = e_beg; e8 <= t_last + 1 && okd; e8 += 8) {
+                        const u64 qq = (u64)dev_nib8(q4, qp0 + e8) | (u64)dev_nib8(q4, qp0 + e8 + 8) << 32;
+                        const u64 tt = (u64)dev_nib8(ix.tn, rb + e8) | (u64)dev_nib8(ix.tn, rb + e8 + 8) << 32;
+                        const u64 xm = qq ^ tt;   // (nibbles past the spans are never looked at: see the limits below)
+                        const u64 xs[4] = {(qq >> 4) ^ tt, qq ^ (tt >> 4), (qq >> 8) ^ tt, qq ^ (tt >> 8)};
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e8 + u;
+                            if (e > t_last + 1) break;
+                            const int m0 = ((xm >> (4 * u)) & 0xf) != 0, m1 = ((xm >> (4 * u + 4)) & 0xf) != 0;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const int g = 1 + (v >> 1);
+                                if (g >= g0 || e + g > lq) continue;
+                                const int lim = g * o.a + o.o_ins + o.o_del + g * (o.e_ins + o.e_del);   // g a + c(g)
+                                const int tail = m0 + (g == 2 ? m1 : 0);
+                                if ((o.a + o.b) * (K[v] + tail) > lim) okd = 0;
+                                const int mb = ((xs[v] >> (4 * u)) & 0xf) != 0;
+                                K[v] += m0 - mb;
+                                K[v] = K[v] > 0 ? K[v] : 0;
+                            }
+                        }
+                    }
+                }
+                if (!okd) return 1;   // a gapped path could win: run the DP (k_aln)
+            }
+            // the DP cells mem_reg2aln would have evaluated (telemetry stays comparable with the reference's work)
+            int wq = w2, it = 0, last_sc = -(1 << 30);
+            do {
+                wq = wq < o.w << 2 ? wq : o.w << 2;
+                int max_ins = (int)((double)(((lq + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
+                int max_del = (int)((double)(((lq + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
+                int max_gap = max_ins > max_del ? max_ins : max_del;
+                max_gap = max_gap > 1 ? max_gap : 1;
+                int w = (max_gap + 1) >> 1;
+                w = w < wq ? w : wq;
+                w = w > 3 ? w : 3;
+                {   // sum over rows i of min(i + w + 1, lq) - max(i - w, 0)   (rlen == lq here)
+                    const int n1 = lq - w > 0 ? lq - w : 0, m = lq - 1 - w > 0 ? lq - 1 - w : 0;
+                    *proven_cells += (unsigned)(n1 * (w + 1) + n1 * (n1 - 1) / 2 + (lq - n1) * lq - m * (m + 1) / 2);
+                }
+                if (S0 == last_sc || wq == o.w << 2) break;
+                last_sc = S0;
+                wq <<= 1;
+            } while (++it < 3 && S0 < ar.truesc - o.a);
+        }
+        int mm_ovf = 0;
+        if (nmm > LH_MAX_MM && xo < 0) { mm_ovf = 1; nmm = LH_MAX_MM; }   // (NM keeps the true count)
+        int clip5 = 0, clip3 = 0, no = 0;
+        if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
+        uint32_t* cgo = R.cigar + (size_t)c * LH_MAX_CIGAR;
+        if (clip5) cgo[no++] = (uint32_t)clip5 << 4 | 3;
+        cgo[no++] = (uint32_t)lq << 4 | 0;
+        if (clip3) cgo[no++] = (uint32_t)clip3 << 4 | 3;
+        const int soft_clipping = (clip5 > 0) + (clip3 > 0), soft_clipping_length = clip5 + clip3;
+        int mismatches = NM, matches = lq - NM;
+        const int rid = dev_pos2rid(ix, posf);
+        i64 pos = Offset, aend = End;
+        if (pos != -1 && is_rev) { pos = End + 1; aend = Offset + 1; }
+        R.rid[c] = rid; R.pos[c] = pos; R.aend[c] = aend; R.rb[c] = rb; R.re[c] = re; R.reversed[c] = (uint8_t)is_rev; R.score[c] = ar.score;
+        R.qb[c] = qb; R.qe[c] = qe; R.nm[c] = NM; R.matches[c] = matches; R.mismatches[c] = mismatches; R.indels[c] = 0;
+        R.soft_clipped[c] = soft_clipping; R.soft_clipped_length[c] = soft_clipping_length;
+        R.in_filtered[c] = ar.score >= best - o.aln_score_delta;
+        R.n_cigar[c] = no; R.n_mm[c] = nmm; R.read_len[c] = l_query;
+        R.lap[c] = (dev_single_score(mismatches, 0, soft_clipping, soft_clipping_length) + o.improper_pair_penalty) - o.improper_pair_penalty;
+        if (mm_ovf) atomicOr(status_r, LH_ST_MM_OVERFLOW);
+    return 0;
+}
+
+// ---- one lane per read: candidates without DP are finished here, the others are listed for k_aln; a read with more than LH_ALN_LANE_MAX regions
+// (a repeat copy: tens to hundreds of candidates) is listed for k_aln_heavy, which does the same with one lane per CANDIDATE ----
+#ifndef LH_ALN_LANE_MAX
+#define LH_ALN_LANE_MAX 32
+#endif
 __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                    const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, i64 cand_cap,
                                                    int32_t* __restrict__ status, int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count,
-                                                   DCounters* __restrict__ ctr, const uint32_t* __restrict__ q4) {
+                                                   DCounters* __restrict__ ctr, const uint32_t* __restrict__ q4, int32_t* __restrict__ heavy_r) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     const int live = r < n_reads;
     unsigned proven_cells = 0;   // cells of global DPs whose outcome is known without running them (see below)
-    int n = 0, n_slow = 0, all_slow = 0;
-    uint32_t slow_mask = 0;   // candidates ci < 32 that need DP; reads with more regions are listed entirely
+    int n = 0, n_slow = 0, heavy = 0;
+    uint32_t slow_mask = 0;   // the read's candidates that need DP
+    static_assert(LH_ALN_LANE_MAX <= 32, "slow_mask is one word");
     i64 c0 = 0;
     if (live) {
         const i64 off = seq_off[r];
@@ -295,188 +482,13 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
             R.in_filtered[c] = 1; R.n_cigar[c] = 0; R.n_mm[c] = 0; R.read_len[c] = l_query;
             R.lap[c] = (dev_single_score(0, 0, 0, 0) + o.improper_pair_penalty) - o.improper_pair_penalty;
         }
-        if (n > 32) { all_slow = 1; n_slow = n; }
+        if (n > LH_ALN_LANE_MAX) { heavy = 1; n = 0; }
         else {
             int best = 0;
             for (int i = 0; i < n; ++i) { int s = av[i].score; best = best > s ? best : s; }
             for (int ci = 0; ci < n; ++ci) {
-                DReg ar = av[ci];
-                const i64 c = c0 + ci;
-                const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
-                const i64 rb = ar.rb, re = ar.re;
-                const int rlen = (int)(re - rb);
-                const int valid = lq > 0 && rb < re && !(rb < ix.l_pac && re > ix.l_pac) && rlen <= LH_MAXT;
-                int tmp = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_del, o.e_del);
-                int w2 = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_ins, o.e_ins);
-                w2 = w2 > tmp ? w2 : tmp;
-                if (w2 > o.w) w2 = w2 < ar.w ? w2 : ar.w;
-                w2 = w2 < o.w << 2 ? w2 : o.w << 2;
-                if (!(valid && lq == rlen)) { slow_mask |= 1u << ci; n_slow++; continue; }
-                if (w2 != 0) {
-                    // Equal spans but an inferred band > 0 (BWA's test is only "fewer than two gaps' worth of penalty lost").  The
-                    // banded global alignment is still the plain diagonal whenever no path with gaps can beat it: such a path has
-                    // g >= 1 inserted and g deleted bases, so it scores at most (L-g)*a - (o_ins + g*e_ins) - (o_del + g*e_del),
-                    // largest at g = 1.  If the diagonal's own score S0 reaches that bound the DP ends on the diagonal (ties are
-                    // resolved towards the diagonal in ksw_global2: d = M >= E ? 0 : 1, then h >= F), every retry of mem_reg2aln
-                    // returns the same score, and the CIGAR is lq M.  With the default scoring this settles 3 mismatches
-                    // (bound: mm*(a+b) <= a + oe_ins + oe_del).  S0 needs the bases, so it is checked after the compare loop.
-                }
-                // no gap: CIGAR = [clip] lq M [clip]; one pass over the bases gives NM and lariat's mismatch loci.
-                // The aligned pairs are q[qb + t] vs the base at fwd||rev coordinate rb + t (the wave kernel's oriented views
-                // pair the same bases in the opposite order on the reverse strand).
-                int is_rev;
-                const i64 posf = dev_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
-                const i64 coff = ix.contig_off[ar.rid];
-                const i64 Offset = rb < ix.l_pac ? rb - coff : ix.l_pac * 2 - 1 - rb - coff;   // InterpretAlign (gobwa.go:339-371)
-                const i64 End = re < ix.l_pac ? re - coff : ix.l_pac * 2 - 1 - re - coff;
-                i64 refStart = Offset, refEnd = End;
-                if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
-                int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
-                int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
-                int nmm = 0, n_amb = 0, xo = -2;   // n_amb: mismatching pairs with an ambiguous base (scored -1, not -b)
-                int t_first = lq, t_last = -1;     // the first and the last mismatching pair
-                // 32 pairs per round trip, eight per XOR: the batch's 4-bit reads against the 4-bit text (both strands: rb + t is a text position);
-                // without those tables the same words are put together from the bytes and the 2-bit reference
-                LaneTgt tg;
-                const bool packed = ix.tn && q4;
-                tg.init(ix, rb, 1);
-                for (int t0 = 0; t0 < lq; t0 += 32) {
-                    uint32_t qx[4], tx[4];
-                    if (packed) {
-                        const i64 qp = off + qb + t0, tp = rb + t0;
-                        const uint32_t* qa = q4 + (qp >> 3);
-                        const uint32_t* ta = ix.tn + (tp >> 3);
-                        uint32_t qr[5], tr[5];
-                        for (int k = 0; k < 5; ++k) { qr[k] = qa[k]; tr[k] = ta[k]; }   // (both streams are padded past their ends)
-                        const int qs = (int)(qp & 7) * 4, ts = (int)(tp & 7) * 4;
-                        for (int k = 0; k < 4; ++k) {
-                            qx[k] = qs ? (qr[k] >> qs) | (qr[k + 1] << (32 - qs)) : qr[k];
-                            tx[k] = ts ? (tr[k] >> ts) | (tr[k + 1] << (32 - ts)) : tr[k];
-                        }
-                    } else {
-                        for (int k = 0; k < 4; ++k) {
-                            qx[k] = 0; tx[k] = 0;
-                            for (int u = 0; u < 8 && t0 + 8 * k + u < lq; ++u) { qx[k] |= (uint32_t)(q[qb + t0 + 8 * k + u] & 0xf) << (4 * u); tx[k] |= (uint32_t)tg.base(t0 + 8 * k + u) << (4 * u); }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int tb = t0 + 8 * k;
-                        if (tb >= lq) break;
-                        const uint32_t qw = qx[k];
-                        uint32_t xw = (qw ^ tx[k]) & (lq - tb < 8 ? (1u << (4 * (lq - tb))) - 1u : 0xffffffffu);
-                        while (xw) {
-                            const int u = (__ffs((int)xw) - 1) >> 2, t = tb + u;
-                            xw &= ~(0xfu << (4 * u));
-                            if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
-                            else {   // (rare: the pool, see DCand)
-                                if (xo == -2) {
-                                    xo = atomicAdd(R.mm_xctr, l_query - LH_MAX_MM);
-                                    if (xo + l_query - LH_MAX_MM > R.mm_xcap) xo = -1;
-                                    R.mm_xoff[c] = xo;
-                                }
-                                if (xo >= 0) { R.mm_xref[xo + nmm - LH_MAX_MM] = is_rev ? (int)refEnd - t : t + (int)refStart; R.mm_xread[xo + nmm - LH_MAX_MM] = qb + t; }
-                            }
-                            nmm++;
-                            n_amb += ((qw >> (4 * u)) & 0xf) > 3;
-                            t_first = t_first < t ? t_first : t; t_last = t;
-                        }
-                    }
-                }
-                const int NM = nmm;
-                if (w2 != 0) {
-                    const int S0 = lq * o.a - (nmm - n_amb) * (o.a + o.b) - n_amb * (o.a + 1);
-                    const int bound = (lq - 1) * o.a - (o.o_ins + o.e_ins) - (o.o_del + o.e_del);
-                    if (S0 < bound) {
-                        // A FEW MORE MISMATCHES (new in r03: 37 % of the candidates that used to need the wave DP).  The diagonal still wins when no
-                        // path with gaps reaches it at ANY diagonal cell: let D(t) be the diagonal's score up to pair t and G(t) the best score of a
-                        // path to (t, t) with gaps; ksw_global2 picks M at (t, t) iff H(t-1,t-1) + s >= E, F (ties towards the diagonal), and
-                        // E(t,t), F(t,t) <= G(t), so G(t) <= D(t) for all t leaves score S0 and the CIGAR lq M, in every band and every retry.
-                        // A path back on the diagonal has as many inserted as deleted bases.  (1) Three or more gap runs: at least two runs on one
-                        // side, so >= 2 bases each way, cost >= C3 and at most t + 1 - 2 aligned pairs: below D(t) whenever the diagonal's total
-                        // loss is <= 2a + C3.  (2) One run each way of g bases, cost c(g) = o_ins + o_del + g (e_ins + e_del): the detour replaces
-                        // the pairs [x, e + g) by the pairs of the diagonal shifted by g over [x, e); its gain is (a + b) x (mismatches of the main
-                        // diagonal in [x, e + g) - mismatches of the shifted one in [x, e)) - g a - c(g) <= loss - g a - c(g): never positive
-                        // for g >= g0.  (3) For g < g0, both shifts: the largest gain over all x <= e is a running maximum (Kadane) over the two
-                        // mismatch patterns, compared eight bases per word against the 4-bit text — this is where low-complexity sequence, whose
-                        // shifted diagonals do match, is told apart.  Reads with an ambiguous base in the span take the DP.
-                        const int loss = lq * o.a - S0;
-                        const int c3a = 2 * o.o_ins + 2 * o.e_ins + o.o_del + 2 * o.e_del, c3b = 2 * o.o_del + 2 * o.e_del + o.o_ins + 2 * o.e_ins;
-                        int okd = packed && n_amb == 0 && loss <= 2 * o.a + (c3a < c3b ? c3a : c3b);
-                        int g0 = 1;
-                        while (okd && o.o_ins + o.o_del + g0 * (o.e_ins + o.e_del + o.a) < loss) { if (++g0 > 5) okd = 0; }
-                        if (okd && g0 > 3) okd = 0;   // (shifts of one and two bases are checked below: enough for every loss the bound of (1) admits with BWA's usual penalties)
-                        if (okd) {
-                            // shifts 1 and 2, both directions, in one sweep from the first to the last mismatch of the main diagonal (outside, every gain is
-                            // zero or falling): sixteen bases of read and text per step in two 64-bit words, the shifted diagonals are shifts of those
-                            const i64 qp0 = off + qb;
-                            int K[4] = {0, 0, 0, 0};   // running maxima: (g = 1, insertion first), (1, deletion first), (2, ins), (2, del)
-                            const int e_beg = (t_first - 1 > 0 ? t_first - 1 : 0) & ~7;
-                            for (int e8 = e_beg; e8 <= t_last + 1 && okd; e8 += 8) {
-                                const u64 qq = (u64)dev_nib8(q4, qp0 + e8) | (u64)dev_nib8(q4, qp0 + e8 + 8) << 32;
-                                const u64 tt = (u64)dev_nib8(ix.tn, rb + e8) | (u64)dev_nib8(ix.tn, rb + e8 + 8) << 32;
-                                const u64 xm = qq ^ tt;   // (nibbles past the spans are never looked at: see the limits below)
-                                const u64 xs[4] = {(qq >> 4) ^ tt, qq ^ (tt >> 4), (qq >> 8) ^ tt, qq ^ (tt >> 8)};
-                                for (int u = 0; u < 8; ++u) {
-                                    const int e = e8 + u;
-                                    if (e > t_last + 1) break;
-                                    const int m0 = ((xm >> (4 * u)) & 0xf) != 0, m1 = ((xm >> (4 * u + 4)) & 0xf) != 0;
-#pragma unroll
-                                    for (int v = 0; v < 4; ++v) {
-                                        const int g = 1 + (v >> 1);
-                                        if (g >= g0 || e + g > lq) continue;
-                                        const int lim = g * o.a + o.o_ins + o.o_del + g * (o.e_ins + o.e_del);   // g a + c(g)
-                                        const int tail = m0 + (g == 2 ? m1 : 0);
-                                        if ((o.a + o.b) * (K[v] + tail) > lim) okd = 0;
-                                        const int mb = ((xs[v] >> (4 * u)) & 0xf) != 0;
-                                        K[v] += m0 - mb;
-                                        K[v] = K[v] > 0 ? K[v] : 0;
-                                    }
-                                }
-                            }
-                        }
-                        if (!okd) { slow_mask |= 1u << ci; n_slow++; continue; }   // a gapped path could win: run the DP (k_aln)
-                    }
-                    // the DP cells mem_reg2aln would have evaluated (telemetry stays comparable with the reference's work)
-                    int wq = w2, it = 0, last_sc = -(1 << 30);
-                    do {
-                        wq = wq < o.w << 2 ? wq : o.w << 2;
-                        int max_ins = (int)((double)(((lq + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
-                        int max_del = (int)((double)(((lq + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
-                        int max_gap = max_ins > max_del ? max_ins : max_del;
-                        max_gap = max_gap > 1 ? max_gap : 1;
-                        int w = (max_gap + 1) >> 1;
-                        w = w < wq ? w : wq;
-                        w = w > 3 ? w : 3;
-                        {   // sum over rows i of min(i + w + 1, lq) - max(i - w, 0)   (rlen == lq here)
-                            const int n1 = lq - w > 0 ? lq - w : 0, m = lq - 1 - w > 0 ? lq - 1 - w : 0;
-                            proven_cells += (unsigned)(n1 * (w + 1) + n1 * (n1 - 1) / 2 + (lq - n1) * lq - m * (m + 1) / 2);
-                        }
-                        if (S0 == last_sc || wq == o.w << 2) break;
-                        last_sc = S0;
-                        wq <<= 1;
-                    } while (++it < 3 && S0 < ar.truesc - o.a);
-                }
-                int mm_ovf = 0;
-                if (nmm > LH_MAX_MM && xo < 0) { mm_ovf = 1; nmm = LH_MAX_MM; }   // (NM keeps the true count)
-                int clip5 = 0, clip3 = 0, no = 0;
-                if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
-                uint32_t* cgo = R.cigar + (size_t)c * LH_MAX_CIGAR;
-                if (clip5) cgo[no++] = (uint32_t)clip5 << 4 | 3;
-                cgo[no++] = (uint32_t)lq << 4 | 0;
-                if (clip3) cgo[no++] = (uint32_t)clip3 << 4 | 3;
-                const int soft_clipping = (clip5 > 0) + (clip3 > 0), soft_clipping_length = clip5 + clip3;
-                int mismatches = NM, matches = lq - NM;
-                const int rid = dev_pos2rid(ix, posf);
-                i64 pos = Offset, aend = End;
-                if (pos != -1 && is_rev) { pos = End + 1; aend = Offset + 1; }
-                R.rid[c] = rid; R.pos[c] = pos; R.aend[c] = aend; R.rb[c] = rb; R.re[c] = re; R.reversed[c] = (uint8_t)is_rev; R.score[c] = ar.score;
-                R.qb[c] = qb; R.qe[c] = qe; R.nm[c] = NM; R.matches[c] = matches; R.mismatches[c] = mismatches; R.indels[c] = 0;
-                R.soft_clipped[c] = soft_clipping; R.soft_clipped_length[c] = soft_clipping_length;
-                R.in_filtered[c] = ar.score >= best - o.aln_score_delta;
-                R.n_cigar[c] = no; R.n_mm[c] = nmm; R.read_len[c] = l_query;
-                R.lap[c] = (dev_single_score(mismatches, 0, soft_clipping, soft_clipping_length) + o.improper_pair_penalty) - o.improper_pair_penalty;
-                if (mm_ovf) atomicOr(&status[r], LH_ST_MM_OVERFLOW);
+                const DReg ar = av[ci];
+                if (aln_fast_cand(ix, o, R, q, q4, off, l_query, ar, c0 + ci, best, &status[r], &proven_cells)) { slow_mask |= 1u << ci; n_slow++; }
             }
         }
     }
@@ -492,6 +504,57 @@ __global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_read
         if (lane == 0) basep = atomicAdd(slow_count, total);
         basep = wave_readlane(basep, 0) + incl - n_slow;
         for (int ci = 0; ci < n; ++ci)
-            if (all_slow || (slow_mask >> ci & 1)) { slow_r[basep] = r; slow_ci[basep] = ci; basep++; }
+            if (slow_mask >> ci & 1) { slow_r[basep] = r; slow_ci[basep] = ci; basep++; }
+    }
+    const u64 hb = __ballot(heavy);
+    if (hb) {
+        int hbase = 0;
+        if (lane == 0) hbase = atomicAdd(slow_count + 1, (int)__popcll(hb));
+        hbase = wave_readlane(hbase, 0);
+        if (heavy) heavy_r[hbase + lanes_below(hb, lane)] = r;
+    }
+}
+
+// ---- one WAVE per listed read, one lane per candidate: the same per-candidate program as k_aln_fast's (64 candidates of one read side by side,
+// their result fields written next to each other); the ones that need the DP are appended to k_aln's list ----
+__global__ void __launch_bounds__(64) k_aln_heavy(DIndex ix, DOpts o, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
+                                                   const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, int32_t* __restrict__ status,
+                                                   int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count, DCounters* __restrict__ ctr,
+                                                   const uint32_t* __restrict__ q4, const int32_t* __restrict__ heavy_r) {
+    const int lane = LANE();
+    const int n_items = slow_count[1];
+    unsigned proven_cells = 0;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int r = heavy_r[item];
+        const i64 off = seq_off[r];
+        int l_query = (int)(seq_off[r + 1] - off);
+        if (l_query > LH_MAXLEN) l_query = 0;
+        const uint8_t* q = seq + off;
+        const DReg* av = regs + reg_off[r];
+        const int n = n_regs[r];
+        const i64 c0 = R.cand_off[r];
+        int best = 0;
+        for (int i = lane; i < n; i += 64) { int s = av[i].score; best = best > s ? best : s; }
+        best = wave_max_i32(best);
+        for (int cb = 0; cb < n; cb += 64) {
+            const int ci = cb + lane;
+            int slow = 0;
+            if (ci < n) {
+                const DReg ar = av[ci];
+                slow = aln_fast_cand(ix, o, R, q, q4, off, l_query, ar, c0 + ci, best, &status[r], &proven_cells);
+            }
+            const u64 sb = __ballot(slow);
+            if (sb) {
+                int basep = 0;
+                if (lane == 0) basep = atomicAdd(slow_count, (int)__popcll(sb));
+                basep = wave_readlane(basep, 0) + lanes_below(sb, lane);
+                if (slow) { slow_r[basep] = r; slow_ci[basep] = ci; }
+            }
+        }
+    }
+    if (ctr) {
+        u64 tot = (u64)(uint32_t)wave_sum_i32((int)(proven_cells >> 16)) << 16;
+        tot += (u64)(uint32_t)wave_sum_i32((int)(proven_cells & 0xffff));
+        if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->glob_cells, tot);
     }
 }
