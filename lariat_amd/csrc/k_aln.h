@@ -558,3 +558,259 @@ __global__ void __launch_bounds__(64) k_aln_heavy(DIndex ix, DOpts o, const uint
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->glob_cells, tot);
     }
 }
+
+// ---- FOUR listed candidates per wave (new in r04): the banded global alignment in a group of 16 lanes ----
+// The band mem_reg2aln asks for is wide (a read with five mismatches: w = 21, 43 columns; measured on the repeat-family input: 15 % of the
+// listed candidates have at most 16 columns, 55 % between 33 and 64), the alignment it finds is not: almost always it stays within a few
+// columns of the main diagonal.  A NARROW band of wn = 7 (15 columns) gives the same score AND the same traceback as any wider one when
+// every path that leaves the narrow band scores below the narrow band's optimum Sn.  Such a path holds at least wn + 1 inserted bases at
+// some point (or wn + 1 deleted ones) and must come back to the end cell, dq = lq - rlen columns off the main diagonal: at most
+//   U = max( a (lq - (wn+1)) - (o_ins + e_ins (wn+1)) - [o_del + e_del (wn+1-dq)]+ ,  a (rlen - (wn+1)) - (o_del + e_del (wn+1)) - [o_ins + e_ins (wn+1+dq)]+ )
+// even if every aligned pair matched.  Sn > U: the wide DP's optimum is Sn as well (the narrow band's cells are a subset), its traceback is
+// an optimal path, hence inside the narrow band; along that path every value the traceback's choices look at is the same in both DPs on the
+// chosen side and no larger in the narrow one on the other side (a cell value of the narrow band never exceeds the wide band's), and
+// ksw_global2 resolves ties by fixed preference (diagonal, then E, then F), so the same choice is made at every cell: the same CIGAR.  The
+// same holds for each wider band of mem_reg2aln's retries, which therefore return Sn again and stop.  Measured: 83 % of the listed
+// candidates of the repeat-family input and 99.9 % of the headline's are settled here; the others (Sn <= U, a reference span beyond
+// LH_GRP_T, more than LH_GRP_CIG operations) are listed for k_aln, which starts them afresh.
+#define LH_GRP_W 7
+#define LH_GRP_T 176
+#define LH_GRP_Z (LH_GRP_T * (2 * LH_GRP_W + 1))
+#define LH_GRP_CIG 32
+__global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
+                                                 const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, int32_t* __restrict__ status, DCounters* __restrict__ ctr,
+                                                 const int32_t* __restrict__ slow_r, const int32_t* __restrict__ slow_ci, const int32_t* __restrict__ slow_count,
+                                                 int32_t* __restrict__ wide_r, int32_t* __restrict__ wide_ci, int32_t* __restrict__ wide_count) {
+    __shared__ uint8_t q_[4][LH_MAXLEN + 6];
+    __shared__ uint8_t tref_[4][LH_GRP_T];
+    __shared__ uint32_t cg_[4][LH_GRP_CIG + 4];
+    __shared__ uint32_t cgo_[4][LH_GRP_CIG + 4];
+    __shared__ int32_t sh_[4][8];
+    __shared__ uint8_t z_[4][LH_GRP_Z];
+    const int lane = LANE(), g = lane >> 4, d = lane & 15;
+    uint8_t* const q = q_[g];
+    uint8_t* const tref = tref_[g];
+    uint32_t* const cg = cg_[g];
+    uint32_t* const cgo = cgo_[g];
+    int32_t* const sh = sh_[g];
+    uint8_t* const z = z_[g];
+    u64 cells = 0;   // (the group's first lane: the cells of the DPs mem_reg2aln asks for, whatever band was run)
+    const int n_items = *slow_count;
+    for (int base = blockIdx.x * 4; base < n_items; base += gridDim.x * 4) {
+        const int item = base + g;
+        const int has = item < n_items;
+        int r = 0, ci = 0, l_query = 0, n = 0;
+        i64 off = 0, c0 = 0;
+        const DReg* av = regs;
+        if (has) {
+            r = slow_r[item]; ci = slow_ci[item];
+            off = seq_off[r];
+            l_query = (int)(seq_off[r + 1] - off);
+            if (l_query > LH_MAXLEN) l_query = 0;
+            av = regs + reg_off[r];
+            n = n_regs[r];
+            c0 = R.cand_off[r];
+        }
+        WAVE_SYNC();
+        for (int i = d; i < l_query; i += 16) q[i] = seq[off + i];
+        int best = 0;
+        for (int i = d; i < n; i += 16) { int s = av[i].score; best = best > s ? best : s; }
+        best = grp_max_i32(best);
+        DReg ar;
+        ar.rb = ar.re = 0; ar.qb = ar.qe = ar.rid = ar.score = ar.truesc = ar.w = 0;
+        if (has) ar = av[ci];
+        const i64 c = c0 + ci;
+        const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
+        const i64 rb = ar.rb, re = ar.re;
+        const int rlen = (int)(re - rb);
+        const int rev = rb >= ix.l_pac;
+        const int qoff = rev ? qe - 1 : qb, qstep = rev ? -1 : 1;
+        const i64 t0 = rev ? re - 1 : rb;
+        const int tstep = rev ? -1 : 1;
+        const int dq = lq - rlen, adq = dq < 0 ? -dq : dq;
+        const int valid = has && lq > 0 && rb < re && !(rb < ix.l_pac && re > ix.l_pac) && re - rb <= LH_GRP_T;
+        int towide = has && !valid;
+        if (valid)
+            for (int i = d; i < rlen; i += 16) tref[i] = (uint8_t)dev_ref_base(ix, t0 + (i64)tstep * i);
+        WAVE_SYNC();
+        int tmp = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_del, o.e_del);
+        int w2 = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_ins, o.e_ins);
+        w2 = w2 > tmp ? w2 : tmp;
+        if (w2 > o.w) w2 = w2 < ar.w ? w2 : ar.w;
+        int score = 0, last_sc = -(1 << 30), n_cigar = 0, proved = 0, wn = 0;
+        u64 ccells = 0;   // this candidate's DP cells (counted when it is settled here: k_aln counts its own)
+        int act = valid;   // mem_reg2aln's loop is still running for this candidate
+        for (int it = 0; it < 3; ++it) {
+            if (!__any(act)) break;
+            int w = 0, run = 0;
+            if (act) {
+                w2 = w2 < o.w << 2 ? w2 : o.w << 2;
+                if (lq == rlen && w2 == 0) { towide = 1; act = 0; }   // ("no gap; no need to do DP": never listed by the kernels above; k_aln has the branch)
+                else {
+                    int max_ins = (int)((double)(((lq + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
+                    int max_del = (int)((double)(((lq + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
+                    int max_gap = max_ins > max_del ? max_ins : max_del;
+                    max_gap = max_gap > 1 ? max_gap : 1;
+                    w = (max_gap + adq + 1) >> 1;
+                    w = w < w2 ? w : w2;
+                    const int min_w = adq + 3;
+                    w = w > min_w ? w : min_w;
+                    if (d == 0)
+                        for (int i = 0; i < rlen; ++i) {   // the cells ksw_global2 evaluates with the band it was asked for
+                            const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
+                            if (end > beg) ccells += (u64)(end - beg);
+                        }
+                    if (!proved) {
+                        wn = w < LH_GRP_W ? w : LH_GRP_W;
+                        if (wn < adq + 3) { towide = 1; act = 0; }   // (the narrow band would not reach the end cell with BWA's own margin)
+                        else run = 1;
+                    }
+                }
+            }
+            const int tl_max = wave_max_i32(run ? rlen : 0);
+            if (tl_max > 0) {
+                const int sc = grp_ksw_global2_band(o, q, qoff, qstep, lq, tref, rlen, wn, z, lane, run, tl_max);
+                if (run) score = sc;
+            }
+            WAVE_SYNC();
+            if (run && wn < w) {
+                const int ui = o.a * (lq - (wn + 1)) - (o.o_ins + o.e_ins * (wn + 1)) - (wn + 1 - dq > 0 ? o.o_del + o.e_del * (wn + 1 - dq) : 0);
+                const int ud = o.a * (rlen - (wn + 1)) - (o.o_del + o.e_del * (wn + 1)) - (wn + 1 + dq > 0 ? o.o_ins + o.e_ins * (wn + 1 + dq) : 0);
+                if (score > (ui > ud ? ui : ud)) proved = 1;
+                else { towide = 1; act = 0; run = 0; }
+            }
+            if (run && d == 0) {   // backtrack, by the group's first lane (ops are produced last-to-first; equal neighbours merge)
+                const int n_col = lq < 2 * wn + 1 ? lq : 2 * wn + 1;
+                int which = 0, nc = 0, ovf = 0;
+                int i = rlen - 1, k = (i + wn + 1 < lq ? i + wn + 1 : lq) - 1;
+                while (i >= 0 && k >= 0) {
+                    which = z[i * n_col + (k - (i > wn ? i - wn : 0))] >> (which << 1) & 3;
+                    int op;
+                    if (which == 0) { op = 0; --i; --k; }
+                    else if (which == 1) { op = 2; --i; }
+                    else { op = 1; --k; }
+                    if (nc == 0 || op != (int)(cg[nc - 1] & 0xf)) { if (nc < LH_GRP_CIG) cg[nc++] = 1u << 4 | op; else ovf = 1; }
+                    else cg[nc - 1] += 1u << 4;
+                }
+                if (i >= 0) { if (nc == 0 || 2 != (int)(cg[nc - 1] & 0xf)) { if (nc < LH_GRP_CIG) cg[nc++] = (uint32_t)(i + 1) << 4 | 2; else ovf = 1; } else cg[nc - 1] += (uint32_t)(i + 1) << 4; }
+                if (k >= 0) { if (nc == 0 || 1 != (int)(cg[nc - 1] & 0xf)) { if (nc < LH_GRP_CIG) cg[nc++] = (uint32_t)(k + 1) << 4 | 1; else ovf = 1; } else cg[nc - 1] += (uint32_t)(k + 1) << 4; }
+                for (int u = 0; u < nc >> 1; ++u) { uint32_t t = cg[u]; cg[u] = cg[nc - 1 - u]; cg[nc - 1 - u] = t; }
+                sh[0] = nc; sh[1] = ovf;
+            }
+            WAVE_SYNC();
+            if (run) {
+                n_cigar = sh[0];
+                if (sh[1]) { towide = 1; act = 0; }
+            }
+            if (act) {   // (a proved candidate's wider retry returns the same score: this is where its loop ends)
+                if (score == last_sc || w2 == o.w << 2) act = 0;
+                else {
+                    last_sc = score;
+                    w2 <<= 1;
+                    if (!(it + 1 < 3 && score < ar.truesc - o.a)) act = 0;
+                }
+            }
+        }
+        const int fin = valid && !towide;
+        // NM: mismatches inside M runs + inserted + deleted bases (terminal D excluded)
+        int NM = 0;
+        {
+            int x = 0, y = 0, n_mm = 0, n_gap = 0;
+            if (fin)
+                for (int k = 0; k < n_cigar; ++k) {
+                    const int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
+                    if (op == 0) {
+                        for (int t = d; t < len; t += 16) n_mm += q[qoff + qstep * (x + t)] != tref[y + t];
+                        x += len; y += len;
+                    } else if (op == 2) {
+                        if (k > 0 && k < n_cigar - 1) n_gap += len;
+                        y += len;
+                    } else if (op == 1) { x += len; n_gap += len; }
+                }
+            NM = grp_sum_i32(n_mm) + n_gap;
+        }
+        int is_rev = 0;
+        i64 posf = 0;
+        if (fin) posf = dev_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+        WAVE_SYNC();
+        if (fin && d == 0) {
+            int nc = n_cigar, s0 = 0, no = 0;
+            if (nc > 0) {   // squeeze out leading or trailing deletions
+                if ((cg[0] & 0xf) == 2) { s0 = 1; nc--; }
+                else if ((cg[nc - 1] & 0xf) == 2) nc--;
+            }
+            int clip5 = 0, clip3 = 0;
+            if (qb != 0 || qe != l_query) { clip5 = is_rev ? l_query - qe : qb; clip3 = is_rev ? qb : l_query - qe; }
+            if (clip5) cgo[no++] = (uint32_t)clip5 << 4 | 3;
+            for (int u = 0; u < nc; ++u) cgo[no++] = cg[s0 + u];
+            if (clip3) cgo[no++] = (uint32_t)clip3 << 4 | 3;
+            sh[3] = no;
+        }
+        WAVE_SYNC();
+        const int no = fin ? sh[3] : 0;
+        static_assert(LH_GRP_CIG + 2 <= LH_MAX_CIGAR, "a group's CIGAR with both clips fits the candidate's slots");
+        const i64 coff = fin ? ix.contig_off[ar.rid] : 0;
+        const i64 Offset = rb < ix.l_pac ? rb - coff : ix.l_pac * 2 - 1 - rb - coff;   // InterpretAlign (gobwa.go:339-371)
+        const i64 End = re < ix.l_pac ? re - coff : ix.l_pac * 2 - 1 - re - coff;
+        i64 refStart = Offset, refEnd = End;
+        if (is_rev) { refStart = End + 1; refEnd = Offset + 1; }
+        // CIGAR walk in READ orientation (lariat.go:1591-1632): the group's lanes over the bases of each M run
+        int matches = 0, indels = 0, indel_length = 0, soft_clipping = 0, soft_clipping_length = 0, refSeqOffset = 0, readOffset = 0, nmm = 0;
+        int32_t* mref = R.mm_ref + (size_t)c * LH_MAX_MM;
+        int32_t* mread = R.mm_read + (size_t)c * LH_MAX_MM;
+        const int refLen = (int)(refEnd - refStart);
+        const int no_max = wave_max_i32(no);
+        for (int u = 0; u < no_max; ++u) {
+            const uint32_t cv = u < no ? cgo[is_rev ? no - 1 - u : u] : 15u;
+            const int op = cv & 0xf, len = (int)(cv >> 4);
+            const int mlen = op == 0 ? len : 0;
+            const int lmax = wave_max_i32(mlen);
+            for (int t0 = 0; t0 < lmax; t0 += 16) {
+                const int t = t0 + d, k = refSeqOffset + t;
+                int mm = 0;
+                if (t < mlen && k < refLen && readOffset + t < l_query) {
+                    const int rbase = k < rlen ? tref[rev ? rlen - 1 - k : k] : 255;
+                    mm = rbase != q[readOffset + t];
+                }
+                const uint32_t bm = (uint32_t)(__ballot(mm) >> (g * 16)) & 0xffffu;
+                if (nmm + (int)__popc(bm) > LH_MAX_MM) towide = 1;   // (more loci than slots: k_aln knows the pool)
+                else if (mm) {
+                    const int slot = nmm + (int)__popc(bm & ((1u << d) - 1u));
+                    mref[slot] = is_rev ? (int)refEnd - k : k + (int)refStart; mread[slot] = readOffset + t;
+                }
+                nmm += (int)__popc(bm);
+            }
+            if (op == 0) { matches += len; refSeqOffset += len; readOffset += len; }
+            else if (op == 1) { indels += 1; indel_length += len; readOffset += len; }
+            else if (op == 2) { indels += 1; indel_length += len; refSeqOffset += len; }
+            else if (op == 3) { soft_clipping += 1; soft_clipping_length += len; readOffset += len; }
+        }
+        if (fin && !towide) {
+            cells += ccells;
+            for (int k = d; k < no; k += 16) R.cigar[(size_t)c * LH_MAX_CIGAR + k] = cgo[k];
+            if (d == 0) {
+                const int rid = dev_pos2rid(ix, posf);
+                int mismatches = NM - indel_length;
+                matches -= mismatches;
+                if (mismatches < 0) mismatches = 0;
+                i64 pos = Offset, aend = End;
+                if (pos != -1 && is_rev) { pos = End + 1; aend = Offset + 1; }
+                R.rid[c] = rid; R.pos[c] = pos; R.aend[c] = aend; R.rb[c] = rb; R.re[c] = re; R.reversed[c] = (uint8_t)is_rev; R.score[c] = ar.score;
+                R.qb[c] = qb; R.qe[c] = qe; R.nm[c] = NM; R.matches[c] = matches; R.mismatches[c] = mismatches; R.indels[c] = indels;
+                R.soft_clipped[c] = soft_clipping; R.soft_clipped_length[c] = soft_clipping_length;
+                R.in_filtered[c] = ar.score >= best - o.aln_score_delta;
+                R.n_cigar[c] = no; R.n_mm[c] = nmm; R.read_len[c] = l_query;
+                R.lap[c] = (dev_single_score(mismatches, indels, soft_clipping, soft_clipping_length) + o.improper_pair_penalty) - o.improper_pair_penalty;
+            }
+        }
+        // the candidates this kernel does not settle: listed for k_aln (the wave reserves the space once)
+        const u64 tb = __ballot(towide && d == 0);
+        if (tb) {
+            int bp = 0;
+            if (lane == 0) bp = atomicAdd(wide_count, (int)__popcll(tb));
+            bp = wave_readlane(bp, 0) + (int)__popcll(tb & ((1ull << lane) - 1ull));
+            if (towide && d == 0) { wide_r[bp] = r; wide_ci[bp] = ci; }
+        }
+    }
+    if (d == 0 && ctr && cells) atomicAdd(&LH_CTR(ctr)->glob_cells, cells);
+}

@@ -164,6 +164,86 @@ __device__ __forceinline__ int wave_ksw_global2_band(const DIndex& ix, const DOp
     return last;
 }
 
+// ---- the same recurrence for FOUR candidates per wave: a group of 16 lanes per candidate, lane d of the group = band column d (2w + 1 <= 15) ----
+// Every cross-lane operation stays inside a DPP row (= the group); the four groups run their own rows side by side, a group whose DP is
+// shorter (or that has none: run = 0) idles through the other groups' rows.  qarr / tg / z: the group's LDS areas (tg[i] = reference base of row i).
+#ifdef LH_EMU
+__device__ __forceinline__ int grp_scan_max_i32(int v, int lane) {
+    for (int d = 1; d < 16; d <<= 1) { int o = __shfl_up(v, d); if ((lane & 15) >= d) v = v > o ? v : o; }
+    return v;
+}
+__device__ __forceinline__ int grp_shr1_i32(int v, int fill) { int o = __shfl_up(v, 1); return (LANE() & 15) == 0 ? fill : o; }
+__device__ __forceinline__ int grp_shl1_i32(int v, int fill) { int o = __shfl_down(v, 1); return (LANE() & 15) == 15 ? fill : o; }
+#else
+__device__ __forceinline__ int grp_scan_max_i32(int v, int) {
+    const int ID = (int)0x80000000;
+    int t;
+    t = LH_DPP(ID, v, 0x111, 0xF); v = v > t ? v : t;
+    t = LH_DPP(ID, v, 0x112, 0xF); v = v > t ? v : t;
+    t = LH_DPP(ID, v, 0x114, 0xF); v = v > t ? v : t;
+    t = LH_DPP(ID, v, 0x118, 0xF); v = v > t ? v : t;
+    return v;
+}
+__device__ __forceinline__ int grp_shr1_i32(int v, int fill) { return LH_DPP(fill, v, 0x111, 0xF); }   // row_shr:1
+__device__ __forceinline__ int grp_shl1_i32(int v, int fill) { return LH_DPP(fill, v, 0x101, 0xF); }   // row_shl:1
+#endif
+__device__ __forceinline__ int grp_max_i32(int v) { for (int m = 8; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v > o ? v : o; } return v; }
+__device__ __forceinline__ int grp_sum_i32(int v) { for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m); return v; }
+
+__device__ __forceinline__ int grp_ksw_global2_band(const DOpts& o, const uint8_t* qarr, int qoff, int qstep, int qlen, const uint8_t* tg, int tlen, int w, uint8_t* z, int lane,
+                                                    int run, int tl_max) {
+    const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const int d = lane & 15;
+    int H, E = LH_MINUS_INF, lastv = LH_MINUS_INF;
+    {
+        const int j = d - w;
+        H = j == 0 ? 0 : ((j >= 1 && j <= qlen && j <= w) ? -(o_ins + e_ins * j) : LH_MINUS_INF);
+    }
+    for (int i = 0; i < tl_max; ++i) {
+        const int ra = run && i < tlen;
+        const int tb = ra ? tg[i] : 4;
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int j = i - w + d;
+        const int in = ra && j >= beg && j < end;
+        int mm = LH_MINUS_INF, tins = LH_MINUS_INF, dir = 0;
+        if (in) {
+            const int qv = qarr[qoff + qstep * j];
+            const int sc = (tb > 3 || qv > 3) ? -1 : (tb == qv ? a_ : -b_);
+            mm = (j == 0 ? (i == 0 ? 0 : -(o_del + e_del * i)) : H) + sc;
+            tins = mm - oe_ins;
+        }
+        const int bj = in ? tins + (j + 1) * e_ins : -0x7fffffff;
+        const int incl = grp_scan_max_i32(bj, lane);
+        const int excl = grp_shr1_i32(incl, -0x7fffffff);
+        const int gc = LH_MINUS_INF + beg * e_ins;
+        const int G = gc > excl ? gc : excl;
+        const int f = G - j * e_ins;
+        int h = LH_MINUS_INF, enew = LH_MINUS_INF;
+        if (in) {
+            const int e = E;
+            dir = mm >= e ? 0 : 1;
+            h = mm >= e ? mm : e;
+            dir = h >= f ? dir : 2;
+            h = h >= f ? h : f;
+            const int t_ = mm - oe_del;
+            enew = e - e_del;
+            dir |= enew > t_ ? 1 << 2 : 0;
+            enew = enew > t_ ? enew : t_;
+            const int fd = f - e_ins;
+            dir |= fd > tins ? 2 << 4 : 0;
+            z[i * n_col + (j - beg)] = (uint8_t)dir;
+            if (j == qlen - 1) lastv = h;
+        }
+        H = in ? h : LH_MINUS_INF;
+        E = grp_shl1_i32(in ? enew : LH_MINUS_INF, LH_MINUS_INF);
+    }
+    // eh[qlen].h after the last row = H(tlen - 1, qlen - 1): the band reaches that cell (callers: w >= |qlen - tlen| + 3), lane qlen - tlen + w held it
+    return grp_max_i32(run && d == qlen - tlen + w ? lastv : (int)0x80000000);
+}
+
 // bwa_gen_cigar2 without traceback: global score of query[qb_..qe_) against the fwd||rev reference interval [rb,re).
 // Returns 0 and sets *ok=0 when upstream would reject the interval.
 __device__ __forceinline__ int wave_gen_score(const DIndex& ix, const DOpts& o, const uint8_t* q, int qb_, int l_query, int w_, i64 rb, i64 re, int lane, int* ok,

@@ -249,3 +249,25 @@ def k7_shift_case(g, ins_first):
     mate = contig[p + 250:p + 400]
     r2 = (3 - mate[::-1]).astype(np.uint8)
     return ["chrK"], [contig], capi.Batch([r1, r2], [0, 1]), p
+
+
+def k7_band_case(g, ins_first):
+    """a read pair whose read 1 runs g columns off its main diagonal for 60 bases: g inserted bases after base 40 and g deleted reference bases
+    60 bases later (or the other way round) — equal spans, a path of two gaps.  K7's four-per-wave kernel (k_aln_grp, k_aln.h) runs a band
+    of 7 and proves it sufficient; from g = 8 on the path lies outside that band and the proof must fail.  Returns (names, contigs, batch, p)."""
+    from lariat_amd import capi
+    rng = np.random.default_rng(1000 + 2 * g + int(ins_first))
+    contig = rng.integers(0, 4, size=8400).astype(np.uint8)
+    p = 4000
+    R = contig[p:p + 150]
+    X = rng.integers(0, 4, size=g).astype(np.uint8)
+    if ins_first:
+        X[0] = (R[40] + 1) & 3; X[-1] = (R[39] + 2) & 3
+        r1 = np.concatenate([R[:40], X, R[40:100], R[100 + g:]])
+    else:
+        r1 = np.concatenate([R[:40], R[40 + g:110], X, R[110:]])
+    r1 = r1.astype(np.uint8)
+    assert len(r1) == 150
+    mate = contig[p + 250:p + 400]
+    r2 = (3 - mate[::-1]).astype(np.uint8)
+    return ["chrB"], [contig], capi.Batch([r1, r2], [0, 1]), p

@@ -355,3 +355,21 @@ def test_emu_k7_gapped_path_beats_a_four_mismatch_diagonal(emu, oracle, g, ins_f
     helpers.assert_same_result(res, ores, inference=False)
     c = list(ores.cands_of_read(0))[0]
     assert int(ores.indels[c]) == 2 and int(ores.mismatches[c]) == 0 and int(ores.pos[c]) == p - 66
+
+
+@pytest.mark.parametrize("g,ins_first", [(3, True), (6, False), (7, True), (7, False), (8, True), (8, False), (9, False), (12, True)])
+def test_emu_k7_narrow_band_and_its_proof(emu, oracle, g, ins_first):
+    """K7's four-candidates-per-wave kernel runs a band of 7 whatever band mem_reg2aln asks for (here 20 and more) and keeps the result only when
+    no path outside that band can reach its score (k_aln.h, k_aln_grp).  A read that runs g columns off its diagonal for 60 bases: up to
+    g = 7 the path is inside the band and the bound holds (a path further out loses at least 8 pairs and two longer gaps); from g = 8 on the
+    band of 7 cannot hold the path, the bound says so, and the candidate takes the wave kernel with the full band.  Every field against the
+    oracle's ksw_global2 with BWA's own band."""
+    names, contigs, b, p = helpers.k7_band_case(g, ins_first)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    res = idx.context(8).align_barcodes(b, emu.opts(run_inference=0))
+    ores = oidx.align_barcodes(b, oracle.opts(run_inference=0))
+    helpers.assert_same_result(res, ores, inference=False)
+    assert res.counters["glob_cells"] == ores.counters["glob_cells"]
+    c = list(ores.cands_of_read(0))[0]
+    assert int(ores.indels[c]) == 2 and int(ores.pos[c]) == p

@@ -194,3 +194,18 @@ def test_gapped_path_beats_a_four_mismatch_diagonal(lib, oracle, g, ins_first):
     helpers.assert_same_result(res, ores, inference=False)
     c = list(res.cands_of_read(0))[0]
     assert int(res.indels[c]) == 2 and int(res.mismatches[c]) == 0 and int(res.pos[c]) == p - 66
+
+
+@pytest.mark.parametrize("g,ins_first", [(3, True), (7, False), (8, True), (8, False), (12, True)])
+def test_k7_narrow_band_and_its_proof(lib, oracle, g, ins_first):
+    """k_aln_grp's band of 7 and the bound that decides whether its result stands, on the device (the construction: helpers.k7_band_case,
+    the argument: tests/test_emu_front.py)"""
+    names, contigs, b, p = helpers.k7_band_case(g, ins_first)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    res = idx.context(8).align_barcodes(b, lib.opts(run_inference=0))
+    ores = oidx.align_barcodes(b, oracle.opts(run_inference=0))
+    helpers.assert_same_result(res, ores, inference=False)
+    assert res.counters["glob_cells"] == ores.counters["glob_cells"]
+    c = list(res.cands_of_read(0))[0]
+    assert int(res.indels[c]) == 2 and int(res.pos[c]) == p
