@@ -234,7 +234,7 @@ __device__ __forceinline__ ExtRes lane_ksw_extend2_dyn(const DOpts& o, const uin
 #define LH_EXT_ROUNDS 6   // every round ends with the latency of its slowest DP (~0.2 ms): what is left after six goes to the wave kernel (tests also build with 2)
 #endif
 #define LH_EXT_JOB_BINS 1536
-struct ExtSt { int32_t w0, narrow, sc0, pad; };   // w0: chain | seed rank << 8 | regions so far << 16 | side << 24 | band try << 25 | (left side used the doubled band) << 26
+struct ExtSt { int32_t w0, narrow, sc0, w1; };   // w0: seed rank | side << 24 | band try << 25 | (left side used the doubled band) << 26; w1: chain | regions so far << 16 (a read in the rounds has fewer than 32,768 seeds)
 struct DExtJobs {
     int32_t hist[LH_EXT_JOB_BINS], cursor[LH_EXT_JOB_BINS];
     int32_t count[LH_EXT_ROUNDS + 2];    // jobs queued for round k (k = 1 ..)
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) k_extj_count(const int32_t* __restrict__ 
     __syncthreads();
     for (int b = threadIdx.x; b < LH_EXT_JOB_BINS; b += 256) if (hist[b]) atomicAdd(&jb->hist[b], hist[b]);
 }
-__global__ void __launch_bounds__(256) k_extj_offsets(DExtJobs* __restrict__ jb, int round) {   // exclusive scan of the histogram; clears it for the next round
+__global__ void __launch_bounds__(256) k_extj_offsets(DExtJobs* __restrict__ jb, int round, int reuse) {   // exclusive scan of the histogram; clears it for the next round.  reuse >= 0 (the long queue alternates between two slots): slot `reuse` collects the next round's jobs, this round's slice counter starts at 0
     __shared__ int32_t part[256];
     const int t = threadIdx.x, per = LH_EXT_JOB_BINS / 256;
     int loc[per], s = 0;
@@ -281,7 +281,10 @@ __global__ void __launch_bounds__(256) k_extj_offsets(DExtJobs* __restrict__ jb,
     const int excl = part[t] - s;
     for (int u = 0; u < per; ++u) { const int b = t * per + u, c = jb->hist[b]; if (c) atomicAdd(&jb->kinds[3 * round + (b < 960 ? 0 : b < 1216 ? 1 : 2)], c); }
     for (int u = 0; u < per; ++u) { jb->cursor[t * per + u] = excl + loc[u]; jb->hist[t * per + u] = 0; }
-    if (t == 255) { jb->range[2 * round] = 0; jb->range[2 * round + 1] = part[255]; }
+    if (t == 255) {
+        jb->range[2 * round] = 0; jb->range[2 * round + 1] = part[255];
+        if (reuse >= 0) { jb->count[reuse] = 0; jb->next[round] = 0; }
+    }
 }
 __global__ void __launch_bounds__(256) k_extj_scatter(const int32_t* __restrict__ n_jobs, const int32_t* __restrict__ key, const int32_t* __restrict__ list,
                                                        DExtJobs* __restrict__ jb, int32_t* __restrict__ order) {
@@ -337,7 +340,7 @@ __device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, con
         a.rb = a.re = 0; a.qb = a.qe = 0; a.rid = 0; a.score = a.truesc = -1; a.sub = a.csub = 0; a.w = o.w; a.seedcov = 0; a.secondary = 0; a.seedlen0 = 0; a.n_comp = 0; a.is_alt = 0; a.frac_rep = 0;
         if (DP) {
             const ExtSt st = est[r];
-            ci = st.w0 & 0xff; k = (st.w0 >> 8) & 0xff; n_av = (st.w0 >> 16) & 0xff; side = (st.w0 >> 24) & 1; tri = (st.w0 >> 25) & 1; aw0 = o.w << ((st.w0 >> 26) & 1);
+            k = st.w0 & 0xffff; ci = st.w1 & 0xffff; n_av = (st.w1 >> 16) & 0xffff; side = (st.w0 >> 24) & 1; tri = (st.w0 >> 25) & 1; aw0 = o.w << ((st.w0 >> 26) & 1);
             narrow = st.narrow; sc0 = st.sc0;
             a = av[n_av];
             resume = true;
@@ -494,7 +497,7 @@ __device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, con
         if (!out) n_regs[r] = n_av;
         else if (out == 1) {
             ExtSt st;
-            st.w0 = ci | k << 8 | n_av << 16 | side << 24 | tri << 25 | (aw0 != o.w ? 1 : 0) << 26; st.narrow = narrow; st.sc0 = sc0; st.pad = 0;
+            st.w0 = k | side << 24 | tri << 25 | (aw0 != o.w ? 1 : 0) << 26; st.narrow = narrow; st.sc0 = sc0; st.w1 = ci | n_av << 16;
             est[r] = st;
             av[n_av] = a;
         } else cells = 0;   // the read is redone from scratch: its cells are counted there
@@ -548,5 +551,114 @@ __global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int3
         u64 tot = (u64)(uint32_t)wave_sum_i32((int)(lo >> 16)) << 16;
         tot += (u64)(uint32_t)wave_sum_i32((int)(lo & 0xffff));
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->ext_cells, tot);
+    }
+}
+
+
+// ---- THE LONG QUEUE (new in r04): the reads the wave kernel chained — many seeds, many chains: reads on the copies of a repeat family, tens to
+// hundreds of regions each — through rounds as well.  mem_chain2aln is sequential per read (a seed is skipped when an earlier region of the read
+// contains it), so such a read needs one round per ksw_extend2 call: a hundred and more.  The wave-per-read kernel runs those calls one
+// after the other with a wave-wide DP of ~100 lane-instructions per cell; in the rounds the calls of 64 different reads run side by side at
+// ~25.  k_ext_prep does per chain what k_extend does before it extends (the reference window, the order of the seeds) — one LANE per chain: a
+// repeat read's chains have one or two seeds —, k_ext_round0 runs every read up to its first call, then rounds follow until few jobs are
+// left (the host reads the count every few rounds); the reads still in the queue then, and the ones ext_control hands over, are extended
+// from scratch by k_extend.  Few listed reads (unique sequence: 0.2 % of the reads): all of them to k_extend, as before.
+#ifndef LH_EXT_PREP_MAXN
+#define LH_EXT_PREP_MAXN 64   // a chain with more seeds (low-complexity sequence) is prepared and extended by the wave kernel
+#endif
+__global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, const int32_t* __restrict__ list, const int32_t* __restrict__ range, int min_long, ExtArgs A,
+                                                  int32_t* __restrict__ srt_w, i64* __restrict__ rmax_w, int32_t* __restrict__ long_list, int32_t* __restrict__ long_count,
+                                                  int32_t* __restrict__ fb_list, int32_t* __restrict__ fb_count, DCounters* __restrict__ ctr) {
+    const int lane = LANE();
+    const int first = range[0], last = range[1];
+    if (last - first < min_long) {
+        for (int i = first + (int)blockIdx.x * 64 + lane; i < last; i += (int)gridDim.x * 64) fb_list[i - first] = list[i];
+        if (blockIdx.x == 0 && lane == 0) *fb_count = last - first;
+        return;
+    }
+    const i64 l_pac = ix.l_pac;
+    unsigned win = 0, nchs = 0;   // (< 2^32 window bases per lane)
+    for (int it = first + (int)blockIdx.x; it < last; it += (int)gridDim.x) {
+        const int r = list[it];
+        const i64 base = A.seed_off[r];
+        const int S = (int)(A.seed_off[r + 1] - base);
+        const int nch = A.n_chains[r];
+        int l_query = (int)(A.seq_off[r + 1] - A.seq_off[r]);
+        if (l_query > LH_MAXLEN) l_query = 0;
+        int big = 0;
+        for (int ci = lane; ci < nch; ci += 64) big |= A.chains[base + ci].n > LH_EXT_PREP_MAXN;
+        if (S >= 32768 || __any(big)) {
+            if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = r;
+            continue;
+        }
+        for (int ci = lane; ci < nch; ci += 64) {
+            const DChain c = A.chains[base + ci];
+            const int n = c.n;
+            if (n == 0) continue;
+            const DSeed* sd = A.cseeds + base + c.seed_start;
+            int32_t* srt = srt_w + base + c.seed_start;
+            int32_t* done = A.sdone + base + c.seed_start;
+            i64 r0 = l_pac << 1, r1 = 0;   // max possible span
+            for (int i = 0; i < n; ++i) {
+                const DSeed t = sd[i];
+                const i64 b = t.rbeg - (t.qbeg + dev_cal_max_gap(o, t.qbeg));
+                const i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_cal_max_gap(o, l_query - t.qbeg - t.len));
+                r0 = r0 < b ? r0 : b;
+                r1 = r1 > e ? r1 : e;
+            }
+            i64 rmax0 = r0 > 0 ? r0 : 0, rmax1 = r1 < l_pac << 1 ? r1 : l_pac << 1;
+            const DSeed s0 = sd[0];
+            if (rmax0 < l_pac && l_pac < rmax1) {   // crossing the forward-reverse boundary; then choose one side
+                if (s0.rbeg < l_pac) rmax1 = l_pac;
+                else rmax0 = l_pac;
+            }
+            dev_fetch_clamp(ix, &rmax0, s0.rbeg, &rmax1);
+            win += (unsigned)(rmax1 - rmax0);
+            rmax_w[2 * (base + ci)] = rmax0; rmax_w[2 * (base + ci) + 1] = rmax1;
+            for (int i = 0; i < n; ++i) {   // by seed score (= len) then index, ascending
+                const DSeed t = sd[i];
+                int rank = 0;
+                for (int u = 0; u < n; ++u) { const DSeed x = sd[u]; rank += (x.len < t.len) || (x.len == t.len && u < i); }
+                srt[rank] = i;
+                done[i] = 1;
+            }
+        }
+        if (lane == 0) { nchs += (unsigned)nch; long_list[atomicAdd(long_count, 1)] = r; }
+    }
+    if (ctr) {
+        u64 wtot = (u64)(uint32_t)wave_sum_i32((int)(win >> 16)) << 16;
+        wtot += (u64)(uint32_t)wave_sum_i32((int)(win & 0xffff));
+        const int ctot = wave_sum_i32((int)nchs);
+        if (lane == 0 && (wtot || ctot)) { atomicAdd(&LH_CTR(ctr)->win_bases, wtot); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)ctot); }
+    }
+}
+// every listed read up to its first ksw_extend2 call that needs a DP (one lane per read)
+__global__ void __launch_bounds__(64) k_ext_round0(DIndex ix, DOpts o, const int32_t* __restrict__ list, const int32_t* __restrict__ count, ExtArgs A,
+                                                    int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key,
+                                                    int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list, DCounters* __restrict__ ctr) {
+    const int lane = LANE();
+    const int n = *count;
+    u64 cells = 0;
+    for (int g0 = (int)blockIdx.x * 64; g0 < n; g0 += (int)gridDim.x * 64) {
+        const int g = g0 + lane;
+        const int r = g < n ? list[g] : -1;
+        int out = 0, key = 0;
+        if (r >= 0) out = ext_control<false>(ix, o, A, r, nullptr, lane, &key, &cells);
+        ext_append(out, r, key, lane, next_count, next_list, next_key, defer_count, defer_list);
+    }
+    if (ctr) {
+        uint32_t lo = (uint32_t)cells;
+        u64 tot = (u64)(uint32_t)wave_sum_i32((int)(lo >> 16)) << 16;
+        tot += (u64)(uint32_t)wave_sum_i32((int)(lo & 0xffff));
+        if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->ext_cells, tot);
+    }
+}
+// the reads still queued when the rounds stop: to the list of the wave kernel
+__global__ void __launch_bounds__(64) k_ext_flush(const int32_t* __restrict__ count, const int32_t* __restrict__ list, int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list) {
+    const int lane = LANE();
+    const int n = *count;
+    for (int g0 = (int)blockIdx.x * 64; g0 < n; g0 += (int)gridDim.x * 64) {
+        const int g = g0 + lane;
+        ext_append(g < n ? 2 : 0, g < n ? list[g] : -1, 0, lane, nullptr, nullptr, nullptr, defer_count, defer_list);
     }
 }

@@ -451,6 +451,7 @@ __device__ __forceinline__ DiagScan dev_diag_scan(const DIndex& ix, const DOpts&
 }
 // one 64-bit value into page-locked host memory the device can write: a read-back that does not queue behind the bulk transfers of the copy engines
 __global__ void k_peek_i64(const i64* __restrict__ src, i64* __restrict__ dst_host) { *dst_host = *src; }
+__global__ void k_peek_i32(const int32_t* __restrict__ src, i64* __restrict__ dst_host) { dst_host[0] = *src; }
 __global__ void k_peek_i64_i32(const i64* __restrict__ src, const int32_t* __restrict__ src2, i64* __restrict__ dst_host) { dst_host[0] = *src; dst_host[1] = *src2; }
 // the batch's reads as a 4-bit stream (base i of the batch buffer at symbol i; non-bases = 4), two words of padding in front
 __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ seq, i64 n_bases, uint32_t* __restrict__ q4) {
