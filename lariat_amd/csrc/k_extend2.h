@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) k_extj_offsets(DExtJobs* __restrict__ jb,
     for (int u = 0; u < per; ++u) { jb->cursor[t * per + u] = excl + loc[u]; jb->hist[t * per + u] = 0; }
     if (t == 255) {
         jb->range[2 * round] = 0; jb->range[2 * round + 1] = part[255];
-        if (reuse >= 0) { jb->count[reuse] = 0; jb->next[round] = 0; }
+        if (reuse >= 0) { jb->count[reuse] = 0; jb->next[round] = 0; jb->count[3] = 0; }   // (count[3]: the calls listed for k_ext_wround, consumed by now)
     }
 }
 __global__ void __launch_bounds__(256) k_extj_scatter(const int32_t* __restrict__ n_jobs, const int32_t* __restrict__ key, const int32_t* __restrict__ list,
@@ -313,14 +313,21 @@ __global__ void __launch_bounds__(256) k_extj_scatter(const int32_t* __restrict_
 struct ExtArgs {   // what a read's control flow reads and writes
     const uint8_t* seq; const uint32_t* q4; const i64* seq_off; const i64* seed_off; const DChain* chains; const DSeed* cseeds; const int32_t* n_chains;
     const int32_t* sorder; int32_t* sdone; const i64* chain_rmax; const i64* reg_off; DReg* regs; int32_t* n_regs; ExtSt* est;
+    // the long queue's units (one chain of a read each, indexed like the chain: seed_off[read] + chain): owner read, saved state, regions found; per read: "extend me from scratch"
+    const int32_t* u_read; ExtSt* est_u; int32_t* nreg_u; int32_t* rflag;
 };
 // mem_chain2aln for read r, from the start (DP = false) or from its queued ksw_extend2 call (DP = true: the call is made here, in
 // the lane's LDS window ehl), up to the next call that needs a DP.  Returns 0: the read is finished (n_regs written); 1: a call was
 // queued (state saved, *key = its bin); 2: the read is left to the wave-per-read kernel (a live-interval window outgrew its 64 columns,
 // or — first seed of the read only, as before — a long side whose diagonal loses LH_NARROW_MAX_LOSS or more, e.g. behind an indel:
 // one full-band DP of that size keeps a lane busy for most of a millisecond).
-template <bool DP>
-__device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, const ExtArgs& A, const int r, uint32_t* ehl, const int lane, int* key_out, u64* cells_out) {
+// UNIT (the long queue, below): id names ONE chain of a read — the program runs that chain alone, its regions go to the chain's own slots
+// (region slot = seed slot: a chain yields at most one region per seed), and the test against earlier regions only sees the chain's own.
+// WAVE (UNIT only; k_ext_wround): all 64 lanes run the unit's program in step, and its pending call — one whose live interval outgrew a lane's
+// 64-column window — is made by the whole wave (wave_ksw_extend2, k_extend.h: ehl = the read's bytes in LDS); the unit then goes back to the lanes' queue.
+template <bool DP, bool UNIT = false, bool WAVE = false>
+__device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, const ExtArgs& A, const int id, uint32_t* ehl, const int lane, int* key_out, u64* cells_out) {
+    const int r = UNIT ? A.u_read[id] : id;
     const uint8_t* seq = A.seq; const uint32_t* q4 = A.q4; const i64* seq_off = A.seq_off; const i64* seed_off = A.seed_off; const DChain* chains = A.chains;
     const DSeed* cseeds = A.cseeds; const int32_t* n_chains = A.n_chains; const int32_t* sorder = A.sorder; int32_t* sdone = A.sdone; const i64* chain_rmax = A.chain_rmax;
     const i64* reg_off = A.reg_off; DReg* regs = A.regs; int32_t* n_regs = A.n_regs; ExtSt* est = A.est;
@@ -332,15 +339,16 @@ __device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, con
         if (l_query > LH_MAXLEN) l_query = 0;
         const uint8_t* q = seq + off;
         const i64 base = seed_off[r];
-        DReg* av = regs + reg_off[r];
-        const int nch = n_chains[r];
-        int ci = 0, k = 0, n_av = 0, side = 0, tri = 0, narrow = 0, sc0 = 0, aw0 = o.w;
+        const int ci0 = UNIT ? (int)(id - base) : 0;
+        DReg* av = regs + reg_off[r] + (UNIT ? chains[id].seed_start : 0);
+        const int nch = UNIT ? ci0 + 1 : n_chains[r];
+        int ci = ci0, k = 0, n_av = 0, side = 0, tri = 0, narrow = 0, sc0 = 0, aw0 = o.w;
         bool resume = false;
         DReg a;
         a.rb = a.re = 0; a.qb = a.qe = 0; a.rid = 0; a.score = a.truesc = -1; a.sub = a.csub = 0; a.w = o.w; a.seedcov = 0; a.secondary = 0; a.seedlen0 = 0; a.n_comp = 0; a.is_alt = 0; a.frac_rep = 0;
         if (DP) {
-            const ExtSt st = est[r];
-            k = st.w0 & 0xffff; ci = st.w1 & 0xffff; n_av = (st.w1 >> 16) & 0xffff; side = (st.w0 >> 24) & 1; tri = (st.w0 >> 25) & 1; aw0 = o.w << ((st.w0 >> 26) & 1);
+            const ExtSt st = UNIT ? A.est_u[id] : est[r];
+            k = st.w0 & 0xffff; ci = UNIT ? ci0 : st.w1 & 0xffff; n_av = (st.w1 >> 16) & 0xffff; side = (st.w0 >> 24) & 1; tri = (st.w0 >> 25) & 1; aw0 = o.w << ((st.w0 >> 26) & 1);
             narrow = st.narrow; sc0 = st.sc0;
             a = av[n_av];
             resume = true;
@@ -389,7 +397,7 @@ __device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, con
                     a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid;
                     aw0 = o.w; side = 0;
                 }
-                const bool first_seed = !DP && ci == 0 && n_av == 0 && k == n - 1;
+                const bool first_seed = !DP && !UNIT && ci == 0 && n_av == 0 && k == n - 1;
                 int aw1 = o.w;
                 while (side < 2 && !out) {   // 0 = left (reversed query prefix vs reversed reference prefix), 1 = right
                     int qoff, qstep, qlen, tstep, tlen, bonus, h0;
@@ -451,7 +459,15 @@ __device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, con
                             const int dyn = !circ && qlen >= 64;                       // full band, query side longer than the LDS window: live-interval window
                             LaneTgt tg;
                             tg.init(ix, tc0, tstep);
-                            if (dyn) {
+                            if (WAVE) {
+                                const uint8_t* ql = (const uint8_t*)ehl;
+                                const int band = narrow && narrow < aw ? narrow : aw;
+                                u64 wc = 0;
+                                if (qlen <= 64) e = wave_ksw_extend2<1>(ix, o, ql, qoff, qstep, qlen, tc0, tstep, tlen, band, bonus, o.zdrop, h0, lane, &wc);
+                                else if (qlen <= 128) e = wave_ksw_extend2<2>(ix, o, ql, qoff, qstep, qlen, tc0, tstep, tlen, band, bonus, o.zdrop, h0, lane, &wc);
+                                else e = wave_ksw_extend2<4>(ix, o, ql, qoff, qstep, qlen, tc0, tstep, tlen, band, bonus, o.zdrop, h0, lane, &wc);
+                                cells += wc;
+                            } else if (dyn) {
                                 int over = 0;
                                 e = lane_ksw_extend2_dyn(o, q, ehl, lane, qoff, qstep, qlen, tg, tlen, aw, bonus, o.zdrop, h0, &cells, &over);
                                 if (over) { out = 2; break; }
@@ -494,11 +510,12 @@ __device__ __forceinline__ int ext_control(const DIndex& ix, const DOpts& o, con
             }
             if (!out) ++ci;
         }
-        if (!out) n_regs[r] = n_av;
+        // (UNIT, verdict 2 = the pending call's live interval outgrew the lane's window: the saved state still describes that call; the unit is listed for k_ext_wround)
+        if (!out) { if (UNIT) A.nreg_u[id] = n_av; else n_regs[r] = n_av; }
         else if (out == 1) {
             ExtSt st;
             st.w0 = k | side << 24 | tri << 25 | (aw0 != o.w ? 1 : 0) << 26; st.narrow = narrow; st.sc0 = sc0; st.w1 = ci | n_av << 16;
-            est[r] = st;
+            if (UNIT) A.est_u[id] = st; else est[r] = st;
             av[n_av] = a;
         } else cells = 0;   // the read is redone from scratch: its cells are counted there
     }
@@ -528,6 +545,7 @@ __device__ __forceinline__ void ext_append(int out, int r, int key, int lane, in
 // A read that queues a call appends itself to next_list (its bin in next_key); one that is left to the wave kernel, or queues a call
 // in the last round (next_* = the deferred list), appends itself to the deferred list.  (Round 0 — every read up to its first call —
 // runs at the end of k_chain_lane, k_chain.h.)
+template <bool UNIT>
 __global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int32_t* __restrict__ range, int32_t* __restrict__ slice_ctr, const int32_t* __restrict__ order, ExtArgs A,
                                                    int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key,
                                                    int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list, DCounters* __restrict__ ctr) {
@@ -543,7 +561,7 @@ __global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int3
         const int g = first + blk * 64 + lane;
         const int r = g < last ? order[g] : -1;
         int out = 0, key = 0;
-        if (r >= 0) out = ext_control<true>(ix, o, A, r, ehl, lane, &key, &cells);
+        if (r >= 0) out = ext_control<true, UNIT>(ix, o, A, r, ehl, lane, &key, &cells);
         ext_append(out, r, key, lane, next_count, next_list, next_key, defer_count, defer_list);
     }
     if (ctr) {
@@ -556,19 +574,27 @@ __global__ void __launch_bounds__(64) k_ext_round(DIndex ix, DOpts o, const int3
 
 
 // ---- THE LONG QUEUE (new in r04): the reads the wave kernel chained — many seeds, many chains: reads on the copies of a repeat family, tens to
-// hundreds of regions each — through rounds as well.  mem_chain2aln is sequential per read (a seed is skipped when an earlier region of the read
-// contains it), so such a read needs one round per ksw_extend2 call: a hundred and more.  The wave-per-read kernel runs those calls one
-// after the other with a wave-wide DP of ~100 lane-instructions per cell; in the rounds the calls of 64 different reads run side by side at
-// ~25.  k_ext_prep does per chain what k_extend does before it extends (the reference window, the order of the seeds) — one LANE per chain: a
-// repeat read's chains have one or two seeds —, k_ext_round0 runs every read up to its first call, then rounds follow until few jobs are
-// left (the host reads the count every few rounds); the reads still in the queue then, and the ones ext_control hands over, are extended
-// from scratch by k_extend.  Few listed reads (unique sequence: 0.2 % of the reads): all of them to k_extend, as before.
+// hundreds of regions each — through rounds as well.  The wave-per-read kernel runs a read's ksw_extend2 calls one after the other with a
+// wave-wide DP of ~100 lane-instructions per cell; in the rounds the calls of 64 different reads run side by side at ~25.  But
+// mem_chain2aln is sequential per read — a seed is skipped when an earlier region of the read contains it — and a read with a hundred
+// regions would need two hundred rounds (measured: 150 rounds of 60,000 jobs, a quarter of the chip, slower than the wave kernel).  That
+// dependence is almost never there ACROSS chains: a region found at one copy of the repeat does not contain a seed at another copy.  So the
+// unit of work is the CHAIN (ext_control<.., UNIT>): every chain of a read runs as if it were alone, its regions go to its own slots, and
+// the test against earlier regions sees only the chain's own.  Afterwards k_ext_merge checks, per read, what the units assumed — no
+// extended seed of a chain is contained in a region of an EARLIER chain (mem_chain2aln's own test, same arithmetic) — and moves the regions
+// together in chain order: the result is then exactly what the sequential program produces (an extended seed's DP depends on the seed
+// alone; a seed skipped inside its chain is skipped in the sequential program too, which sees those regions and more).  A read that fails
+// the check, or holds a DP a lane cannot (ext_control's verdict 2), or is still queued when the rounds stop, is extended from scratch by
+// k_extend, as are all listed reads when they are few (unique sequence: 0.2 % of the reads) and reads with a chain of more than
+// LH_EXT_PREP_MAXN seeds (low-complexity sequence).  k_ext_prep does per chain what k_extend does before it extends (the reference
+// window, the order of the seeds), one LANE per chain, and lists the units; k_ext_round0 runs every unit up to its first DP.
 #ifndef LH_EXT_PREP_MAXN
-#define LH_EXT_PREP_MAXN 64   // a chain with more seeds (low-complexity sequence) is prepared and extended by the wave kernel
+#define LH_EXT_PREP_MAXN 64
 #endif
 __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, const int32_t* __restrict__ list, const int32_t* __restrict__ range, int min_long, ExtArgs A,
-                                                  int32_t* __restrict__ srt_w, i64* __restrict__ rmax_w, int32_t* __restrict__ long_list, int32_t* __restrict__ long_count,
-                                                  int32_t* __restrict__ fb_list, int32_t* __restrict__ fb_count, DCounters* __restrict__ ctr) {
+                                                  int32_t* __restrict__ srt_w, i64* __restrict__ rmax_w, int32_t* __restrict__ u_read_w, int32_t* __restrict__ long_list,
+                                                  int32_t* __restrict__ long_count, int32_t* __restrict__ fb_list, int32_t* __restrict__ fb_count, int32_t* __restrict__ ulist,
+                                                  int32_t* __restrict__ ucount, DCounters* __restrict__ ctr) {
     const int lane = LANE();
     const int first = range[0], last = range[1];
     if (last - first < min_long) {
@@ -591,39 +617,53 @@ __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, const int32
             if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = r;
             continue;
         }
-        for (int ci = lane; ci < nch; ci += 64) {
-            const DChain c = A.chains[base + ci];
-            const int n = c.n;
-            if (n == 0) continue;
-            const DSeed* sd = A.cseeds + base + c.seed_start;
-            int32_t* srt = srt_w + base + c.seed_start;
-            int32_t* done = A.sdone + base + c.seed_start;
-            i64 r0 = l_pac << 1, r1 = 0;   // max possible span
-            for (int i = 0; i < n; ++i) {
-                const DSeed t = sd[i];
-                const i64 b = t.rbeg - (t.qbeg + dev_cal_max_gap(o, t.qbeg));
-                const i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_cal_max_gap(o, l_query - t.qbeg - t.len));
-                r0 = r0 < b ? r0 : b;
-                r1 = r1 > e ? r1 : e;
+        for (int cb = 0; cb < nch; cb += 64) {
+            const int ci = cb + lane;
+            int n = 0;
+            if (ci < nch) {
+                const DChain c = A.chains[base + ci];
+                n = c.n;
+                u_read_w[base + ci] = r;
+                A.nreg_u[base + ci] = 0;
+                if (n > 0) {
+                    const DSeed* sd = A.cseeds + base + c.seed_start;
+                    int32_t* srt = srt_w + base + c.seed_start;
+                    int32_t* done = A.sdone + base + c.seed_start;
+                    i64 r0 = l_pac << 1, r1 = 0;   // max possible span
+                    for (int i = 0; i < n; ++i) {
+                        const DSeed t = sd[i];
+                        const i64 b = t.rbeg - (t.qbeg + dev_cal_max_gap(o, t.qbeg));
+                        const i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_cal_max_gap(o, l_query - t.qbeg - t.len));
+                        r0 = r0 < b ? r0 : b;
+                        r1 = r1 > e ? r1 : e;
+                    }
+                    i64 rmax0 = r0 > 0 ? r0 : 0, rmax1 = r1 < l_pac << 1 ? r1 : l_pac << 1;
+                    const DSeed s0 = sd[0];
+                    if (rmax0 < l_pac && l_pac < rmax1) {   // crossing the forward-reverse boundary; then choose one side
+                        if (s0.rbeg < l_pac) rmax1 = l_pac;
+                        else rmax0 = l_pac;
+                    }
+                    dev_fetch_clamp(ix, &rmax0, s0.rbeg, &rmax1);
+                    win += (unsigned)(rmax1 - rmax0);
+                    rmax_w[2 * (base + ci)] = rmax0; rmax_w[2 * (base + ci) + 1] = rmax1;
+                    for (int i = 0; i < n; ++i) {   // by seed score (= len) then index, ascending
+                        const DSeed t = sd[i];
+                        int rank = 0;
+                        for (int u = 0; u < n; ++u) { const DSeed x = sd[u]; rank += (x.len < t.len) || (x.len == t.len && u < i); }
+                        srt[rank] = i;
+                        done[i] = 1;
+                    }
+                }
             }
-            i64 rmax0 = r0 > 0 ? r0 : 0, rmax1 = r1 < l_pac << 1 ? r1 : l_pac << 1;
-            const DSeed s0 = sd[0];
-            if (rmax0 < l_pac && l_pac < rmax1) {   // crossing the forward-reverse boundary; then choose one side
-                if (s0.rbeg < l_pac) rmax1 = l_pac;
-                else rmax0 = l_pac;
-            }
-            dev_fetch_clamp(ix, &rmax0, s0.rbeg, &rmax1);
-            win += (unsigned)(rmax1 - rmax0);
-            rmax_w[2 * (base + ci)] = rmax0; rmax_w[2 * (base + ci) + 1] = rmax1;
-            for (int i = 0; i < n; ++i) {   // by seed score (= len) then index, ascending
-                const DSeed t = sd[i];
-                int rank = 0;
-                for (int u = 0; u < n; ++u) { const DSeed x = sd[u]; rank += (x.len < t.len) || (x.len == t.len && u < i); }
-                srt[rank] = i;
-                done[i] = 1;
+            const u64 um = __ballot(n > 0);   // the chunk's units: one reservation per wave
+            if (um) {
+                int bp = 0;
+                if (lane == 0) bp = atomicAdd(ucount, (int)__popcll(um));
+                bp = wave_readlane(bp, 0);
+                if (n > 0) ulist[bp + lanes_below(um, lane)] = (int)(base + ci);
             }
         }
-        if (lane == 0) { nchs += (unsigned)nch; long_list[atomicAdd(long_count, 1)] = r; }
+        if (lane == 0) { nchs += (unsigned)nch; A.rflag[r] = 0; long_list[atomicAdd(long_count, 1)] = r; }
     }
     if (ctr) {
         u64 wtot = (u64)(uint32_t)wave_sum_i32((int)(win >> 16)) << 16;
@@ -632,19 +672,18 @@ __global__ void __launch_bounds__(64) k_ext_prep(DIndex ix, DOpts o, const int32
         if (lane == 0 && (wtot || ctot)) { atomicAdd(&LH_CTR(ctr)->win_bases, wtot); atomicAdd(&LH_CTR(ctr)->n_chain_ext, (u64)ctot); }
     }
 }
-// every listed read up to its first ksw_extend2 call that needs a DP (one lane per read)
+// every listed unit up to its first ksw_extend2 call that needs a DP (one lane per unit)
 __global__ void __launch_bounds__(64) k_ext_round0(DIndex ix, DOpts o, const int32_t* __restrict__ list, const int32_t* __restrict__ count, ExtArgs A,
-                                                    int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key,
-                                                    int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list, DCounters* __restrict__ ctr) {
+                                                    int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key, DCounters* __restrict__ ctr) {
     const int lane = LANE();
     const int n = *count;
     u64 cells = 0;
     for (int g0 = (int)blockIdx.x * 64; g0 < n; g0 += (int)gridDim.x * 64) {
         const int g = g0 + lane;
-        const int r = g < n ? list[g] : -1;
+        const int id = g < n ? list[g] : -1;
         int out = 0, key = 0;
-        if (r >= 0) out = ext_control<false>(ix, o, A, r, nullptr, lane, &key, &cells);
-        ext_append(out, r, key, lane, next_count, next_list, next_key, defer_count, defer_list);
+        if (id >= 0) out = ext_control<false, true>(ix, o, A, id, nullptr, lane, &key, &cells);
+        ext_append(out, id, key, lane, next_count, next_list, next_key, nullptr, nullptr);   // (a unit has no verdict 2: ext_control flags its read instead)
     }
     if (ctr) {
         uint32_t lo = (uint32_t)cells;
@@ -653,12 +692,112 @@ __global__ void __launch_bounds__(64) k_ext_round0(DIndex ix, DOpts o, const int
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->ext_cells, tot);
     }
 }
-// the reads still queued when the rounds stop: to the list of the wave kernel
-__global__ void __launch_bounds__(64) k_ext_flush(const int32_t* __restrict__ count, const int32_t* __restrict__ list, int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list) {
+// the calls a lane could not hold, one WAVE per unit; the unit's next call goes back to the lanes' queue
+__global__ void __launch_bounds__(64) k_ext_wround(DIndex ix, DOpts o, const int32_t* __restrict__ list, const int32_t* __restrict__ count, ExtArgs A,
+                                                    int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key, DCounters* __restrict__ ctr) {
+    __shared__ uint8_t q[LH_MAXLEN + 6];
     const int lane = LANE();
     const int n = *count;
-    for (int g0 = (int)blockIdx.x * 64; g0 < n; g0 += (int)gridDim.x * 64) {
-        const int g = g0 + lane;
-        ext_append(g < n ? 2 : 0, g < n ? list[g] : -1, 0, lane, nullptr, nullptr, nullptr, defer_count, defer_list);
+    u64 cells = 0;
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        const int id = list[it];
+        const int r = A.u_read[id];
+        const i64 off = A.seq_off[r];
+        int l_query = (int)(A.seq_off[r + 1] - off);
+        if (l_query > LH_MAXLEN) l_query = 0;
+        WAVE_SYNC();
+        for (int i = lane; i < l_query; i += 64) q[i] = A.seq[off + i];
+        WAVE_SYNC();
+        int key = 0;
+        const int out = ext_control<true, true, true>(ix, o, A, id, (uint32_t*)q, lane, &key, &cells);
+        ext_append(lane == 0 ? out : 0, id, key, lane, next_count, next_list, next_key, nullptr, nullptr);
+    }
+    if (lane == 0 && ctr && cells) atomicAdd(&LH_CTR(ctr)->ext_cells, cells);
+}
+// the units still queued when the rounds stop: their reads are extended from scratch
+__global__ void __launch_bounds__(256) k_ext_flush(const int32_t* __restrict__ count, const int32_t* __restrict__ list, ExtArgs A) {
+    const int n = *count;
+    for (int g = (int)(blockIdx.x * blockDim.x + threadIdx.x); g < n; g += (int)(gridDim.x * blockDim.x)) atomicOr(&A.rflag[A.u_read[list[g]]], 1);
+}
+// per read of the long list: the check of what its units assumed, then the regions moved together in chain order (or the read listed for k_extend)
+#define LH_EXT_MERGE_CAP 512
+struct ExtMReg { i64 rb, re; int32_t qb, qe, seedlen0, w; };
+__global__ void __launch_bounds__(64) k_ext_merge(DOpts o, const int32_t* __restrict__ long_list, const int32_t* __restrict__ long_count, ExtArgs A, DReg* __restrict__ tmp,
+                                                   int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list, int32_t* __restrict__ why) {   // why[0..2] (diagnostics): reads handed on because a unit flagged them / too many regions / the check failed
+    __shared__ ExtMReg P[LH_EXT_MERGE_CAP];
+    const int lane = LANE();
+    const int n_items = *long_count;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int r = long_list[it];
+        const i64 base = A.seed_off[r];
+        const int nch = A.n_chains[r];
+        int l_query = (int)(A.seq_off[r + 1] - A.seq_off[r]);
+        if (l_query > LH_MAXLEN) l_query = 0;
+        DReg* const av = A.regs + A.reg_off[r];
+        DReg* const tv = tmp + A.reg_off[r];
+        int bad = A.rflag[r] != 0, reason = 0;
+        int total = 0;
+        WAVE_SYNC();
+        if (!bad) {
+            for (int cb = 0; cb < nch; cb += 64) {   // the regions of every chain, in chain order, to LDS (what the test reads) and to the scratch (whole records)
+                const int ci = cb + lane;
+                int m = 0, ss = 0;
+                if (ci < nch) { m = A.nreg_u[base + ci]; ss = A.chains[base + ci].seed_start; }
+                const int incl = wave_scan_add_i32(m);
+                const int off = total + incl - m;
+                total += wave_readlane(incl, 63);
+                if (total > LH_EXT_MERGE_CAP) { bad = 1; reason = 1; break; }
+                for (int j = 0; j < m; ++j) {
+                    const DReg p = av[ss + j];
+                    tv[off + j] = p;
+                    ExtMReg e;
+                    e.rb = p.rb; e.re = p.re; e.qb = p.qb; e.qe = p.qe; e.seedlen0 = p.seedlen0; e.w = p.w;
+                    P[off + j] = e;
+                }
+            }
+        }
+        WAVE_SYNC();
+        if (!bad) {
+            int hit = 0, before = 0;
+            for (int cb = 0; cb < nch; cb += 64) {
+                const int ci = cb + lane;
+                int m = 0;
+                if (ci < nch) m = A.nreg_u[base + ci];
+                const int incl = wave_scan_add_i32(m);
+                const int off = before + incl - m;   // the regions of the earlier chains: P[0, off)
+                before += wave_readlane(incl, 63);
+                if (ci < nch && m > 0 && off > 0) {
+                    const DChain c = A.chains[base + ci];
+                    const DSeed* sd = A.cseeds + base + c.seed_start;
+                    const int32_t* done = A.sdone + base + c.seed_start;
+                    for (int i = 0; i < c.n && !hit; ++i) {
+                        if (!done[i]) continue;   // skipped inside its own chain: skipped by the sequential program as well
+                        const DSeed s = sd[i];
+                        for (int j = 0; j < off; ++j) {
+                            const ExtMReg p = P[j];
+                            if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;   // not fully contained
+                            if (s.len - p.seedlen0 > .1 * l_query) continue;
+                            int qd = s.qbeg - p.qb; i64 rd = s.rbeg - p.rb;
+                            int max_gap = dev_cal_max_gap(o, qd < rd ? qd : (int)rd);
+                            int w = max_gap < p.w ? max_gap : p.w;
+                            if (qd - rd < w && rd - qd < w) { hit = 1; break; }
+                            qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+                            max_gap = dev_cal_max_gap(o, qd < rd ? qd : (int)rd);
+                            w = max_gap < p.w ? max_gap : p.w;
+                            if (qd - rd < w && rd - qd < w) { hit = 1; break; }
+                        }
+                    }
+                }
+            }
+            bad = __any(hit);   // (the sequential program would have looked at the chain's other seeds before deciding: the wave kernel does)
+            if (bad) reason = 2;
+        }
+        if (bad) {
+            if (lane == 0) { defer_list[atomicAdd(defer_count, 1)] = r; atomicAdd(&why[reason], 1); }
+            continue;
+        }
+        WAVE_SYNC();
+        for (int j = lane; j < total; j += 64) av[j] = tv[j];
+        if (lane == 0) A.n_regs[r] = total;
     }
 }
