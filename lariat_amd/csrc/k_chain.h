@@ -34,7 +34,11 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
     // a read's chain table, its two index arrays and its seeds live in LDS while they fit (reads on repeat families have dozens of chains and a
     // hundred seeds: every step of the loops below is a dependent access, ~1 us from HBM); larger reads use the HBM scratch as before
     __shared__ DChainTmp Cs[LH_CHAIN_LDS];
-    __shared__ int32_t ods[LH_CHAIN_LDS + 1], sts[LH_CHAIN_LDS + 1], nxs[LH_CHAIN_LDS], rids[LH_CHAIN_LDS];
+    __shared__ i64 okk[LH_CHAIN_LDS + 1];   // while the read's seeds are being chained: one key per chain, (pos << 16 | chain); afterwards the two index arrays
+    int32_t* const ods = (int32_t*)okk;
+    int32_t* const sts = ods + LH_CHAIN_LDS + 1;
+    __shared__ int32_t nxs[LH_CHAIN_LDS], rids[LH_CHAIN_LDS];
+    static_assert(LH_CHAIN_LDS < 512, "chain ids in 9 bits of the packed sort keys");
     __shared__ DSeed sds[LH_CHAIN_LDS];
     __shared__ int32_t sh_n;
     const int lane = LANE();
@@ -61,6 +65,71 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
         WAVE_SYNC();
     }
     int nch = 0;
+    if (in_lds) {
+        // (r04) BWA keeps the chains in a B-tree by position and asks it for the chain before the seed.  Here the chains' keys (pos << 16 | chain:
+        // chains of equal pos in the order they were made, as the tree holds them) sit in LDS in NO order and the chain before the seed is a
+        // maximum over them — one read and one reduction per seed instead of a binary search of dependent reads and a shifted insertion; the
+        // tree's traversal order, which mem_chain_flt starts from, is made once at the end, by counting.
+        for (int s = 0; s < S; ++s) {
+            const int rid = rids[s];
+            if (rid < 0) continue;   // bridging contigs / the forward-reverse boundary
+            const DSeed p = sds[s];
+            i64 bestk = -1;
+            for (int k = lane; k < nch; k += 64) { const i64 v = okk[k]; if ((v >> 16) <= p.rbeg && v > bestk) bestk = v; }
+            bestk = wave_max_i64(bestk);
+            int to_add = 1;
+            if (bestk >= 0) {
+                const int ci = (int)(bestk & 0xffff);
+                const DChainTmp c = Cs[ci];
+                WAVE_SYNC();   // every lane has its copy before lane 0 updates the chain
+                const i64 qend = c.last_qbeg + c.last_len, rend = c.last_rbeg + c.last_len;   // test_and_merge
+                int res = 0;   // 0: new chain, 1: contained, 2: appended
+                if (rid != c.rid) res = 0;
+                else if (p.qbeg >= c.first_qbeg && p.qbeg + p.len <= qend && p.rbeg >= c.pos && p.rbeg + p.len <= rend) res = 1;
+                else if ((c.last_rbeg < ix.l_pac || c.pos < ix.l_pac) && p.rbeg >= ix.l_pac) res = 0;
+                else {
+                    const i64 x = p.qbeg - c.last_qbeg, y = p.rbeg - c.last_rbeg;
+                    if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c.last_len < o.max_chain_gap && y - c.last_len < o.max_chain_gap) res = 2;
+                }
+                if (res == 2 && lane == 0) {
+                    nxs[c.tail] = s; nxs[s] = -1;
+                    Cs[ci].tail = s; Cs[ci].n = c.n + 1; Cs[ci].last_rbeg = p.rbeg; Cs[ci].last_qbeg = p.qbeg; Cs[ci].last_len = p.len;
+                }
+                to_add = (res == 0);
+            }
+            if (to_add) {
+                if (lane == 0) {
+                    okk[nch] = (i64)p.rbeg << 16 | (i64)nch;
+                    DChainTmp c;
+                    c.pos = p.rbeg; c.last_rbeg = p.rbeg; c.first_qbeg = p.qbeg; c.last_qbeg = p.qbeg; c.last_len = p.len; c.rid = rid;
+                    c.n = 1; c.head = s; c.tail = s; c.w = 0; c.kept = 0; c.first = -1; c.beg = 0; c.end = 0;
+                    Cs[nch] = c;
+                    nxs[s] = -1;
+                }
+                nch++;
+            }
+            WAVE_SYNC();
+        }
+        {   // od[] = the chains by (pos, order of creation)
+            constexpr int PER = (LH_CHAIN_LDS + 63) / 64;
+            int rk[PER];
+#pragma unroll
+            for (int t = 0; t < PER; ++t) {
+                const int k = t * 64 + lane;
+                rk[t] = -1;
+                if (k < nch) {
+                    const i64 v = okk[k];
+                    int c_ = 0;
+                    for (int u = 0; u < nch; ++u) c_ += okk[u] < v;
+                    rk[t] = c_;
+                }
+            }
+            WAVE_SYNC();
+#pragma unroll
+            for (int t = 0; t < PER; ++t) if (rk[t] >= 0) ods[rk[t]] = t * 64 + lane;
+            WAVE_SYNC();
+        }
+    } else
     for (int s = 0; s < S; ++s) {
         int rid = rid_[s];
         if (rid < 0) continue;   // bridging contigs / the forward-reverse boundary
@@ -147,7 +216,11 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
             st[n++] = id;
         }
         if (n > 0) {
-            dev_introsort(n, st, [&](int x, int y) { return C[x].w > C[y].w; }, o.wd);
+            if (in_lds) {   // the same sort on (weight << 9 | chain): what the comparisons see is the weight, what moves is one word — no second, dependent read per comparison
+                for (int k = 0; k < n; ++k) st[k] = C[st[k]].w << 9 | st[k];   // (a chain's weight is at most the read's length)
+                dev_introsort(n, st, [&](int x, int y) { return (x >> 9) > (y >> 9); }, o.wd);
+                for (int k = 0; k < n; ++k) st[k] &= 511;
+            } else dev_introsort(n, st, [&](int x, int y) { return C[x].w > C[y].w; }, o.wd);
             C[st[0]].kept = 3;
             od[0] = 0;
         }
@@ -207,23 +280,29 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
         }
     }
     WAVE_SYNC();
-    if (lane == 0) {
-        // emit kept chains in sorted order
-        int m = 0, sstart = 0;
-        for (int i = 0; i < n; ++i) {
-            DChainTmp c = C[st[i]];
-            if (c.kept == 0) continue;
-            DChain oc;
-            oc.pos = c.pos; oc.rid = c.rid; oc.n = c.n; oc.seed_start = sstart; oc.w = c.w; oc.kept = c.kept; oc.is_alt = (ix.contig_alt && ix.contig_alt[c.rid]) ? 1 : 0;
-            oc.frac_rep = (float)l_rep[r] / len; oc.pad = st[i];   // pad carries the tmp id for the flatten step
-            chains[base + m] = oc;
-            sstart += c.n;
-            m++;
+    int m = 0;
+    {   // emit kept chains in sorted order
+        int sstart = 0;
+        const float frac_rep = (float)l_rep[r] / len;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            int kept = 0, cn = 0;
+            DChainTmp c;
+            if (i < n) { c = C[st[i]]; kept = c.kept != 0; cn = kept ? c.n : 0; }
+            const u64 km = __ballot(kept);
+            const int incl = wave_scan_add_i32(cn);
+            if (kept) {
+                DChain oc;
+                oc.pos = c.pos; oc.rid = c.rid; oc.n = c.n; oc.seed_start = sstart + incl - cn; oc.w = c.w; oc.kept = c.kept; oc.is_alt = (ix.contig_alt && ix.contig_alt[c.rid]) ? 1 : 0;
+                oc.frac_rep = frac_rep; oc.pad = st[i];   // pad carries the tmp id for the flatten step
+                chains[base + m + lanes_below(km, lane)] = oc;
+            }
+            m += (int)__popcll(km);
+            sstart += wave_readlane(incl, 63);
         }
-        n_chains[r] = m;
+        if (lane == 0) n_chains[r] = m;
     }
     WAVE_SYNC();
-    int m = n_chains[r];
     for (int k = lane; k < m; k += 64) {   // flatten each chain's seed list
         DChain oc = chains[base + k];
         int s = C[oc.pad].head;

@@ -35,14 +35,24 @@ __device__ __forceinline__ int wave_patch_reg(const DIndex& ix, const DOpts& o, 
 }
 
 // mem_sort_dedup_patch over av[0..n).  ia: int scratch [n]; tmp: DReg scratch [n].  Returns the new count (uniform).
+// lk / lk_cap: LDS scratch for the two sorts (may be null).  With it, what the introsorts move is one 64-bit word per region — the sort key with the
+// region's index in its low 9 bits, compared without them — instead of an index whose every comparison reads two region records from memory: the
+// same comparisons, the same moves, the same order for equal keys.
 __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOpts& o, const uint8_t* q, DReg* av, int n, int32_t* ia, DReg* tmp,
-                                                     int do_patch, int lane, u64* cells) {
+                                                     int do_patch, int lane, u64* cells, i64* lk = nullptr, int lk_cap = 0) {
     if (n <= 1) return n;
-    if (lane == 0) {
-        for (int i = 0; i < n; ++i) { ia[i] = i; av[i].n_comp = 1; }
-        dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; }, o.wd);   // sort by the END position, not START!
+    const bool packed = lk && n <= lk_cap && n <= 512;
+    for (int i = lane; i < n; i += 64) { ia[i] = i; av[i].n_comp = 1; if (packed) lk[i] = av[i].re << 9 | (i64)i; }
+    WAVE_SYNC();
+    if (lane == 0) {   // sort by the END position, not START!
+        if (packed) dev_introsort(n, lk, [&](i64 x, i64 y) { return (x >> 9) < (y >> 9); }, o.wd);
+        else dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; }, o.wd);
     }
     WAVE_SYNC();
+    if (packed) {
+        for (int i = lane; i < n; i += 64) ia[i] = (int)(lk[i] & 511);
+        WAVE_SYNC();
+    }
     int wd = 1000000;
     for (int i = 1; i < n; ++i) {
         DReg p = av[ia[i]];
@@ -86,7 +96,29 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     if (lane == 0) {
         for (int i = 0; i < n; ++i)   // exclude identical hits
             if (av[ia[i]].qe > av[ia[i]].qb) ia[m++] = ia[i];
-        dev_introsort(m, ia, [&](int x, int y) {
+        ia[n] = m;
+    }
+    WAVE_SYNC();
+    m = ia[n];
+    int pk2 = packed;
+    if (packed) {   // (score desc, rb, qb) as one ascending key: 13 + 33 + 8 bits above the index; a region outside those ranges: the comparator on the records
+        int bad = 0;
+        for (int i = lane; i < m; i += 64) {
+            const DReg& g = av[ia[i]];
+            bad |= g.score < 0 || g.score > 8191 || g.rb < 0 || g.rb >= (1ll << 33) || g.qb < 0 || g.qb > 255;
+            lk[i] = (i64)(8191 - g.score) << 50 | g.rb << 17 | (i64)g.qb << 9 | (i64)ia[i];
+        }
+        pk2 = !__any(bad);
+    }
+    WAVE_SYNC();
+    if (pk2) {
+        if (lane == 0) dev_introsort(m, lk, [&](i64 x, i64 y) { return (x >> 9) < (y >> 9); }, o.wd);
+        WAVE_SYNC();
+        for (int i = lane; i < m; i += 64) ia[i] = (int)(lk[i] & 511);
+        WAVE_SYNC();
+    }
+    if (lane == 0) {
+        if (!pk2) dev_introsort(m, ia, [&](int x, int y) {
             const DReg &A = av[x], &B = av[y];
             return A.score > B.score || (A.score == B.score && (A.rb < B.rb || (A.rb == B.rb && A.qb < B.qb)));
         }, o.wd);
@@ -179,6 +211,7 @@ __global__ void __launch_bounds__(64) k_dedup(DIndex ix, DOpts o, int n_reads, c
                                                int32_t* __restrict__ n_regs, int32_t* __restrict__ best_score, DCounters* __restrict__ ctr,
                                                const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
     __shared__ uint8_t q[LH_MAXLEN + 6];
+    __shared__ i64 lk[512];
     const int lane = LANE();
     const int n_items = list ? *list_count : n_reads;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -193,7 +226,7 @@ __global__ void __launch_bounds__(64) k_dedup(DIndex ix, DOpts o, int n_reads, c
     DReg* av = regs + ro;
     int n = n_regs[r];
     u64 cells = 0;
-    n = wave_sort_dedup_patch(ix, o, q, av, n, ia_pool + ro + r, regs_tmp + ro, 1, lane, &cells);
+    n = wave_sort_dedup_patch(ix, o, q, av, n, ia_pool + ro + r, regs_tmp + ro, 1, lane, &cells, lk, 512);
     int best = 0;
     for (int i = lane; i < n; i += 64) { int s = av[i].score; best = best > s ? best : s; }
     best = wave_max_i32(best);

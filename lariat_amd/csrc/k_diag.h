@@ -135,7 +135,9 @@ __global__ void __launch_bounds__(64) k_diag_resc_dedup(DIndex ix, DOpts o, int 
         WAVE_SYNC();
         const int n_full = wave_sort_dedup_patch(ix, o, nullptr, B, n + 1, I, T, 0, lane, &cells);
         // (b) incremental
-        const int n_inc = resc_dedup_incremental(o, W, n, b, lane);
+        int app = 0;
+        const int n_inc = resc_dedup_incremental(o, W, n, b, lane, &app);
+        if (n_inc >= 0 && app) resc_list_sort(W, n_inc, lane);
         WAVE_SYNC();
         int bad = 0;
         if (n_inc >= 0) {

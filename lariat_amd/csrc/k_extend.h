@@ -12,14 +12,6 @@
 
 struct ExtRes { int score, qle, tle, gtle, gscore, max_off; };
 
-__device__ __forceinline__ i64 wave_min_i64(i64 v) {
-    for (int m = 32; m >= 1; m >>= 1) { i64 o = shfl_i64(v, LANE() ^ m); v = v < o ? v : o; }
-    return v;
-}
-__device__ __forceinline__ i64 wave_max_i64(i64 v) {
-    for (int m = 32; m >= 1; m >>= 1) { i64 o = shfl_i64(v, LANE() ^ m); v = v > o ? v : o; }
-    return v;
-}
 
 #define LH_NEG_INF (-0x3fffffff)
 

@@ -388,8 +388,35 @@ __device__ __forceinline__ int resc_redundant(const DOpts& o, i64 q_rb, i64 q_re
     return (float)orr > o.mask_level_redun * (float)mr && (float)oq > o.mask_level_redun * (float)mq;
 }
 
+// the list in LDS into the order mem_sort_dedup_patch leaves it in — (score desc, rb, qb), all keys distinct while the list lives in LDS —: every
+// entry's rank is the number of entries before it.  (resc_dedup_incremental appends: the order only matters when the list goes back to memory.)
+__device__ __forceinline__ void resc_list_sort(RescList& W, int n, int lane) {
+    constexpr int PER = LH_RA_CAP / 64;
+    i64 e[PER], krb[PER]; int kqb[PER], kqe[PER], ksc[PER], krid[PER], ksrc[PER], rank[PER];
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int k = t * 64 + lane;
+        rank[t] = -1;
+        if (k < n) {
+            e[t] = W.re[k]; krb[t] = W.rb[k]; kqb[t] = W.qb[k]; kqe[t] = W.qe[k]; ksc[t] = W.score[k]; krid[t] = W.rid[k]; ksrc[t] = W.src[k];
+            int rk = 0;
+            for (int u = 0; u < n; ++u) {
+                const int us = W.score[u];
+                rk += us > ksc[t] || (us == ksc[t] && (W.rb[u] < krb[t] || (W.rb[u] == krb[t] && W.qb[u] < kqb[t])));
+            }
+            rank[t] = rk;
+        }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+        if (rank[t] >= 0) { const int d = rank[t]; W.re[d] = e[t]; W.rb[d] = krb[t]; W.qb[d] = kqb[t]; W.qe[d] = kqe[t]; W.score[d] = ksc[t]; W.rid[d] = krid[t]; W.src[d] = ksrc[t]; }
+    WAVE_SYNC();
+}
 // the list in LDS back into the memory arrays: entries that were there when it was loaded (src >= 0) keep their other fields, rescued ones get mem_matesw's
-__device__ __forceinline__ void resc_list_store(const DIndex& ix, const RescList& W, int n, DReg* ma, DReg* tmp, int lane) {
+__device__ __forceinline__ void resc_list_store(const DIndex& ix, RescList& W, int n, DReg* ma, DReg* tmp, int lane, int sorted) {
+    if (!sorted) resc_list_sort(W, n, lane);
     WAVE_SYNC();
     for (int k = lane; k < n; k += 64) {
         DReg g;
@@ -409,87 +436,66 @@ __device__ __forceinline__ void resc_list_store(const DIndex& ix, const RescList
     WAVE_SYNC();
 }
 
-// mem_sort_dedup_patch(opt, 0, 0, 0, n + 1, list + b) for a CLEAN list in W (see above) and a new region b, in place.  Returns the new length,
-// or -1 (W untouched) when equal keys make the introsorts' order matter or the list is full: the caller runs the call as written.
-__device__ __forceinline__ int resc_dedup_incremental(const DOpts& o, RescList& W, int n_ma, const DReg& b, int lane) {
-    i64 lo_bar = -0x7fffffffffffffffll, hi_bar = 0x7fffffffffffffffll;   // nearest entries of ANOTHER contig left and right of b (by re): the scans stop there
+// mem_sort_dedup_patch(opt, 0, 0, 0, n + 1, list + b) for a CLEAN list in W (see above; in any order) and a new region b, in place: the survivors keep
+// their places, b — if it survives — goes to the end (*appended).  Returns the new length, or -1 (W untouched) when equal keys make the introsorts'
+// order matter or the list is full: the caller runs the call as written.  One pass finds what decides b's fate (the nearest redundant entry with a
+// higher score to the left, the nearest redundant one that is not worse to the right, the nearest entries of another contig: the scans stop there),
+// a second one the entries b excludes; the list is only compacted when there are any.
+__device__ __forceinline__ int resc_dedup_incremental(const DOpts& o, RescList& W, int n_ma, const DReg& b, int lane, int* appended) {
+    const i64 NINF = -0x7fffffffffffffffll, PINF = 0x7fffffffffffffffll;
+    i64 lo_bar = NINF, hi_bar = PINF, r_cand = NINF, s_cand = PINF;
     int tie = 0;
     for (int i0 = 0; i0 < n_ma; i0 += 64) {
         const int k = i0 + lane;
         if (k < n_ma) {
-            const i64 e = W.re[k];
-            tie |= e == b.re || (W.score[k] == b.score && W.rb[k] == b.rb && W.qb[k] == b.qb);
+            const i64 e = W.re[k], krb = W.rb[k];
+            const int ksc = W.score[k], kqb = W.qb[k];
+            tie |= e == b.re || (ksc == b.score && krb == b.rb && kqb == b.qb);
             if (W.rid[k] != b.rid) { if (e < b.re && e > lo_bar) lo_bar = e; if (e > b.re && e < hi_bar) hi_bar = e; }
+            else if (e < b.re) {
+                if (b.rb < e + o.max_chain_gap && b.score < ksc && e > r_cand && resc_redundant(o, krb, e, kqb, W.qe[k], b.rb, b.re, b.qb, b.qe)) r_cand = e;
+            } else {
+                if (krb < b.re + o.max_chain_gap && !(ksc < b.score) && e < s_cand && resc_redundant(o, b.rb, b.re, b.qb, b.qe, krb, e, kqb, W.qe[k])) s_cand = e;
+            }
         }
     }
-    tie = __any(tie) || n_ma + 1 > LH_RA_CAP;
-    if (tie) return -1;
-    {
-        lo_bar = wave_max_i64(lo_bar); hi_bar = wave_min_i64(hi_bar);
-        // p = b: to the left
-        i64 r_star = -0x7fffffffffffffffll;   // the nearest redundant entry with a higher score: it excludes b
-        for (int i0 = 0; i0 < n_ma; i0 += 64) {
-            const int k = i0 + lane;
-            if (k < n_ma) {
-                const i64 e = W.re[k];
-                if (e < b.re && e > lo_bar && W.rid[k] == b.rid && b.rb < e + o.max_chain_gap && b.score < W.score[k] &&
-                    resc_redundant(o, W.rb[k], e, W.qb[k], W.qe[k], b.rb, b.re, b.qb, b.qe) && e > r_star) r_star = e;
-            }
+    if (__any(tie) || n_ma + 1 > LH_RA_CAP) return -1;
+    lo_bar = wave_max_i64(lo_bar); hi_bar = wave_min_i64(hi_bar);
+    r_cand = wave_max_i64(r_cand); s_cand = wave_min_i64(s_cand);
+    const i64 r_star = r_cand > lo_bar ? r_cand : NINF;   // (beyond an entry of another contig the scan to the left never gets)
+    const int b_dead_a = r_star != NINF;
+    const i64 s_star = !b_dead_a && s_cand < hi_bar ? s_cand : PINF;
+    const int b_alive = !b_dead_a && s_star == PINF;
+    int n_new = 0, compact = 0;
+    for (int i0 = 0; i0 < n_ma; i0 += 64) {   // the entries b excludes: to its left while it goes left (down to r_star), to its right while it is alive (up to s_star)
+        const int k = i0 + lane;
+        int dead = 0;
+        i64 e = 0, krb = 0; int kqb = 0, kqe = 0, ksc = 0, krid = 0, ksrc = 0;
+        if (k < n_ma) {
+            e = W.re[k]; krb = W.rb[k]; kqb = W.qb[k]; kqe = W.qe[k]; ksc = W.score[k]; krid = W.rid[k];
+            if (e < b.re && e > lo_bar && e > r_star && krid == b.rid && b.rb < e + o.max_chain_gap && !(b.score < ksc))
+                dead = resc_redundant(o, krb, e, kqb, kqe, b.rb, b.re, b.qb, b.qe);
+            else if (!b_dead_a && e > b.re && e < hi_bar && e < s_star && krid == b.rid && krb < b.re + o.max_chain_gap && ksc < b.score)
+                dead = resc_redundant(o, b.rb, b.re, b.qb, b.qe, krb, e, kqb, kqe);
         }
-        r_star = wave_max_i64(r_star);
-        const int b_dead_a = r_star != -0x7fffffffffffffffll;
-        // p right of b, while b is alive
-        i64 s_star = 0x7fffffffffffffffll;   // the nearest redundant entry to the right whose score is not below b's: it excludes b
-        if (!b_dead_a) {
-            for (int i0 = 0; i0 < n_ma; i0 += 64) {
-                const int k = i0 + lane;
-                if (k < n_ma) {
-                    const i64 e = W.re[k];
-                    if (e > b.re && e < hi_bar && W.rid[k] == b.rid && W.rb[k] < b.re + o.max_chain_gap && !(W.score[k] < b.score) &&
-                        resc_redundant(o, b.rb, b.re, b.qb, b.qe, W.rb[k], e, W.qb[k], W.qe[k]) && e < s_star) s_star = e;
-                }
-            }
-            s_star = wave_min_i64(s_star);
-        }
-        const int b_alive = !b_dead_a && s_star == 0x7fffffffffffffffll;
-        // the survivors, compacted in place (the order stays), and b's place among them
-        int n_new = 0, pos_b = 0;
-        for (int i0 = 0; i0 < n_ma; i0 += 64) {
-            const int k = i0 + lane;
-            int keep = 0, before = 0;
-            i64 e = 0, krb = 0; int kqb = 0, kqe = 0, ksc = 0, krid = 0, ksrc = 0;
-            if (k < n_ma) {
-                e = W.re[k]; krb = W.rb[k]; kqb = W.qb[k]; kqe = W.qe[k]; ksc = W.score[k]; krid = W.rid[k]; ksrc = W.src[k];
-                int dead = 0;
-                if (e < b.re && e > lo_bar && e > r_star && krid == b.rid && b.rb < e + o.max_chain_gap && !(b.score < ksc))
-                    dead = resc_redundant(o, krb, e, kqb, kqe, b.rb, b.re, b.qb, b.qe);
-                else if (!b_dead_a && e > b.re && e < hi_bar && e < s_star && krid == b.rid && krb < b.re + o.max_chain_gap && ksc < b.score)
-                    dead = resc_redundant(o, b.rb, b.re, b.qb, b.qe, krb, e, kqb, kqe);
-                keep = !dead;
-                before = keep && (ksc > b.score || (ksc == b.score && (krb < b.rb || (krb == b.rb && kqb < b.qb))));
-            }
-            const u64 mk = __ballot(keep), mb = __ballot(before);
+        const u64 mk = __ballot(k < n_ma && !dead);
+        compact |= __any(dead);
+        if (compact) {   // (wave-uniform) from the first chunk with an excluded entry on, the survivors move up
+            if (k < n_ma) ksrc = W.src[k];
             WAVE_SYNC();   // every lane holds its entry before any is moved
-            if (keep) { const int d = n_new + lanes_below(mk, lane); W.re[d] = e; W.rb[d] = krb; W.qb[d] = kqb; W.qe[d] = kqe; W.score[d] = ksc; W.rid[d] = krid; W.src[d] = ksrc; }
-            n_new += __popcll(mk); pos_b += __popcll(mb);
+            if (k < n_ma && !dead) { const int d = n_new + lanes_below(mk, lane); W.re[d] = e; W.rb[d] = krb; W.qb[d] = kqb; W.qe[d] = kqe; W.score[d] = ksc; W.rid[d] = krid; W.src[d] = ksrc; }
             WAVE_SYNC();
         }
-        n_ma = n_new;
-        if (b_alive) {
-            for (int top = n_ma; top > pos_b; top -= 64) {   // make room at pos_b
-                const int j = top - 1 - lane;
-                i64 e = 0, krb = 0; int kqb = 0, kqe = 0, ksc = 0, krid = 0, ksrc = 0;
-                if (j >= pos_b) { e = W.re[j]; krb = W.rb[j]; kqb = W.qb[j]; kqe = W.qe[j]; ksc = W.score[j]; krid = W.rid[j]; ksrc = W.src[j]; }
-                WAVE_SYNC();
-                if (j >= pos_b) { W.re[j + 1] = e; W.rb[j + 1] = krb; W.qb[j + 1] = kqb; W.qe[j + 1] = kqe; W.score[j + 1] = ksc; W.rid[j + 1] = krid; W.src[j + 1] = ksrc; }
-                WAVE_SYNC();
-            }
-            if (lane == 0) { W.re[pos_b] = b.re; W.rb[pos_b] = b.rb; W.qb[pos_b] = b.qb; W.qe[pos_b] = b.qe; W.score[pos_b] = b.score; W.rid[pos_b] = b.rid; W.src[pos_b] = -1; }
-            n_ma++;
-            WAVE_SYNC();
-        }
-        return n_ma;
+        n_new += __popcll(mk);
     }
+    n_ma = n_new;
+    *appended = b_alive;
+    if (b_alive) {
+        if (lane == 0) { W.re[n_ma] = b.re; W.rb[n_ma] = b.rb; W.qb[n_ma] = b.qb; W.qe[n_ma] = b.qe; W.score[n_ma] = b.score; W.rid[n_ma] = b.rid; W.src[n_ma] = -1; }
+        n_ma++;
+        WAVE_SYNC();
+    }
+    return n_ma;
 }
 
 template <int DIR>
@@ -521,6 +527,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
         int jp = 0;
         u64 cells = 0;
         int n_sw = 0, num = 0;
+        int w_sorted = 1;   // the list in LDS is in the call's final order (until a rescued region is appended)
         int mode = 0;   // 0: the list is in memory, no dedup call yet; 1: in LDS (W), clean; 2: in memory for good (equal re left behind / too long); 3: in memory for this call
         for (int i = 0; i < nf && num < o.rescue_max_hits && l_ms > 0; ++i) {
             const DReg a = from[i];
@@ -587,11 +594,12 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
             if (mode == 1) {
                 if (!hit) continue;   // a clean list and nothing new: the call changes nothing
                 {   // the call as a function of b
-                    const int n_inc = resc_dedup_incremental(o, W, n_ma, b, lane);
-                    if (n_inc >= 0) { n_ma = n_inc; continue; }
+                    int app = 0;
+                    const int n_inc = resc_dedup_incremental(o, W, n_ma, b, lane, &app);
+                    if (n_inc >= 0) { n_ma = n_inc; if (app) w_sorted = 0; continue; }
                 }
                 // equal keys: this call as written, on the list in memory (mode 3: it may come back if the call leaves no equal re behind)
-                resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane);
+                resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane, w_sorted);
                 mode = 3;
             }
             // ---- the list in memory: insert, then mem_sort_dedup_patch as written
@@ -614,13 +622,14 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 n_ma++;
                 WAVE_SYNC();
             }
-            n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells);
+            n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells, W.rb, LH_RA_CAP);   // (the list is in memory during the call: W's first array is the sorts' scratch)
             if (mode != 2 && n_ma + o.rescue_max_hits <= LH_RA_CAP) {   // (back) into LDS if the list fits with everything that may still come and no two re are equal
                 for (int k = lane; k < n_ma; k += 64) {
                     const DReg& g = ma[k];
                     W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k;
                 }
                 WAVE_SYNC();
+                w_sorted = 1;
                 int eq = 0;
                 if (mode == 0) {   // the first call is behind: any pair
                     for (int k = lane; k < n_ma; k += 64) { const i64 e = W.re[k]; for (int u = 0; u < k; ++u) eq |= W.re[u] == e; }
@@ -632,7 +641,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 mode = __any(eq) ? 2 : 1;
             } else mode = 2;
         }
-        if (mode == 1) resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane);
+        if (mode == 1) resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane, w_sorted);
         if (lane == 0) {
             n_regs[r_ms] = n_ma;
             if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); }

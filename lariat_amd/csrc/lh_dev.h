@@ -234,6 +234,30 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return wave_readlane(v, 63);
 }
 #endif
+// 64-bit maximum / minimum over the wave
+#ifdef LH_EMU
+__device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int m = 32; m >= 1; m >>= 1) { i64 o = shfl_xor_i64(v, m); v = v > o ? v : o; } return v; }
+__device__ __forceinline__ i64 wave_min_i64(i64 v) { for (int m = 32; m >= 1; m >>= 1) { i64 o = shfl_xor_i64(v, m); v = v < o ? v : o; } return v; }
+#else
+// (DPP on both halves: six steps of two moves, a compare and a select instead of twelve ds_bpermute round trips)
+#define LH_DPP64_STEP(ctrl, rmask, id_hi, id_lo, cmp)                                                       \
+    {                                                                                                      \
+        const int lo_ = LH_DPP((int)(id_lo), (int)(uint32_t)(u64)v, ctrl, rmask);                          \
+        const int hi_ = LH_DPP((int)(id_hi), (int)((u64)v >> 32), ctrl, rmask);                            \
+        const i64 t_ = (i64)((u64)(uint32_t)hi_ << 32 | (u64)(uint32_t)lo_);                               \
+        v = v cmp t_ ? v : t_;                                                                             \
+    }
+__device__ __forceinline__ i64 wave_max_i64(i64 v) {
+    LH_DPP64_STEP(0x111, 0xF, 0x80000000u, 0u, >) LH_DPP64_STEP(0x112, 0xF, 0x80000000u, 0u, >) LH_DPP64_STEP(0x114, 0xF, 0x80000000u, 0u, >)
+    LH_DPP64_STEP(0x118, 0xF, 0x80000000u, 0u, >) LH_DPP64_STEP(0x142, 0xA, 0x80000000u, 0u, >) LH_DPP64_STEP(0x143, 0xC, 0x80000000u, 0u, >)
+    return (i64)((u64)(uint32_t)wave_readlane((int)((u64)v >> 32), 63) << 32 | (u64)(uint32_t)wave_readlane((int)(uint32_t)(u64)v, 63));
+}
+__device__ __forceinline__ i64 wave_min_i64(i64 v) {
+    LH_DPP64_STEP(0x111, 0xF, 0x7fffffffu, 0xffffffffu, <) LH_DPP64_STEP(0x112, 0xF, 0x7fffffffu, 0xffffffffu, <) LH_DPP64_STEP(0x114, 0xF, 0x7fffffffu, 0xffffffffu, <)
+    LH_DPP64_STEP(0x118, 0xF, 0x7fffffffu, 0xffffffffu, <) LH_DPP64_STEP(0x142, 0xA, 0x7fffffffu, 0xffffffffu, <) LH_DPP64_STEP(0x143, 0xC, 0x7fffffffu, 0xffffffffu, <)
+    return (i64)((u64)(uint32_t)wave_readlane((int)((u64)v >> 32), 63) << 32 | (u64)(uint32_t)wave_readlane((int)(uint32_t)(u64)v, 63));
+}
+#endif
 __device__ __forceinline__ int lanes_below(u64 mask, int lane) { return __popcll(mask & ((1ull << lane) - 1)); }
 
 // DPP lane exchanges inside a 16-lane row (1 VALU op instead of an LDS-crossbar ds_bpermute round trip)
