@@ -374,9 +374,11 @@ __global__ void __launch_bounds__(64) k_resc_sw(DIndex ix, DOpts o, RJob* __rest
 // When all re are distinct and no entry has b's (score, rb, qb), the introsorts' handling of equal keys cannot matter, and the above IS the
 // call's result: a few reductions over the list, which lives in LDS.  A call after an attempt that added nothing changes nothing.  Anything
 // else — equal keys, a list that outgrows the LDS arrays — goes back to wave_sort_dedup_patch on the arrays in memory, for the rest of the pair.
-#define LH_RA_CAP 256
+#ifndef LH_RA_CAP
+#define LH_RA_CAP 320   // measured 192 / 256 / 320 / 384: K6 390 / 323 / 296 / 297 ms on the repeat-family input (the pairs whose lists do not fit run every call from memory)
+#endif
 struct RescList {
-    i64 rb[LH_RA_CAP], re[LH_RA_CAP];
+    i64 rb[LH_RA_CAP], re[LH_RA_CAP];   // (first: wave_sort_dedup_patch's scratch while the list is in memory)
     int32_t qb[LH_RA_CAP], qe[LH_RA_CAP], score[LH_RA_CAP], rid[LH_RA_CAP], src[LH_RA_CAP];   // src: the entry's place in the memory arrays when the list was loaded; -1: rescued since
 };
 // "one of the hits is redundant": q = the entry with the smaller re (mem_sort_dedup_patch's a[j]), p = the one with the larger
@@ -622,7 +624,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 n_ma++;
                 WAVE_SYNC();
             }
-            n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells, W.rb, LH_RA_CAP);   // (the list is in memory during the call: W's first array is the sorts' scratch)
+            n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells, (i64*)&W, 2 * LH_RA_CAP);   // (the list is in memory during the call: W's two 64-bit arrays are the sorts' scratch)
             if (mode != 2 && n_ma + o.rescue_max_hits <= LH_RA_CAP) {   // (back) into LDS if the list fits with everything that may still come and no two re are equal
                 for (int k = lane; k < n_ma; k += 64) {
                     const DReg& g = ma[k];

@@ -34,10 +34,14 @@ template <class T, class Lt> __device__ inline void dev_combsort(int n, T* a, Lt
 
 // (its stack lives in LDS: one lane of a single-wave block runs it; a private array would be 1.7 KB of scratch in every kernel that sorts)
 #define LH_ISORT_STK 64
+struct LhIsortStk { int32_t left, right, depth; };
+__device__ __forceinline__ LhIsortStk* lh_isort_stack_ptr() {   // ONE array per kernel, whatever the number of element types and orders it sorts by (a template's own __shared__ array exists once per instantiation)
+    __shared__ LhIsortStk lh_isort_stack[LH_ISORT_STK];
+    return lh_isort_stack;
+}
 template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, Lt lt, int32_t* wdp) {
-    struct Stk { int32_t left, right, depth; };
-    __shared__ Stk lh_isort_stack[LH_ISORT_STK];
-    Stk* const stack = lh_isort_stack;
+    typedef LhIsortStk Stk;
+    Stk* const stack = lh_isort_stack_ptr();
     int d;
     T rp, swap_tmp;
     T *s, *t, *i, *j, *k;
