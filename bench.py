@@ -602,14 +602,15 @@ def repeats_leg(lib, a, local_rank, opts, steps=3):
     families of 50-200 copies x 20 kb at 98-99.5 %, 40 LINE-like and 80 SINE-like families, 40 ALT contigs (is_alt) — with EVERY read drawn on
     the copies (flank <= 2 kb): tens to hundreds of candidates per read, up to 50 + 50 mate-rescue Smith-Watermans per pair (gobwa.go:286-325),
     n_a x n_m pair scores per read in tagBestAlignments / estimateMapQualities.  Its own index (the headline index has been freed by now);
-    batches of a tenth of the headline's size (a pair costs ~500 times the DP cells of a pair on unique sequence)."""
+    batches of a fifth of the headline's size (a pair costs ~500 times the DP cells of a pair on unique sequence; 4,000 barcodes: one wave per barcode
+    in K8 — fewer leave the chip half empty there: 2,000 -> 4,000 barcodes per step is 277 k -> 322 k pairs/s)."""
     import numpy as np
     from lariat_amd import capi, workload
     t0 = time.time()
     g = workload.config4_genome(lib, a.genome_mb * 1e6 * 0.987)
     idx = lib.index_build_device(g["pac"], g["l_pac"], g["contigs"], device=local_rank)
     idx.set_alt(g["alt_flags"])
-    n_bc = max(1, a.barcodes // 10)
+    n_bc = max(1, a.barcodes // 5)
     n_pairs = n_bc * a.pairs_per_barcode
     ctx = idx.context(n_pairs)
     for slot in range(steps):

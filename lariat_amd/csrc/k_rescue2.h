@@ -393,7 +393,7 @@ __device__ __forceinline__ int resc_redundant(const DOpts& o, i64 q_rb, i64 q_re
 // the list in LDS into the order mem_sort_dedup_patch leaves it in — (score desc, rb, qb), all keys distinct while the list lives in LDS —: every
 // entry's rank is the number of entries before it.  (resc_dedup_incremental appends: the order only matters when the list goes back to memory.)
 __device__ __forceinline__ void resc_list_sort(RescList& W, int n, int lane) {
-    constexpr int PER = LH_RA_CAP / 64;
+    constexpr int PER = (LH_RA_CAP + 63) / 64;
     i64 e[PER], krb[PER]; int kqb[PER], kqe[PER], ksc[PER], krid[PER], ksrc[PER], rank[PER];
     WAVE_SYNC();
 #pragma unroll
