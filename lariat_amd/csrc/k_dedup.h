@@ -41,16 +41,17 @@ __device__ __forceinline__ int wave_patch_reg(const DIndex& ix, const DOpts& o, 
 __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOpts& o, const uint8_t* q, DReg* av, int n, int32_t* ia, DReg* tmp,
                                                      int do_patch, int lane, u64* cells, i64* lk = nullptr, int lk_cap = 0) {
     if (n <= 1) return n;
-    const bool packed = lk && n <= lk_cap && n <= 512;
-    for (int i = lane; i < n; i += 64) { ia[i] = i; av[i].n_comp = 1; if (packed) lk[i] = av[i].re << 9 | (i64)i; }
+    const bool packed = lk && n <= lk_cap && n <= 2048;
+    const int ib = n <= 512 ? 9 : 11;   // bits of the region index below the key
+    for (int i = lane; i < n; i += 64) { ia[i] = i; av[i].n_comp = 1; if (packed) lk[i] = av[i].re << ib | (i64)i; }
     WAVE_SYNC();
     if (lane == 0) {   // sort by the END position, not START!
-        if (packed) dev_introsort(n, lk, [&](i64 x, i64 y) { return (x >> 9) < (y >> 9); }, o.wd);
+        if (packed) dev_introsort(n, lk, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); }, o.wd);
         else dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; }, o.wd);
     }
     WAVE_SYNC();
     if (packed) {
-        for (int i = lane; i < n; i += 64) ia[i] = (int)(lk[i] & 511);
+        for (int i = lane; i < n; i += 64) ia[i] = (int)(lk[i] & ((1 << ib) - 1));
         WAVE_SYNC();
     }
     int wd = 1000000;
@@ -101,20 +102,24 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     WAVE_SYNC();
     m = ia[n];
     int pk2 = packed;
-    if (packed) {   // (score desc, rb, qb) as one ascending key: 13 + 33 + 8 bits above the index; a region outside those ranges: the comparator on the records
-        int bad = 0;
+    if (packed) {   // (score desc, rb, qb) as one ascending key: the bits of the list's largest score, 33 and 8 above the index; a region outside those ranges: the comparator on the records
+        int smax = 0;
+        for (int i = lane; i < m; i += 64) { const int sc = av[ia[i]].score; smax = smax > sc ? smax : sc; }
+        smax = wave_max_i32(smax);
+        const int sb = 32 - __clz(smax | 1);
+        int bad = sb + 33 + 8 + ib > 63;
         for (int i = lane; i < m; i += 64) {
             const DReg& g = av[ia[i]];
-            bad |= g.score < 0 || g.score > 8191 || g.rb < 0 || g.rb >= (1ll << 33) || g.qb < 0 || g.qb > 255;
-            lk[i] = (i64)(8191 - g.score) << 50 | g.rb << 17 | (i64)g.qb << 9 | (i64)ia[i];
+            bad |= g.score < 0 || g.rb < 0 || g.rb >= (1ll << 33) || g.qb < 0 || g.qb > 255;
+            lk[i] = (i64)(smax - g.score) << (41 + ib) | g.rb << (8 + ib) | (i64)g.qb << ib | (i64)ia[i];
         }
         pk2 = !__any(bad);
     }
     WAVE_SYNC();
     if (pk2) {
-        if (lane == 0) dev_introsort(m, lk, [&](i64 x, i64 y) { return (x >> 9) < (y >> 9); }, o.wd);
+        if (lane == 0) dev_introsort(m, lk, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); }, o.wd);
         WAVE_SYNC();
-        for (int i = lane; i < m; i += 64) ia[i] = (int)(lk[i] & 511);
+        for (int i = lane; i < m; i += 64) ia[i] = (int)(lk[i] & ((1 << ib) - 1));
         WAVE_SYNC();
     }
     if (lane == 0) {

@@ -53,6 +53,10 @@ __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) { return (uint32_t)
 __device__ __forceinline__ int grp16_min(int v) { for (int m = 8; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v < o ? v : o; } return v; }
 __device__ __forceinline__ int grp16_max(int v) { for (int m = 8; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v > o ? v : o; } return v; }
 
+// entries of the replay's region list in LDS (k_resc_apply)
+#ifndef LH_RA_CAP
+#define LH_RA_CAP 320   // measured 192 / 256 / 320 / 384: K6 390 / 323 / 296 / 297 ms on the repeat-family input (the pairs whose lists do not fit run every call from memory)
+#endif
 #define LH_RJ_TMAX (LH_MAXLEN + 560)        // longest window: pes_high - pes_low + l_ms (lariat: 535 + l_ms)
 #define LH_RJ_TSLOT (16 + LH_RJ_TMAX + 16)  // a job's target bases in LDS: 16 non-matching rows in front and behind (the systolic skew)
 #define LH_RJ_NB 17                         // buckets: slen 0 .. 16
@@ -68,7 +72,7 @@ struct RJob {
 struct RMeta {   // per direction, on the device
     int32_t hist[LH_RJ_NB], bstart[LH_RJ_NB + 1], bcur[LH_RJ_NB];       // forward jobs by slen; bstart: bucket starts in the order array, each padded to 8
     int32_t hist2[LH_RJ_NB], bstart2[LH_RJ_NB + 1], bcur2[LH_RJ_NB];    // reverse jobs
-    int32_t list_count, pad_;
+    int32_t list_count, long_count;   // listed pairs; those of them whose mate's list is too long for the replay's usual LDS arrays
 };
 
 // which attempts of one pair and direction get past mem_matesw's first test ("a consistent pair exists; no need to perform SW") against the
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pai
     __shared__ int32_t sh_hist[LH_RJ_NB];
     const int slot = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     // the counting pass looks at every pair; the emitting pass only at the pairs it listed (a few thousand of two million on unique sequence)
-    const int p = EMIT ? (slot < meta->list_count ? list[slot] : n_pairs) : slot;
+    const int p = EMIT ? (slot < meta->list_count ? list[slot] & 0x3fffffff : n_pairs) : slot;
     if (!EMIT) { if (threadIdx.x < LH_RJ_NB) sh_hist[threadIdx.x] = 0; __syncthreads(); }
     int nj = 0, need = 0, slen = 0, obase = 0;
     if (EMIT) {   // the pair's places in the order array: one reservation per wave and bucket
@@ -142,9 +146,11 @@ __global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pai
             todo &= ~__ballot(mine);
         }
     }
+    int long_list = 0;
     if (p < n_pairs) {
         RescWalk w;
         w.init(DIR, p, seq_off, reg_off, regs, n_regs, best_score);
+        long_list = w.nm + o.rescue_max_hits > LH_RA_CAP;
         slen = (w.l_ms + 15) / 16;
         int has_n = -1;   // unknown
         i64 jbase = EMIT ? job_off[p] : 0;
@@ -187,9 +193,10 @@ __global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pai
         u64 m = __ballot(need);
         if (m) {
             int basep = 0;
-            if (lane == 0) basep = atomicAdd(&meta->list_count, (int32_t)__popcll(m));
+            const u64 ml = __ballot(need && long_list);
+            if (lane == 0) { basep = atomicAdd(&meta->list_count, (int32_t)__popcll(m)); if (ml) atomicAdd(&meta->long_count, (int32_t)__popcll(ml)); }
             basep = wave_readlane(basep, 0);
-            if (need) list[basep + lanes_below(m, lane)] = p;
+            if (need) list[basep + lanes_below(m, lane)] = p | (long_list ? 1 << 30 : 0);   // bit 30: the mate's list will not fit the replay's usual LDS arrays (k_resc_apply)
         }
         __syncthreads();
         if (threadIdx.x < LH_RJ_NB && sh_hist[threadIdx.x]) atomicAdd(&meta->hist[threadIdx.x], sh_hist[threadIdx.x]);
@@ -205,7 +212,7 @@ __global__ void k_resc_offsets(RMeta* __restrict__ meta, int which, i64* __restr
     int acc = 0;
     for (int s = 0; s < LH_RJ_NB; ++s) { bs[s] = acc; bc[s] = 0; acc += (h[s] + 7) & ~7; }
     bs[LH_RJ_NB] = acc;
-    if (peek_host) { peek_host[0] = *total_jobs; peek_host[1] = acc; peek_host[2] = meta->list_count; }
+    if (peek_host) { peek_host[0] = *total_jobs; peek_host[1] = acc; peek_host[2] = meta->list_count; peek_host[3] = meta->long_count; }
 }
 
 // the reverse passes (jobs whose forward pass reached minsc) by the striping of THEIR query, the prefix that ends at qe.  A block takes a
@@ -374,13 +381,14 @@ __global__ void __launch_bounds__(64) k_resc_sw(DIndex ix, DOpts o, RJob* __rest
 // When all re are distinct and no entry has b's (score, rb, qb), the introsorts' handling of equal keys cannot matter, and the above IS the
 // call's result: a few reductions over the list, which lives in LDS.  A call after an attempt that added nothing changes nothing.  Anything
 // else — equal keys, a list that outgrows the LDS arrays — goes back to wave_sort_dedup_patch on the arrays in memory, for the rest of the pair.
-#ifndef LH_RA_CAP
-#define LH_RA_CAP 320   // measured 192 / 256 / 320 / 384: K6 390 / 323 / 296 / 297 ms on the repeat-family input (the pairs whose lists do not fit run every call from memory)
-#endif
-struct RescList {
-    i64 rb[LH_RA_CAP], re[LH_RA_CAP];   // (first: wave_sort_dedup_patch's scratch while the list is in memory)
-    int32_t qb[LH_RA_CAP], qe[LH_RA_CAP], score[LH_RA_CAP], rid[LH_RA_CAP], src[LH_RA_CAP];   // src: the entry's place in the memory arrays when the list was loaded; -1: rescued since
+#ifndef LH_RA_CAP_BIG
+#define LH_RA_CAP_BIG 1024   // the few pairs whose lists are longer run in a second instance of the kernel with room for them (a pair that ran every call from memory — two
+#endif                       // single-lane introsorts of 400 regions, 50 times — took 25-50 ms: the kernel's duration; the sum of all waves' time was 7 ms of the chip)
+template <int CAP> struct RescListT {
+    i64 rb[CAP], re[CAP];   // (first: wave_sort_dedup_patch's scratch while the list is in memory)
+    int32_t qb[CAP], qe[CAP], score[CAP], rid[CAP], src[CAP];   // src: the entry's place in the memory arrays when the list was loaded; -1: rescued since
 };
+typedef RescListT<LH_RA_CAP> RescList;
 // "one of the hits is redundant": q = the entry with the smaller re (mem_sort_dedup_patch's a[j]), p = the one with the larger
 __device__ __forceinline__ int resc_redundant(const DOpts& o, i64 q_rb, i64 q_re, int q_qb, int q_qe, i64 p_rb, i64 p_re, int p_qb, int p_qe) {
     const i64 orr = q_re - p_rb;
@@ -392,8 +400,8 @@ __device__ __forceinline__ int resc_redundant(const DOpts& o, i64 q_rb, i64 q_re
 
 // the list in LDS into the order mem_sort_dedup_patch leaves it in — (score desc, rb, qb), all keys distinct while the list lives in LDS —: every
 // entry's rank is the number of entries before it.  (resc_dedup_incremental appends: the order only matters when the list goes back to memory.)
-__device__ __forceinline__ void resc_list_sort(RescList& W, int n, int lane) {
-    constexpr int PER = (LH_RA_CAP + 63) / 64;
+template <int CAP> __device__ __forceinline__ void resc_list_sort(RescListT<CAP>& W, int n, int lane) {
+    constexpr int PER = (CAP + 63) / 64;
     i64 e[PER], krb[PER]; int kqb[PER], kqe[PER], ksc[PER], krid[PER], ksrc[PER], rank[PER];
     WAVE_SYNC();
 #pragma unroll
@@ -417,7 +425,7 @@ __device__ __forceinline__ void resc_list_sort(RescList& W, int n, int lane) {
     WAVE_SYNC();
 }
 // the list in LDS back into the memory arrays: entries that were there when it was loaded (src >= 0) keep their other fields, rescued ones get mem_matesw's
-__device__ __forceinline__ void resc_list_store(const DIndex& ix, RescList& W, int n, DReg* ma, DReg* tmp, int lane, int sorted) {
+template <int CAP> __device__ __forceinline__ void resc_list_store(const DIndex& ix, RescListT<CAP>& W, int n, DReg* ma, DReg* tmp, int lane, int sorted) {
     if (!sorted) resc_list_sort(W, n, lane);
     WAVE_SYNC();
     for (int k = lane; k < n; k += 64) {
@@ -443,7 +451,7 @@ __device__ __forceinline__ void resc_list_store(const DIndex& ix, RescList& W, i
 // order matter or the list is full: the caller runs the call as written.  One pass finds what decides b's fate (the nearest redundant entry with a
 // higher score to the left, the nearest redundant one that is not worse to the right, the nearest entries of another contig: the scans stop there),
 // a second one the entries b excludes; the list is only compacted when there are any.
-__device__ __forceinline__ int resc_dedup_incremental(const DOpts& o, RescList& W, int n_ma, const DReg& b, int lane, int* appended) {
+template <int CAP> __device__ __forceinline__ int resc_dedup_incremental(const DOpts& o, RescListT<CAP>& W, int n_ma, const DReg& b, int lane, int* appended) {
     const i64 NINF = -0x7fffffffffffffffll, PINF = 0x7fffffffffffffffll;
     i64 lo_bar = NINF, hi_bar = PINF, r_cand = NINF, s_cand = PINF;
     int tie = 0;
@@ -461,7 +469,7 @@ __device__ __forceinline__ int resc_dedup_incremental(const DOpts& o, RescList& 
             }
         }
     }
-    if (__any(tie) || n_ma + 1 > LH_RA_CAP) return -1;
+    if (__any(tie) || n_ma + 1 > CAP) return -1;
     lo_bar = wave_max_i64(lo_bar); hi_bar = wave_min_i64(hi_bar);
     r_cand = wave_max_i64(r_cand); s_cand = wave_min_i64(s_cand);
     const i64 r_star = r_cand > lo_bar ? r_cand : NINF;   // (beyond an entry of another contig the scan to the left never gets)
@@ -500,20 +508,23 @@ __device__ __forceinline__ int resc_dedup_incremental(const DOpts& o, RescList& 
     return n_ma;
 }
 
-template <int DIR>
+template <int DIR, int CAP>
 __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
                                                     DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool, int32_t* __restrict__ n_regs,
                                                     const int32_t* __restrict__ best_score, DCounters* __restrict__ ctr, const int32_t* __restrict__ list, const RMeta* __restrict__ meta,
                                                     const int32_t* __restrict__ n_jobs, const i64* __restrict__ job_off, const RJob* __restrict__ jobs) {
     __shared__ uint8_t qm[LH_MAXLEN + 6];
-    __shared__ RescList W;
+    __shared__ RescListT<CAP> W;
     const int lane = LANE();
     const int n_items = meta->list_count;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int p = list[item];
-        WAVE_SYNC();   // the previous pair's query and list are no longer in use
+        // two instances of this kernel share the list: the one with the usual LDS arrays takes the pairs whose mate's list fits them with everything that
+        // may come, the one with LH_RA_CAP_BIG entries the others (k_resc_enum decided, bit 30 of the entry: every pair is replayed exactly once)
+        if (((list[item] >> 30) & 1) != (CAP != LH_RA_CAP)) continue;
+        const int p = list[item] & 0x3fffffff;
         const int r1 = 2 * p, r2 = 2 * p + 1;
         const int r_ms = DIR ? r2 : r1, r_from = DIR ? r1 : r2;
+        WAVE_SYNC();   // the previous pair's query and list are no longer in use
         const i64 off_ms = seq_off[r_ms];
         int l_ms = (int)(seq_off[r_ms + 1] - off_ms);
         if (l_ms > LH_MAXLEN) l_ms = 0;
@@ -526,16 +537,32 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
         const int nf = n_regs[r_from], bestf = best_score[r_from];
         const RJob* pj = jobs + job_off[p];
         const int npj = n_jobs[p];
+        // the pair's jobs and, 64 at a time, its anchors live in the lanes' registers (lane k: job k / anchor i0 + k) and are read with v_readlane: a dependent
+        // read from memory per iteration — anchor record, job anchor, job record — was most of an iteration's latency
+        const bool jreg = npj <= 64;
+        RJob myjob;
+        myjob.anchor = 0x7fff; myjob.score = 0; myjob.te = myjob.qe = myjob.tb = myjob.qb = 0; myjob.tlen = 0; myjob.rows2 = 0;
+        if (jreg && lane < npj) myjob = pj[lane];
+        int a_sc = 0, a_rid = 0, a_alt = 0;
+        i64 a_rb = 0;
         int jp = 0;
         u64 cells = 0;
         int n_sw = 0, num = 0;
         int w_sorted = 1;   // the list in LDS is in the call's final order (until a rescued region is appended)
         int mode = 0;   // 0: the list is in memory, no dedup call yet; 1: in LDS (W), clean; 2: in memory for good (equal re left behind / too long); 3: in memory for this call
         for (int i = 0; i < nf && num < o.rescue_max_hits && l_ms > 0; ++i) {
-            const DReg a = from[i];
+            if ((i & 63) == 0) {
+                const int k = i + lane;
+                if (k < nf) { const DReg& g = from[k]; a_sc = g.score; a_rb = g.rb; a_rid = g.rid; a_alt = g.is_alt; }
+            }
+            DReg a;
+            a.score = wave_readlane(a_sc, i & 63);
             if (a.score < bestf - o.rescue_score_delta) continue;
+            a.rb = (i64)((u64)(uint32_t)wave_readlane((int)((u64)a_rb >> 32), i & 63) << 32 | (u64)(uint32_t)wave_readlane((int)(uint32_t)(u64)a_rb, i & 63));
+            a.rid = wave_readlane(a_rid, i & 63); a.is_alt = wave_readlane(a_alt, i & 63);
             num++;
-            while (jp < npj && pj[jp].anchor < i) ++jp;             // (jobs of attempts that have become unnecessary are passed over)
+            if (jreg) jp = (int)__popcll(__ballot(lane < npj && myjob.anchor < i));   // (jobs of attempts that have become unnecessary are passed over)
+            else while (jp < npj && pj[jp].anchor < i) ++jp;
             int skip1 = 0;
             for (int i0 = 0; i0 < n_ma; i0 += 64) {                 // which orientation has been found
                 int k = i0 + lane, f = 0;
@@ -551,8 +578,13 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
             if (!resc_window(ix, o, a, l_ms, &rb, &re)) continue;
             n_sw++;
             KswR aln;
-            if (jp < npj && pj[jp].anchor == i) {
-                const RJob J = pj[jp];
+            if (jp < npj && (jreg ? wave_readlane((int)myjob.anchor, jp) : (int)pj[jp].anchor) == i) {
+                RJob J;
+                if (jreg) {
+                    J.score = (int16_t)wave_readlane((int)myjob.score, jp); J.te = (int16_t)wave_readlane((int)myjob.te, jp); J.qe = (int16_t)wave_readlane((int)myjob.qe, jp);
+                    J.tb = (int16_t)wave_readlane((int)myjob.tb, jp); J.qb = (int16_t)wave_readlane((int)myjob.qb, jp); J.tlen = (int16_t)wave_readlane((int)myjob.tlen, jp);
+                    J.rows2 = (int16_t)wave_readlane((int)myjob.rows2, jp);
+                } else J = pj[jp];
                 aln.score = J.score; aln.te = J.te; aln.qe = J.qe; aln.tb = J.tb; aln.qb = J.qb;
                 cells += (u64)(16 * ((l_ms + 15) / 16)) * (u64)J.tlen;
                 if (J.score >= o.min_seed_len * o.a) cells += (u64)(16 * ((J.qe + 1 + 15) / 16)) * (u64)J.rows2;
@@ -569,7 +601,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
                 b.truesc = 0; b.sub = 0; b.w = 0; b.seedlen0 = 0; b.n_comp = 0; b.frac_rep = 0;
             }
-            if (mode == 0 && n_ma + o.rescue_max_hits <= LH_RA_CAP) {
+            if (mode == 0 && n_ma + o.rescue_max_hits <= CAP) {
                 // the first attempt that gets here: the list as k_dedup left it (sorted, no identical hits).  If it also holds no redundant pair and no
                 // two equal re — one pass over its pairs — the call that follows this attempt is already a function of the added region alone
                 for (int k = lane; k < n_ma; k += 64) {
@@ -624,8 +656,8 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 n_ma++;
                 WAVE_SYNC();
             }
-            n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells, (i64*)&W, 2 * LH_RA_CAP);   // (the list is in memory during the call: W's two 64-bit arrays are the sorts' scratch)
-            if (mode != 2 && n_ma + o.rescue_max_hits <= LH_RA_CAP) {   // (back) into LDS if the list fits with everything that may still come and no two re are equal
+            n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells, (i64*)&W, 2 * CAP);   // (the list is in memory during the call: W's two 64-bit arrays are the sorts' scratch)
+            if (mode != 2 && n_ma + o.rescue_max_hits <= CAP) {   // (back) into LDS if the list fits with everything that may still come and no two re are equal
                 for (int k = lane; k < n_ma; k += 64) {
                     const DReg& g = ma[k];
                     W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k;
