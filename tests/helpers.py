@@ -271,3 +271,29 @@ def k7_band_case(g, ins_first):
     mate = contig[p + 250:p + 400]
     r2 = (3 - mate[::-1]).astype(np.uint8)
     return ["chrB"], [contig], capi.Batch([r1, r2], [0, 1]), p
+
+
+def repeat_family_case(seed, n_barcodes, pairs=30):
+    """a 600-kb genome with a family of 12 copies x 3 kb (0.2-1.2 % off the consensus, indels), one of 30 copies x 300 bp (2-8 %) and five tandem copies
+    of 1.2 kb; every read pair drawn on and around the copies: tens of chains, regions and rescue attempts per read — the regime of BASELINE
+    configs[4] in miniature.  Returns (names, contigs, read set)."""
+    from lariat_amd import synth, workload
+    rng = np.random.default_rng(seed)
+    g = rng.choice(4, size=600000, p=[0.295, 0.205, 0.205, 0.295]).astype(np.uint8)
+    q = g.reshape(-1, 4)
+    pac = np.concatenate([(q[:, 0] << 6 | q[:, 1] << 4 | q[:, 2] << 2 | q[:, 3]).astype(np.uint8), np.zeros(1, dtype=np.uint8)])
+    ctg = [("c0", 400000, 0), ("c1", 200000, 400000)]
+    fam = workload.plant_family(pac, ctg, rng, 3000, 12, 0.002, 0.012, indel_per_base=1 / 1500.0)
+    fam2 = workload.plant_family(pac, ctg, rng, 300, 30, 0.02, 0.08, indel_per_base=1 / 300.0)
+    tand = workload._unpack(pac, 100000, 1200)
+    for k in range(1, 5):   # tandem copies: rescue windows that hold two alignments of the mate, regions next to each other
+        seg = tand.copy(); m = rng.random(1200) < 0.01; seg[m] = (seg[m] + 1) & 3
+        workload._repack(pac, 100000 + 1200 * k, seg)
+    names = [c[0] for c in ctg]
+    contigs = [workload._unpack(pac, off, ln) for _, ln, off in ctg]
+    win = workload.windows_on(ctg, fam, 1000) + workload.windows_on(ctg, fam2, 850) + [("t", 9000, 98000)] * 6
+    wnames = ["w%d" % i for i in range(len(win))]
+    wcontigs = [workload._unpack(pac, off // 4 * 4, (ln + off % 4 + 3) // 4 * 4)[off % 4: off % 4 + ln] for _, ln, off in win]
+    rs = synth.make_reads(wcontigs, wnames, n_barcodes=n_barcodes, pairs_per_barcode=pairs, seed=seed + 9, mol_min=2, mol_max=4, ins_mean=470, ins_sd=120, ins_max=900,
+                          junk_frac=0.02)
+    return names, contigs, rs
