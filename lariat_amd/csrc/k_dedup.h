@@ -168,36 +168,60 @@ __global__ void __launch_bounds__(256) k_dedup_fast(DIndex ix, DOpts o, int n_re
         int n = n_regs[r];
         if (n <= 1) best_score[r] = n == 1 ? regs[reg_off[r]].score : 0;
         else if (n == 2) {
+            // (the decisions read six fields of each record; the records themselves move at most once, as 8-byte words: whole-record
+            // selects made the compiler keep them in 376 B of scratch)
             DReg* av = regs + reg_off[r];
-            DReg x0 = av[0], x1 = av[1];
-            x0.n_comp = 1; x1.n_comp = 1;
-            // sorted by re (klib's introsort on two elements: swapped only when strictly out of order)
-            DReg qq = x1.re < x0.re ? x1 : x0, p = x1.re < x0.re ? x0 : x1;
-            if (p.rid == qq.rid && p.rb < qq.re + o.max_chain_gap) {
-                i64 orr = qq.re - p.rb;
-                i64 oq = qq.qb < p.qb ? qq.qe - p.qb : p.qe - qq.qb;
-                i64 mr = qq.re - qq.rb < p.re - p.rb ? qq.re - qq.rb : p.re - p.rb;
-                i64 mq = qq.qe - qq.qb < p.qe - p.qb ? qq.qe - qq.qb : p.qe - p.qb;
+            const i64 rb0 = av[0].rb, re0 = av[0].re, rb1 = av[1].rb, re1 = av[1].re;
+            const int qb0 = av[0].qb, qe0 = av[0].qe, sc0 = av[0].score, rid0 = av[0].rid, qb1 = av[1].qb, qe1 = av[1].qe, sc1 = av[1].score, rid1 = av[1].rid;
+            // sorted by re (klib's introsort on two elements: swapped only when strictly out of order): qq = the first, p = the second
+            const int s = re1 < re0;
+            const i64 q_rb = s ? rb1 : rb0, q_re = s ? re1 : re0, p_rb = s ? rb0 : rb1, p_re = s ? re0 : re1;
+            const int q_qb = s ? qb1 : qb0, q_qe = s ? qe1 : qe0, q_sc = s ? sc1 : sc0, q_rid = s ? rid1 : rid0;
+            const int p_qb = s ? qb0 : qb1, p_qe = s ? qe0 : qe1, p_sc = s ? sc0 : sc1, p_rid = s ? rid0 : rid1;
+            int kp = p_qe > p_qb, kq = q_qe > q_qb;   // still there
+            if (p_rid == q_rid && p_rb < q_re + o.max_chain_gap) {
+                const i64 orr = q_re - p_rb;
+                const i64 oq = q_qb < p_qb ? q_qe - p_qb : p_qe - q_qb;
+                const i64 mr = q_re - q_rb < p_re - p_rb ? q_re - q_rb : p_re - p_rb;
+                const i64 mq = q_qe - q_qb < p_qe - p_qb ? q_qe - q_qb : p_qe - p_qb;
                 if ((float)orr > o.mask_level_redun * (float)mr && (float)oq > o.mask_level_redun * (float)mq) {
-                    if (p.score < qq.score) p.qe = p.qb;
-                    else qq.qe = qq.qb;
-                } else if (qq.rb < p.rb && dev_patch_needs_dp(ix, o, qq, p)) need = 1;
+                    if (p_sc < q_sc) kp = 0;
+                    else kq = 0;
+                } else if (q_rb < p_rb) {
+                    DReg a, b;   // (mem_patch_reg's tests up to its DP read the spans only)
+                    a.rb = q_rb; a.re = q_re; a.qb = q_qb; a.qe = q_qe; b.rb = p_rb; b.re = p_re; b.qb = p_qb; b.qe = p_qe;
+                    need = dev_patch_needs_dp(ix, o, a, b);
+                }
             }
             if (!need) {
                 // exclude, sort by (score desc, rb, qb), drop an identical hit
-                int kp = p.qe > p.qb, kq = qq.qe > qq.qb;
-                DReg a0, a1;
-                int m = 0;
+                int m = 0, first = 0;   // first: the record (0 / 1) that ends up in front
                 if (kq && kp) {   // order after the first sort: qq, p
-                    bool p_first = p.score > qq.score || (p.score == qq.score && (p.rb < qq.rb || (p.rb == qq.rb && p.qb < qq.qb)));
-                    a0 = p_first ? p : qq; a1 = p_first ? qq : p;
-                    m = (a1.score == a0.score && a1.rb == a0.rb && a1.qb == a0.qb) ? 1 : 2;
-                } else if (kq) { a0 = qq; m = 1; }
-                else if (kp) { a0 = p; m = 1; }
-                if (m >= 1) av[0] = a0;
-                if (m == 2) av[1] = a1;
+                    const bool p_first = p_sc > q_sc || (p_sc == q_sc && (p_rb < q_rb || (p_rb == q_rb && p_qb < q_qb)));
+                    first = p_first ? 1 - s : s;
+                    m = (p_sc == q_sc && p_rb == q_rb && p_qb == q_qb) ? 1 : 2;
+                } else if (kq) { first = s; m = 1; }
+                else if (kp) { first = 1 - s; m = 1; }
+                if (m >= 1 && first == 1) {   // the records change places (or the second one moves to the front)
+                    constexpr int NW = (int)(sizeof(DReg) / 8);
+                    static_assert(sizeof(DReg) % 8 == 0, "a region record is a whole number of 8-byte words");
+                    u64* w0 = (u64*)&av[0];
+                    u64* w1 = (u64*)&av[1];
+                    u64 a[NW], b[NW];
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) { a[k] = w0[k]; b[k] = w1[k]; }
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) w0[k] = b[k];
+                    if (m == 2) {
+#pragma unroll
+                        for (int k = 0; k < NW; ++k) w1[k] = a[k];
+                    }
+                }
+                if (m >= 1) av[0].n_comp = 1;
+                if (m == 2) av[1].n_comp = 1;
                 n_regs[r] = m;
-                best_score[r] = m == 0 ? 0 : (m == 2 && a1.score > a0.score ? a1.score : a0.score);
+                const int f_sc = first ? sc1 : sc0, o_sc = first ? sc0 : sc1;
+                best_score[r] = m == 0 ? 0 : (m == 2 && o_sc > f_sc ? o_sc : f_sc);
             }
         } else need = 1;
     }
