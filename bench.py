@@ -264,7 +264,12 @@ def main():
                 out["setup_s"]["index_from_files"] = "failed: %s: %s" % (type(e).__name__, e)
             idx.close()   # (index_from_files has closed it already; the repeat-rich leg builds its own: two do not fit HBM side by side)
             del pac
-            out["repeats"] = repeats_leg(lib, a, local_rank, opts)
+            for div in (5, 10):   # (an informational leg must not cost the headline line: batches of a fifth of the headline's, a tenth if that does not fit beside the index)
+                try:
+                    out["repeats"] = repeats_leg(lib, a, local_rank, opts, div=div)
+                    break
+                except Exception as e:
+                    out["repeats"] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:300]), "barcodes_per_step": a.barcodes // div}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -597,7 +602,7 @@ def end_to_end(lib, idx, a, pac, l_pac, ctg, opts, local_rank):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def repeats_leg(lib, a, local_rank, opts, steps=3):
+def repeats_leg(lib, a, local_rank, opts, steps=3, div=5):
     """BASELINE.json configs[4] on this GPU, in the default run: the hg38-scale genome of workload.config4_genome — 120 segmental-duplication
     families of 50-200 copies x 20 kb at 98-99.5 %, 40 LINE-like and 80 SINE-like families, 40 ALT contigs (is_alt) — with EVERY read drawn on
     the copies (flank <= 2 kb): tens to hundreds of candidates per read, up to 50 + 50 mate-rescue Smith-Watermans per pair (gobwa.go:286-325),
@@ -609,10 +614,29 @@ def repeats_leg(lib, a, local_rank, opts, steps=3):
     t0 = time.time()
     g = workload.config4_genome(lib, a.genome_mb * 1e6 * 0.987)
     idx = lib.index_build_device(g["pac"], g["l_pac"], g["contigs"], device=local_rank)
+    ctx = None
+    try:
+        return _repeats_steps(lib, a, opts, steps, div, g, idx, t0)
+    finally:   # (whatever happens, the index and the context's pools leave HBM: the caller may try again with smaller batches)
+        idx.close()
+
+
+def _repeats_steps(lib, a, opts, steps, div, g, idx, t0):
+    import numpy as np
+    from lariat_amd import capi, workload
     idx.set_alt(g["alt_flags"])
-    n_bc = max(1, a.barcodes // 5)
+    n_bc = max(1, a.barcodes // div)
     n_pairs = n_bc * a.pairs_per_barcode
     ctx = idx.context(n_pairs)
+    try:
+        return _repeats_run(lib, a, opts, steps, g, ctx, n_bc, n_pairs, t0)
+    finally:
+        ctx.close()
+
+
+def _repeats_run(lib, a, opts, steps, g, ctx, n_bc, n_pairs, t0):
+    import numpy as np
+    from lariat_amd import capi, workload
     for slot in range(steps):
         r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400 + slot, n_barcodes=n_bc, pairs_per_barcode=a.pairs_per_barcode)
         ctx.upload_slot(slot, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
@@ -645,8 +669,6 @@ def repeats_leg(lib, a, local_rank, opts, steps=3):
            "setup_s": round(t_setup, 1),
            "workload": "BASELINE.json configs[4] on one GPU: %d Mb genome with 120 segmental-duplication families (50-200 copies x 20 kb, 98-99.5 %%), 40 x 6-kb and 80 x 300-bp "
                        "repeat families, 40 ALT contigs (is_alt); every read drawn on the copies (+- 2 kb); %d steps x %d pairs" % (g["l_pac"] // 1000000, steps, n_pairs)}
-    ctx.close()
-    idx.close()
     return out
 
 
