@@ -448,114 +448,64 @@ __device__ __forceinline__ int aln_fast_cand(const DIndex& ix, const DOpts& o, c
     return 0;
 }
 
-// ---- one lane per read: candidates without DP are finished here, the others are listed for k_aln; a read with more than LH_ALN_LANE_MAX regions
-// (a repeat copy: tens to hundreds of candidates) is listed for k_aln_heavy, which does the same with one lane per CANDIDATE ----
-#ifndef LH_ALN_LANE_MAX
-#define LH_ALN_LANE_MAX 32
-#endif
-__global__ void __launch_bounds__(256) k_aln_fast(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
-                                                   const i64* __restrict__ reg_off, const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, i64 cand_cap,
-                                                   int32_t* __restrict__ status, int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count,
-                                                   DCounters* __restrict__ ctr, const uint32_t* __restrict__ q4, int32_t* __restrict__ heavy_r) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
-    const int live = r < n_reads;
-    unsigned proven_cells = 0;   // cells of global DPs whose outcome is known without running them (see below)
-    int n = 0, n_slow = 0, heavy = 0;
-    uint32_t slow_mask = 0;   // the read's candidates that need DP
-    static_assert(LH_ALN_LANE_MAX <= 32, "slow_mask is one word");
-    i64 c0 = 0;
-    if (live) {
-        const i64 off = seq_off[r];
-        int l_query = (int)(seq_off[r + 1] - off);
-        if (l_query > LH_MAXLEN) l_query = 0;
-        const uint8_t* q = seq + off;
-        const DReg* av = regs + reg_off[r];
-        n = n_regs[r];
-        c0 = R.cand_off[r];
-        if (c0 + (n > 0 ? n : 1) > cand_cap) {   // candidate pool exhausted: flag and skip (host returns LH_E_CAPACITY)
-            atomicOr(&status[r], LH_ST_POOL_OVERFLOW);
-            n = 0;
-        } else if (n == 0) {   // placeholder (lariat.go:1737-1750,1773-1785): contig "", pos -1, aend 0, score 0
-            i64 c = c0;
-            R.rid[c] = -1; R.pos[c] = -1; R.aend[c] = 0; R.rb[c] = -1; R.re[c] = -1; R.reversed[c] = 0; R.score[c] = 0; R.qb[c] = 0; R.qe[c] = 0;
-            R.nm[c] = 0; R.matches[c] = 0; R.mismatches[c] = 0; R.indels[c] = 0; R.soft_clipped[c] = 0; R.soft_clipped_length[c] = 0;
-            R.in_filtered[c] = 1; R.n_cigar[c] = 0; R.n_mm[c] = 0; R.read_len[c] = l_query;
-            R.lap[c] = (dev_single_score(0, 0, 0, 0) + o.improper_pair_penalty) - o.improper_pair_penalty;
-        }
-        if (n > LH_ALN_LANE_MAX) { heavy = 1; n = 0; }
-        else {
-            int best = 0;
-            for (int i = 0; i < n; ++i) { int s = av[i].score; best = best > s ? best : s; }
-            for (int ci = 0; ci < n; ++ci) {
-                const DReg ar = av[ci];
-                if (aln_fast_cand(ix, o, R, q, q4, off, l_query, ar, c0 + ci, best, &status[r], &proven_cells)) { slow_mask |= 1u << ci; n_slow++; }
-            }
-        }
-    }
-    if (ctr) {
-        u64 tot = (u64)(uint32_t)wave_sum_i32((int)(proven_cells >> 16)) << 16;
-        tot += (u64)(uint32_t)wave_sum_i32((int)(proven_cells & 0xffff));
-        if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->glob_cells, tot);
-    }
-    // the wave reserves list space once (same-address atomics are slow), then every lane writes its own items
-    int incl = wave_scan_add_i32(n_slow);
-    int total = wave_readlane(incl, 63), basep = 0;
-    if (total) {
-        if (lane == 0) basep = atomicAdd(slow_count, total);
-        basep = wave_readlane(basep, 0) + incl - n_slow;
-        for (int ci = 0; ci < n; ++ci)
-            if (slow_mask >> ci & 1) { slow_r[basep] = r; slow_ci[basep] = ci; basep++; }
-    }
-    const u64 hb = __ballot(heavy);
-    if (hb) {
-        int hbase = 0;
-        if (lane == 0) hbase = atomicAdd(slow_count + 1, (int)__popcll(hb));
-        hbase = wave_readlane(hbase, 0);
-        if (heavy) heavy_r[hbase + lanes_below(hb, lane)] = r;
+// ---- the candidates that need no DP, one LANE PER CANDIDATE (r04, late; until then a lane per read — 13 of 64 lanes active on unique sequence, where a read has
+// one to five candidates, and a wave per read beside it for reads with dozens).  k_aln_prep, a lane per read: the read's placeholder when it has no
+// region (lariat.go:1737-1750,1773-1785), its best region score, and the read of every candidate slot (-1: the candidate pool cannot hold the read).
+// k_aln_flat: aln_fast_cand for candidate c; the ones that need the DP are listed for k_aln_grp. ----
+__global__ void __launch_bounds__(256) k_aln_prep(DOpts o, int n_reads, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off, const DReg* __restrict__ regs,
+                                                   const int32_t* __restrict__ n_regs, DCand R, i64 cand_cap, int32_t* __restrict__ status, int32_t* __restrict__ best_r,
+                                                   int32_t* __restrict__ cand_rd) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int l_query = (int)(seq_off[r + 1] - seq_off[r]);
+    if (l_query > LH_MAXLEN) l_query = 0;
+    const DReg* av = regs + reg_off[r];
+    const int n = n_regs[r];
+    const i64 c0 = R.cand_off[r];
+    if (c0 + (n > 0 ? n : 1) > cand_cap) {   // candidate pool exhausted: flag and skip (host returns LH_E_CAPACITY)
+        atomicOr(&status[r], LH_ST_POOL_OVERFLOW);
+        for (i64 c = c0; c < c0 + n && c < cand_cap; ++c) cand_rd[c] = -1;
+    } else if (n == 0) {   // placeholder: contig "", pos -1, aend 0, score 0
+        const i64 c = c0;
+        R.rid[c] = -1; R.pos[c] = -1; R.aend[c] = 0; R.rb[c] = -1; R.re[c] = -1; R.reversed[c] = 0; R.score[c] = 0; R.qb[c] = 0; R.qe[c] = 0;
+        R.nm[c] = 0; R.matches[c] = 0; R.mismatches[c] = 0; R.indels[c] = 0; R.soft_clipped[c] = 0; R.soft_clipped_length[c] = 0;
+        R.in_filtered[c] = 1; R.n_cigar[c] = 0; R.n_mm[c] = 0; R.read_len[c] = l_query;
+        R.lap[c] = (dev_single_score(0, 0, 0, 0) + o.improper_pair_penalty) - o.improper_pair_penalty;
+        cand_rd[c] = -1;
+    } else {
+        int best = 0;
+        for (int i = 0; i < n; ++i) { const int sc = av[i].score; best = best > sc ? best : sc; cand_rd[c0 + i] = r; }
+        best_r[r] = best;
     }
 }
-
-// ---- one WAVE per listed read, one lane per candidate: the same per-candidate program as k_aln_fast's (64 candidates of one read side by side,
-// their result fields written next to each other); the ones that need the DP are appended to k_aln's list ----
-__global__ void __launch_bounds__(64) k_aln_heavy(DIndex ix, DOpts o, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
-                                                   const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, int32_t* __restrict__ status,
-                                                   int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count, DCounters* __restrict__ ctr,
-                                                   const uint32_t* __restrict__ q4, const int32_t* __restrict__ heavy_r) {
+__global__ void __launch_bounds__(256) k_aln_flat(DIndex ix, DOpts o, i64 n_cand, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
+                                                   const DReg* __restrict__ regs, DCand R, int32_t* __restrict__ status, int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci,
+                                                   int32_t* __restrict__ slow_count, DCounters* __restrict__ ctr, const uint32_t* __restrict__ q4, const int32_t* __restrict__ best_r,
+                                                   const int32_t* __restrict__ cand_rd) {
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = LANE();
-    const int n_items = slow_count[1];
-    unsigned proven_cells = 0;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int r = heavy_r[item];
+    unsigned proven_cells = 0;   // cells of global DPs whose outcome is known without running them (aln_fast_cand)
+    int slow = 0, r = -1, ci = 0;
+    if (c < n_cand) r = cand_rd[c];
+    if (r >= 0) {
         const i64 off = seq_off[r];
         int l_query = (int)(seq_off[r + 1] - off);
         if (l_query > LH_MAXLEN) l_query = 0;
-        const uint8_t* q = seq + off;
-        const DReg* av = regs + reg_off[r];
-        const int n = n_regs[r];
-        const i64 c0 = R.cand_off[r];
-        int best = 0;
-        for (int i = lane; i < n; i += 64) { int s = av[i].score; best = best > s ? best : s; }
-        best = wave_max_i32(best);
-        for (int cb = 0; cb < n; cb += 64) {
-            const int ci = cb + lane;
-            int slow = 0;
-            if (ci < n) {
-                const DReg ar = av[ci];
-                slow = aln_fast_cand(ix, o, R, q, q4, off, l_query, ar, c0 + ci, best, &status[r], &proven_cells);
-            }
-            const u64 sb = __ballot(slow);
-            if (sb) {
-                int basep = 0;
-                if (lane == 0) basep = atomicAdd(slow_count, (int)__popcll(sb));
-                basep = wave_readlane(basep, 0) + lanes_below(sb, lane);
-                if (slow) { slow_r[basep] = r; slow_ci[basep] = ci; }
-            }
-        }
+        ci = (int)(c - R.cand_off[r]);
+        const DReg ar = regs[reg_off[r] + ci];
+        slow = aln_fast_cand(ix, o, R, seq + off, q4, off, l_query, ar, c, best_r[r], &status[r], &proven_cells);
     }
     if (ctr) {
         u64 tot = (u64)(uint32_t)wave_sum_i32((int)(proven_cells >> 16)) << 16;
         tot += (u64)(uint32_t)wave_sum_i32((int)(proven_cells & 0xffff));
         if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->glob_cells, tot);
+    }
+    const u64 sb = __ballot(slow);   // the wave reserves list space once (same-address atomics are slow)
+    if (sb) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(slow_count, (int)__popcll(sb));
+        basep = wave_readlane(basep, 0) + lanes_below(sb, lane);
+        if (slow) { slow_r[basep] = r; slow_ci[basep] = ci; }
     }
 }
 

@@ -378,11 +378,10 @@ def test_emu_k7_narrow_band_and_its_proof(emu, oracle, g, ins_first):
 @pytest.mark.parametrize("build", ["default", "small"])
 def test_emu_repeat_families(emu, oracle, build):
     """reads on the copies of repeat families (helpers.repeat_family_case: 6-7 candidates per read, 800-3,000 rescue attempts per batch), the paths r04 built
-    for them: K4's long queue (a read's chains as units, the per-read check, the calls a lane cannot hold by a wave), K7's per-candidate lanes and
+    for them: K4's long queue (a read's chains as units, the per-read check, the calls a lane cannot hold by a wave), K7's lane per candidate and
     its four-per-wave DP in a proved band of 7, K6's replay on an unsorted LDS list (two kernel instances by list length), K3's chain keys.
     The default build hands the wave-chained reads of so small a batch to the wave kernel after round 0 (fewer than 1,024 jobs); the `small`
-    build runs the rounds to the end, keeps 64 / 128 regions in the replay's lists (most pairs take the second instance, some neither) and sends
-    every read with more than two regions through K7's per-candidate kernel.  Results, rescue counts and rescue cells against the oracle."""
+    build runs the rounds to the end, keeps 64 / 128 regions in the replay's lists (most pairs take the second instance, some neither).  Results, rescue counts and rescue cells against the oracle."""
     lib = emu
     if build == "small":
         subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "hipemu"), "small"])
