@@ -397,3 +397,19 @@ def test_emu_repeat_families(emu, oracle, build):
         helpers.assert_same_result(res, ref, inference=True)
         for k in ("glob_cells", "n_rescue", "rescue_cells"):
             assert res.counters[k] == ref.counters[k], k
+
+
+def test_emu_context_moves_between_regimes(emu, oracle):
+    """which way K4 takes the wave-chained reads rests on the PREVIOUS batch of the context (lh_host_stage2.inc: the long queue when that batch had many of
+    them, the wave-per-read kernel at once when it had few) — a choice of path, never of result.  One context, a repeat-family batch, then reads on unique
+    sequence, then repeat families twice more: the third batch takes the wave kernel with hundreds of wave-chained reads, the fourth the long queue again;
+    each result equals the oracle's."""
+    names, contigs, rs_rep = helpers.repeat_family_case(13, 10)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    rs_uni = helpers.small_reads(names, contigs, n_barcodes=10, pairs=30, junk=0.03, seed=77)
+    _, _, rs_rep2 = helpers.repeat_family_case(13, 10)
+    ctx = idx.context(max(rs_rep.n_pairs, rs_uni.n_pairs))
+    for rs in (rs_rep, rs_uni, rs_rep2, rs_rep):
+        b = helpers.batch_of(rs)
+        helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b, threads=8), inference=True)

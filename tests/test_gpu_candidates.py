@@ -209,3 +209,16 @@ def test_k7_narrow_band_and_its_proof(lib, oracle, g, ins_first):
     assert res.counters["glob_cells"] == ores.counters["glob_cells"]
     c = list(res.cands_of_read(0))[0]
     assert int(res.indels[c]) == 2 and int(res.pos[c]) == p
+
+
+def test_context_moves_between_regimes(lib, oracle):
+    """K4's choice of path for the wave-chained reads follows the context's previous batch (tests/test_emu_front.py has the argument): repeat families,
+    unique sequence, repeat families twice — every result equal to the oracle's"""
+    names, contigs, rs_rep = helpers.repeat_family_case(13, 24)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = lib.index_from_arrays(oidx.arrays())
+    rs_uni = helpers.small_reads(names, contigs, n_barcodes=24, pairs=30, junk=0.03, seed=77)
+    ctx = idx.context(max(rs_rep.n_pairs, rs_uni.n_pairs))
+    for rs in (rs_rep, rs_uni, rs_rep, rs_rep):
+        b = helpers.batch_of(rs)
+        helpers.assert_same_result(ctx.align_barcodes(b), oidx.align_barcodes(b, threads=8), inference=True)
