@@ -3,9 +3,11 @@
 // GetAlignments CIGAR walk (go/src/inference/lariat.go:1552-1704): matches / mismatches / indels / soft clips /
 // mismatch loci / log_alignment_probability / the best-17 filter.
 //
-// Two kernels.  k_aln_fast (one LANE per read) settles every candidate that needs no DP — query and reference spans of
-// equal length and an inferred band of 0, i.e. bwa_gen_cigar2's "no gap; no need to do DP" branch, the great majority — and
-// writes the others to a list; k_aln (one WAVE per listed candidate) runs the banded global alignment with traceback.
+// Four kernels (r04).  k_aln_prep (a lane per read: placeholders, best scores, the read of every candidate slot) and k_aln_flat (one LANE PER
+// CANDIDATE) settle every candidate that needs no DP — query and reference spans of equal length and an inferred band of 0, i.e.
+// bwa_gen_cigar2's "no gap; no need to do DP" branch, or a diagonal that provably beats every gapped path: the great majority — and list the
+// others; k_aln_grp runs FOUR of those per wave, the banded global alignment with traceback in a band of 7 that is proved sufficient, and
+// hands what it cannot settle to k_aln (one WAVE per candidate, the band mem_reg2aln asks for).
 // Measured: one wave per read for everything was a chain of ~10 dependent phases per candidate (11.7 ms per 2 M reads).
 #pragma once
 #include "k_rescue2.h"
