@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=1, help="lh_context_opts.lanes: 1 = one pipeline, every kernel with the device to itself (per-kernel times and the roofline "
                                                           "are then execution times); 2 = every batch is cut at a barcode boundary and its halves are aligned side by side "
                                                           "inside ONE lh_align_resident call (+5 %: reported under two_lanes_pairs_per_s)")
-    ap.add_argument("--repeats", action="store_true", help="only the configs[4] leg (repeat families, every read on the copies: tens to hundreds of candidates per read)")
+    ap.add_argument("--repeats", action="store_true", help="only the configs[4] legs (repeats: every read on the copies of repeat families, tens to hundreds of candidates per read; mixed: 5 %% of every barcode's pairs on them); with --gpus N every rank runs them on its own batches")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --steps batches in total, split over the ranks (default weak: --steps per rank)")
     ap.add_argument("--cpu-sample-barcodes", type=int, default=10000, help="barcodes of the first batch timed on the host cores (cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,8 +142,13 @@ def main():
     if lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: liblariat_hip has no CPU fallback")
 
-    if a.repeats:   # development: the configs[4] leg alone
-        print(json.dumps({"repeats": repeats_leg(lib, a, local_rank, lib.opts())}), flush=True)
+    if a.repeats:   # the configs[4] legs alone; under the launcher every rank runs them on its own batches (value = all ranks' pairs over the slowest rank's time)
+        legs = config4_legs(lib, a, local_rank, lib.opts(), rank=rank, dist=dist, share=share)
+        if rank == 0:
+            print(json.dumps(legs), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     # ---- synthetic genome + FM-index, built in this rank's HBM (lh_index_build_device; nothing persists between runs) ----
     t0 = time.time()
@@ -266,7 +271,7 @@ def main():
             del pac
             for div in (5, 10):   # (an informational leg must not cost the headline line: batches of a fifth of the headline's, a tenth if that does not fit beside the index)
                 try:
-                    out["repeats"] = repeats_leg(lib, a, local_rank, opts, div=div)
+                    out.update(config4_legs(lib, a, local_rank, opts, div=div))
                     break
                 except Exception as e:
                     out["repeats"] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:300]), "barcodes_per_step": a.barcodes // div}
@@ -542,8 +547,8 @@ def end_to_end(lib, idx, a, pac, l_pac, ctg, opts, local_rank):
                 errs.append(e)
 
         t_start = time.perf_counter()
-        rth = [threading.Thread(target=reader, args=(t,)) for t in range(n_readers)]
-        bth = [threading.Thread(target=bam, args=(t,)) for t in range(n_bam)]
+        rth = [threading.Thread(target=reader, args=(t,), daemon=True) for t in range(n_readers)]
+        bth = [threading.Thread(target=bam, args=(t,), daemon=True) for t in range(n_bam)]
         [t.start() for t in rth + bth]
         done_readers, n_pairs, n_batches = 0, 0, 0
         prev = None      # the batch whose result is still on the device
@@ -558,37 +563,48 @@ def end_to_end(lib, idx, a, pac, l_pac, ctg, opts, local_rank):
                     continue
                 return item
             return None
-        cur = next_batch()
-        if cur is not None:
-            ctx.upload_slot(1, cur[1])
-        slot = 1
-        while cur is not None and not errs:
-            ctx.select(slot)
-            nxt = next_batch()
-            st = None
-            if nxt is not None:
-                st = threading.Thread(target=lambda: ctx.stage_slot(3 - slot, nxt[1]))
-                st.start()
-            ts = time.perf_counter()
-            ctx.align_resident(opts)
-            busy["align"] += time.perf_counter() - ts
-            if prev is not None:
+        try:
+            cur = next_batch()
+            if cur is not None:
+                ctx.upload_slot(1, cur[1])
+            slot = 1
+            while cur is not None and not errs:
+                ctx.select(slot)
+                nxt = next_batch()
+                st = None
+                if nxt is not None:
+                    st = threading.Thread(target=lambda: ctx.stage_slot(3 - slot, nxt[1]))
+                    st.start()
+                ts = time.perf_counter()
+                try:
+                    ctx.align_resident(opts)
+                finally:
+                    if st is not None:   # (never leave the staging thread running beside a failing main loop)
+                        st.join()
+                busy["align"] += time.perf_counter() - ts
+                if prev is not None:
+                    res = ctx.download_end()
+                    q_out[prev[0] % n_bam].put((prev[0], res, prev[1]))
+                ctx.download_begin()
+                n_pairs += cur[1].n_pairs
+                n_batches += 1
+                prev, cur, slot = cur, nxt, 3 - slot
+            if prev is not None and not errs:
                 res = ctx.download_end()
                 q_out[prev[0] % n_bam].put((prev[0], res, prev[1]))
-            ctx.download_begin()
-            if st is not None:
-                st.join()
-            n_pairs += cur[1].n_pairs
-            n_batches += 1
-            prev, cur, slot = cur, nxt, 3 - slot
-        if prev is not None:
-            res = ctx.download_end()
-            q_out[prev[0] % n_bam].put((prev[0], res, prev[1]))
-        for q in q_out:
-            q.put(None)
-        [t.join() for t in rth + bth]
-        dt = time.perf_counter() - t_start
-        ctx.close()
+        finally:
+            # whatever happened above (LH_E_CAPACITY from align_resident, a writer's error): the writers get their sentinels, the readers' bounded queue is
+            # drained so that none of them blocks in put(), every thread is joined (they are daemons besides) and the context's pools leave HBM
+            for q in q_out:
+                q.put(None)
+            while any(t.is_alive() for t in rth):
+                try:
+                    q_in.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            [t.join() for t in rth + bth]
+            dt = time.perf_counter() - t_start
+            ctx.close()
         if errs:
             raise errs[0]
         bam_bytes = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(d) for f in fs if f.endswith(".bam"))
@@ -602,74 +618,113 @@ def end_to_end(lib, idx, a, pac, l_pac, ctg, opts, local_rank):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def repeats_leg(lib, a, local_rank, opts, steps=3, div=5):
+def config4_legs(lib, a, local_rank, opts, steps=3, div=5, legs=("repeats", "mixed"), rank=0, dist=None, share=False):
     """BASELINE.json configs[4] on this GPU, in the default run: the hg38-scale genome of workload.config4_genome — 120 segmental-duplication
-    families of 50-200 copies x 20 kb at 98-99.5 %, 40 LINE-like and 80 SINE-like families, 40 ALT contigs (is_alt) — with EVERY read drawn on
-    the copies (flank <= 2 kb): tens to hundreds of candidates per read, up to 50 + 50 mate-rescue Smith-Watermans per pair (gobwa.go:286-325),
-    n_a x n_m pair scores per read in tagBestAlignments / estimateMapQualities.  Its own index (the headline index has been freed by now);
-    batches of a fifth of the headline's size (a pair costs ~500 times the DP cells of a pair on unique sequence; 4,000 barcodes: one wave per barcode
-    in K8 — fewer leave the chip half empty there: 2,000 -> 4,000 barcodes per step is 277 k -> 322 k pairs/s)."""
-    import numpy as np
-    from lariat_amd import capi, workload
+    families of 50-200 copies x 20 kb at 98-99.5 %, 40 LINE-like and 80 SINE-like families, 40 ALT contigs (is_alt) — its own index (the headline
+    index has been freed by now), and two legs on it:
+      repeats: EVERY read drawn on the copies (flank <= 2 kb): tens to hundreds of candidates per read, up to 50 + 50 mate-rescue Smith-Watermans
+               per pair (gobwa.go:286-325), n_a x n_m pair scores per read in tagBestAlignments / estimateMapQualities; batches of a fifth of the
+               headline's size (a pair costs ~500 times the DP cells of a pair on unique sequence);
+      mixed:   headline-sized batches in which 5 % of the pairs of EVERY barcode are drawn on the copies and the rest on unique sequence — what a
+               barcode-sorted input from a real genome looks like to the path: the repeat regime's per-pair cost decides the rate.
+    Under the launcher (--repeats --gpus N) every rank runs the legs on its own batches; the value is the pairs of all ranks over the slowest rank's time."""
+    from lariat_amd import workload
     t0 = time.time()
     g = workload.config4_genome(lib, a.genome_mb * 1e6 * 0.987)
     idx = lib.index_build_device(g["pac"], g["l_pac"], g["contigs"], device=local_rank)
-    ctx = None
+    out = {}
     try:
-        return _repeats_steps(lib, a, opts, steps, div, g, idx, t0)
+        idx.set_alt(g["alt_flags"])
+        t_setup = time.time() - t0
+        if "repeats" in legs:
+            out["repeats"] = _c4_leg(lib, a, opts, steps, g, idx, max(1, a.barcodes // div), 1.0, t_setup, rank, dist, share)
+        if "mixed" in legs:
+            try:
+                out["mixed"] = _c4_leg(lib, a, opts, 2, g, idx, a.barcodes, 0.05, t_setup, rank, dist, share)
+            except Exception as e:   # (the newer leg must not cost the older one)
+                if "repeats" not in out:
+                    raise
+                out["mixed"] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        return out
     finally:   # (whatever happens, the index and the context's pools leave HBM: the caller may try again with smaller batches)
         idx.close()
 
 
-def _repeats_steps(lib, a, opts, steps, div, g, idx, t0):
+def _c4_reads(lib, a, g, n_bc, frac, seed):
+    """one batch of the configs[4] legs: frac of every barcode's pairs on the repeat copies (g["windows"]), the rest on unique sequence (the primary contigs outside those windows)"""
+    from lariat_amd import workload
+    n_rep = int(round(a.pairs_per_barcode * frac))
+    if n_rep >= a.pairs_per_barcode:
+        return lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=seed, n_barcodes=n_bc, pairs_per_barcode=a.pairs_per_barcode)
+    if "unique" not in g:   # the primary contigs outside every window the repeat reads come from: nothing was planted there
+        g["unique"] = workload.outside_windows(g["contigs"], g["alt_flags"], g["windows"])
+    primary = g["unique"]
+    ra = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=seed, n_barcodes=n_bc, pairs_per_barcode=n_rep)
+    rb = lib.synth_reads(g["pac"], g["l_pac"], primary, seed=seed + 100000, n_barcodes=n_bc, pairs_per_barcode=a.pairs_per_barcode - n_rep)
+    return workload.interleave_reads(ra, rb)
+
+
+def _c4_leg(lib, a, opts, steps, g, idx, n_bc, frac, t_setup, rank=0, dist=None, share=False):
     import numpy as np
+    import torch
     from lariat_amd import capi, workload
-    idx.set_alt(g["alt_flags"])
-    n_bc = max(1, a.barcodes // div)
     n_pairs = n_bc * a.pairs_per_barcode
+    world = dist.get_world_size() if dist is not None else 1
     ctx = idx.context(n_pairs)
     try:
-        return _repeats_run(lib, a, opts, steps, g, ctx, n_bc, n_pairs, t0)
+        t0 = time.time()
+        for slot in range(steps):
+            r = _c4_reads(lib, a, g, n_bc, frac, workload.READS_SEED + (400 if frac >= 1.0 else 700) + slot + 1000 * rank)
+            ctx.upload_slot(slot, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
+        t_reads = time.time() - t0
+        ctx.select(0)
+        ctx.align_resident(opts)   # warm-up: pools grow to this workload's seed, region and job counts
+        kern = {}
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            ctx.select(s)
+            ctx.align_resident(opts)
+            for name, ms in ctx.timings():
+                kern.setdefault(name, []).append(ms)
+        dt = time.perf_counter() - t0
+        per_rank = None
+        if dist is not None:
+            te = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+            allr = [torch.zeros_like(te) for _ in range(world)]
+            dist.all_gather(allr, te)
+            per_rank = [round(float(t.item()), 3) for t in allr]
+            dt = max(per_rank)
+        res = ctx.download()
+        nc = np.diff(res.cand_off)
+        mol = np.maximum.reduceat(res.molecule_id, res.cand_off[:-1][::2 * a.pairs_per_barcode]) + 1   # molecules that survive scrapMolecules, per barcode
+        cnt = res.counters
+        k6 = sum(kern["k_rescue"]) / len(kern["k_rescue"]) * 1e-3
+        out = {"value": round(world * steps * n_pairs / dt, 1), "unit": "read-pairs/s", "n_gpus": world, "steps": steps, "pairs_per_step": n_pairs, "barcodes_per_step": n_bc,
+               "repeat_pair_frac": frac, "ms_per_step": round(dt / steps * 1e3, 3),
+               "kernel_ms": {k: round(sum(v) / len(v), 3) for k, v in kern.items()},
+               "candidates_per_read": {"mean": round(float(nc.mean()), 2), "median": int(np.median(nc)), "p99": int(np.percentile(nc, 99)), "max": int(nc.max())},
+               "per_pair": {"rescue_attempts": round(cnt["n_rescue"] / n_pairs, 2), "rescue_cells": round(cnt["rescue_cells"] / n_pairs), "extension_cells": round(cnt["ext_cells"] / n_pairs),
+                            "global_cells": round(cnt["glob_cells"] / n_pairs), "bwt_extend": round(cnt["n_ext"] / n_pairs)},
+               "molecules_per_barcode": {"mean": round(float(mol.mean()), 1), "max": int(mol.max())},
+               "n_rescue": cnt["n_rescue"], "rescue_cells": cnt["rescue_cells"], "rescue_cells_exec": cnt.get("rescue_cells_exec"),
+               # rescue_cells = the cells ksw_align2 evaluates in the reference (equal to the oracle's count); the stage's rate in those cells, and the stage against the VALU
+               # issue rate of the ksw_u8 recurrence (9.25 packed-16 lane-instructions per cell, 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz) — for the WHOLE K6 bracket
+               # (enumeration, Smith-Waterman launches, replay); the Smith-Waterman launches alone: profiles/r05_*_repeats_*.csv
+               "rescue_GCUPS": round(cnt["rescue_cells"] / k6 / 1e9, 1),
+               "rescue_stage_valu_frac": round(cnt["rescue_cells"] * 9.25 / k6 / (256 * 4 * 16 * 2.4e9), 3),
+               "setup_s": {"genome+index": round(t_setup, 1), "reads": round(t_reads, 1)},
+               "workload": "BASELINE.json configs[4] on one GPU: %d Mb genome with 120 segmental-duplication families (50-200 copies x 20 kb, 98-99.5 %%), 40 x 6-kb and 80 x 300-bp "
+                           "repeat families, 40 ALT contigs (is_alt); %s; %d steps x %d pairs"
+                           % (g["l_pac"] // 1000000, "every read drawn on the copies (+- 2 kb)" if frac >= 1.0 else
+                              "%d of every barcode's %d pairs drawn on the copies (+- 2 kb), the others on unique sequence (the primary contigs outside the windows)" % (int(round(a.pairs_per_barcode * frac)), a.pairs_per_barcode),
+                              steps, n_pairs)}
+        if per_rank:
+            out["per_rank_timed_s"] = per_rank
+        return out
     finally:
         ctx.close()
-
-
-def _repeats_run(lib, a, opts, steps, g, ctx, n_bc, n_pairs, t0):
-    import numpy as np
-    from lariat_amd import capi, workload
-    for slot in range(steps):
-        r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400 + slot, n_barcodes=n_bc, pairs_per_barcode=a.pairs_per_barcode)
-        ctx.upload_slot(slot, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
-    t_setup = time.time() - t0
-    ctx.select(0)
-    ctx.align_resident(opts)   # warm-up: pools grow to this workload's seed, region and job counts
-    kern = {}
-    t0 = time.perf_counter()
-    for s in range(steps):
-        ctx.select(s)
-        ctx.align_resident(opts)
-        for name, ms in ctx.timings():
-            kern.setdefault(name, []).append(ms)
-    dt = time.perf_counter() - t0
-    res = ctx.download()
-    nc = np.diff(res.cand_off)
-    mol = np.maximum.reduceat(res.molecule_id, res.cand_off[:-1][::2 * a.pairs_per_barcode]) + 1   # molecules that survive scrapMolecules, per barcode
-    cnt = res.counters
-    out = {"value": round(steps * n_pairs / dt, 1), "unit": "read-pairs/s", "steps": steps, "pairs_per_step": n_pairs, "ms_per_step": round(dt / steps * 1e3, 3),
-           "kernel_ms": {k: round(sum(v) / len(v), 3) for k, v in kern.items()},
-           "candidates_per_read": {"mean": round(float(nc.mean()), 2), "median": int(np.median(nc)), "p99": int(np.percentile(nc, 99)), "max": int(nc.max())},
-           "per_pair": {"rescue_attempts": round(cnt["n_rescue"] / n_pairs, 2), "rescue_cells": round(cnt["rescue_cells"] / n_pairs), "extension_cells": round(cnt["ext_cells"] / n_pairs),
-                        "global_cells": round(cnt["glob_cells"] / n_pairs), "bwt_extend": round(cnt["n_ext"] / n_pairs)},
-           "molecules_per_barcode": {"mean": round(float(mol.mean()), 1), "max": int(mol.max())},
-           "n_rescue": cnt["n_rescue"], "rescue_cells": cnt["rescue_cells"],
-           "rescue_GCUPS": round(cnt["rescue_cells"] / (sum(kern["k_rescue"]) / len(kern["k_rescue"]) * 1e-3) / 1e9, 1),
-           # the stage against the VALU issue rate its recurrence allows: 9.25 packed-16 lane-instructions per ksw_u8 cell (k_rescue2.h), 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz;
-           # the whole K6 bracket (enumeration, both Smith-Waterman launches per direction, the replay); the Smith-Waterman launches alone: profiles/r04_*_repeats_*.csv
-           "rescue_stage_valu_frac": round(cnt["rescue_cells"] * 9.25 / (sum(kern["k_rescue"]) / len(kern["k_rescue"]) * 1e-3) / (256 * 4 * 16 * 2.4e9), 3),
-           "setup_s": round(t_setup, 1),
-           "workload": "BASELINE.json configs[4] on one GPU: %d Mb genome with 120 segmental-duplication families (50-200 copies x 20 kb, 98-99.5 %%), 40 x 6-kb and 80 x 300-bp "
-                       "repeat families, 40 ALT contigs (is_alt); every read drawn on the copies (+- 2 kb); %d steps x %d pairs" % (g["l_pac"] // 1000000, steps, n_pairs)}
-    return out
 
 
 def extras(lib, idx, batch, n_pairs, opts, step_s):

@@ -277,6 +277,13 @@ static_assert(24 * LH_RFA_MQ_CHUNK <= LH_RFA_LDS_BYTES, "mate staging of estimat
 // A barcode whose tables do not fit the wave's slab (the reader caps a work unit at 30,000 pairs, fastqreader/reader.go:205,
 // far above the common few hundred) is appended to ovf_list and processed by a second launch whose few waves own much
 // larger slabs (work_list = that list); only there an overflow is final (LH_ST_POOL_OVERFLOW).
+// development aid (tools/prof_rfa.sh builds a library with -DLH_RFA_PROF): shader-clock time per phase of the barcode program, summed over the waves
+#ifdef LH_RFA_PROF
+__device__ unsigned long long lh_rfa_prof[24];
+#define RFA_PROF(k_) { const unsigned long long now_ = (unsigned long long)clock64(); if (lane == 0) atomicAdd(&lh_rfa_prof[k_], now_ - prof_t_); prof_t_ = (unsigned long long)clock64(); }
+#else
+#define RFA_PROF(k_)
+#endif
 #ifndef LH_RFA_WAVES
 #define LH_RFA_WAVES 4   // waves per SIMD the register budget is sized for (128 VGPRs + 64 spilled: the kernel waits on memory, 4 waves hide more of it than 2 waves of 190 registers)
 #endif
@@ -319,6 +326,9 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         i64 c_lo = R.cand_off[r0], c_hi = R.cand_off[r0 + nR];
         int NC = (int)(c_hi - c_lo);
         if (c_hi > cand_cap) continue;   // flagged by k_aln
+#ifdef LH_RFA_PROF
+        unsigned long long prof_t_ = (unsigned long long)clock64();
+#endif
         // ---- init per-candidate and per-read state (Alignment defaults, lariat.go:1655-1689) ----
         for (int r = lane; r < nR; r += 64) {
             for (i64 g = R.cand_off[r0 + r]; g < R.cand_off[r0 + r + 1]; ++g) {
@@ -329,6 +339,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             S.split_second_best[r0 + r] = 0; S.split_score[r0 + r] = 0; S.split_mapq[r0 + r] = 0;
         }
         WAVE_SYNC();
+        RFA_PROF(0)
         // ---- tagBestAlignments: one lane per pair.  Read 2 of a pair is always "touched" by read 1 (every read has >= 1
         // filtered candidate), so only read 1's scan decides; its jitter stream is Go's, seeded from the read name. ----
         {   // a read that draws more often than the state-free path allows keeps its generator state in the (still unused) slab
@@ -361,6 +372,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             n_heavy += __popcll(mh);
         }
         WAVE_SYNC();
+        RFA_PROF(1)
         for (int hi = 0; hi < n_heavy; ++hi) {
             const int p = heavy[hi];
             // the pair's filtered candidates and their single-read scores (scoreAlignment's two sums: exact multiples of 0.5), compacted in the slab
@@ -434,6 +446,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             WAVE_SYNC();
         }
         WAVE_SYNC();
+        RFA_PROF(2)
         // ---- slab carve (sizes depend on NC, nR) ----
         size_t so = 0;
         RfaTab T;
@@ -515,6 +528,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
         }
         WAVE_SYNC();
+        RFA_PROF(3)
         // sort.Sort(ByPosition) per contig (lariat.go:1545-1547), one lane per contig; keys staged in LDS when they fit
         if (NCf <= LH_RFA_SORT_LDS && ncont <= 8) {
             // Few contigs: the wave sorts one contig at a time by ranking (every lane counts the smaller keys of its elements).
@@ -566,6 +580,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                         [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = pl[i]; pl[i] = pl[j]; pl[j] = u; }, T.molraw, T.rdl, T.firstf);
         }
         WAVE_SYNC();
+        RFA_PROF(4)
         int do_rfa = bc_do_rfa[bc] != 0;
         int M = 0;
         if (do_rfa) {
@@ -619,6 +634,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             if (lane == 0) { T.psum[NCf] = nfirst; T.actc[NCf] = nactive; }
             WAVE_SYNC();
+            RFA_PROF(5)
             // ---- scrapMolecules: keep molecules with an active alignment, renumber ----
             int ao = 0;
             for (int base = 0; base < Mraw; base += 64) {
@@ -689,6 +705,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 for (int k = 0; k < T.alen[m]; ++k) S.mol_diff[c_lo + T.act_store[T.aoff[m] + k]] = diff;
             }
             WAVE_SYNC();
+            RFA_PROF(6)
             // ---- optimizer.Optimize(opt, 1, 2, 4*M): 8*M greedy molecule moves ----
             // The optimizer is deterministic: once M consecutive turns (every molecule tried once as the source) accept no
             // move, the state can no longer change and the remaining turns are no-ops, so they are not executed.
@@ -736,6 +753,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 WAVE_SYNC();
                 source = (source + 1) % M;
             }
+            RFA_PROF(7)
             // ---- moleculeMapqProbabilitySums ----
             for (int s = 0; s < M; ++s) {
                 for (int sb = 0; sb < M; sb += 64) {
@@ -753,6 +771,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 }
                 WAVE_SYNC();
             }
+            RFA_PROF(8)
             // ---- updateAlignmentsMoleculeStatus: confidences, differences, active molecules ----
             for (int m = lane; m < M; m += 64) {
                 double conf = (double)T.alen[m] / (double)T.nbest[m];
@@ -810,6 +829,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         }
         WAVE_SYNC();
         double lmp = shd[0];
+        RFA_PROF(9)
         // ---- per read: link active mates (lariat.go:892-900).  Done for all reads before any scoring that reads mate links. ----
         for (int r = lane; r < nR; r += 64) {
             i64 act = -1;
@@ -835,6 +855,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             n_heavy_r += __popcll(mh);
         }
         WAVE_SYNC();
+        RFA_PROF(10)
         for (int r = lane; r < nR; r += 64) {
             int gr = r0 + r, gm = r0 + (r ^ 1);
             i64 a0 = R.cand_off[gr], a1 = R.cand_off[gr + 1], m0 = R.cand_off[gm], m1 = R.cand_off[gm + 1];
@@ -905,6 +926,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
 #undef TOPV
         }
         WAVE_SYNC();
+        RFA_PROF(11)
         for (int hi = 0; hi < n_heavy_r; ++hi) {
             const int r = heavy_r[hi];
             const int gr = r0 + r, gm = r0 + (r ^ 1);
@@ -1032,6 +1054,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             WAVE_SYNC();
         }
+        RFA_PROF(12)
         // ---- markDuplicates: first-seen wins on (read1?, reversed, contig, pos, mate contig, mate pos) in read order ----
         {   // open-addressing table over the keys; a slot ends up holding the smallest read index of its key
             const int hmask = (1 << hbits) - 1;
@@ -1071,6 +1094,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
         }
         WAVE_SYNC();
+        RFA_PROF(13)
         // ---- CheckSplitReads / GetSplitAlignment over the unfiltered candidates (split.go) ----
         for (int r = lane; r < nR; r += 64) {
             int gr = r0 + r;
@@ -1111,5 +1135,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             S.split_score[gr] = dev_score_aln(R, S, improper, c, S.mate[P], 0.0);
         }
         WAVE_SYNC();
+        RFA_PROF(14)
     }
 }

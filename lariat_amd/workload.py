@@ -235,3 +235,65 @@ def config4_genome(lib, total_bases, seed=GENOME_SEED + 4, scale=1.0, n_alt=40, 
     if not quiet:
         print("config4 genome: %d Mb, %d families, %d copies, %d windows (%.0f Mb)" % (l_pac // 1000000, len(fams), sum(len(c) for _, c in fams), len(win), sum(w[1] for w in win) / 1e6))
     return dict(pac=pac, l_pac=l_pac, contigs=ctg_all, alt_flags=alt_flags, windows=win, families=fams)
+
+
+def interleave_reads(ra, rb, chunk_reads=400000):
+    """two read sets of lh_synth_reads (dicts of seq / seq_off / bc_pair_off / name_seed [/ truth_*]) over the SAME number of barcodes as one
+    barcode-sorted set: barcode k holds ra's pairs of barcode k, then rb's.  The mixed workload of bench.py / the tests: a few pairs of every
+    barcode drawn on repeat copies, the rest on unique sequence."""
+    import numpy as np
+    nb = len(ra["bc_pair_off"]) - 1
+    assert nb == len(rb["bc_pair_off"]) - 1
+    ca, cb = np.diff(ra["bc_pair_off"]).astype(np.int64), np.diff(rb["bc_pair_off"]).astype(np.int64)
+    npa, npb = int(ca.sum()), int(cb.sum())
+    # source pair of every output pair: index into the concatenation [ra's pairs | rb's pairs]
+    key = np.concatenate([np.repeat(np.arange(nb, dtype=np.int64) * 2, ca), np.repeat(np.arange(nb, dtype=np.int64) * 2 + 1, cb)])
+    src_pair = np.argsort(key, kind="stable")
+    bco = np.zeros(nb + 1, dtype=np.int32)
+    np.cumsum(ca + cb, out=bco[1:])
+    so_a, so_b = np.asarray(ra["seq_off"], dtype=np.int64), np.asarray(rb["seq_off"], dtype=np.int64)
+    starts = np.concatenate([so_a[:-1], so_b[:-1] + so_a[-1]])          # start of every source read in the concatenated bases
+    lens = np.concatenate([np.diff(so_a), np.diff(so_b)])
+    src_read = np.stack([2 * src_pair, 2 * src_pair + 1], axis=1).reshape(-1)
+    out_len = lens[src_read]
+    seq_off = np.zeros(len(src_read) + 1, dtype=np.int64)
+    np.cumsum(out_len, out=seq_off[1:])
+    seq_all = np.concatenate([np.asarray(ra["seq"][: so_a[-1]], dtype=np.uint8), np.asarray(rb["seq"][: so_b[-1]], dtype=np.uint8)])
+    seq = np.empty(int(seq_off[-1]), dtype=np.uint8)
+    for r0 in range(0, len(src_read), chunk_reads):
+        r1 = min(len(src_read), r0 + chunk_reads)
+        o0, o1 = int(seq_off[r0]), int(seq_off[r1])
+        idx = np.repeat(starts[src_read[r0:r1]] - seq_off[r0:r1], out_len[r0:r1]) + np.arange(o0, o1, dtype=np.int64)
+        seq[o0:o1] = seq_all[idx]
+    out = dict(seq=seq, seq_off=seq_off, bc_pair_off=bco, name_seed=np.concatenate([ra["name_seed"], rb["name_seed"]])[src_pair], n_pairs=npa + npb,
+               from_first=(src_pair < npa))
+    for k in ("truth_rid", "truth_pos1", "truth_pos2"):
+        if k in ra and k in rb:
+            out[k] = np.concatenate([ra[k], rb[k]])[src_pair]
+    return out
+
+
+def outside_windows(contigs, alt_flags, windows, min_len=400000):
+    """[(name, len, offset)]: the stretches of the primary contigs that lie outside every window of `windows` and are at least `min_len` long (a molecule of
+    lh_synth_reads is up to 200 kb) — where config4_genome planted nothing: the "unique sequence" the mixed workload draws most of its pairs on"""
+    import numpy as np
+    w = sorted((int(o), int(o + n)) for _, n, o in windows)
+    ws = np.array([a for a, _ in w], dtype=np.int64)
+    we = np.maximum.accumulate(np.array([b for _, b in w], dtype=np.int64)) if w else np.zeros(0, np.int64)
+    out = []
+    for (name, ln, off), alt in zip(contigs, alt_flags):
+        if alt:
+            continue
+        lo = int(np.searchsorted(we, off, side="right"))
+        cur = off
+        k = lo
+        while cur < off + ln:
+            nxt = int(ws[k]) if k < len(ws) and ws[k] < off + ln else off + ln
+            if nxt - cur >= min_len:
+                b = (cur + 3) // 4 * 4
+                out.append(("%s_u%d" % (name, len(out)), int(nxt - b) // 4 * 4, int(b)))
+            if k >= len(ws) or ws[k] >= off + ln:
+                break
+            cur = max(cur, int(we[k]))
+            k += 1
+    return out

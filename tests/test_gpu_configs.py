@@ -280,3 +280,21 @@ def test_config4_repeat_families_at_its_multiplicity(lib, oracle):
     print("oracle: %.1f s on %d threads" % (time.time() - t0, THREADS))
     helpers.assert_same_result(res, ref, inference=True)
     assert cnt["n_rescue"] == ref.counters["n_rescue"] and cnt["rescue_cells"] == ref.counters["rescue_cells"]
+    ctx.close()
+    # the MIXED workload of bench.py's `mixed` leg on the same index: 5 of every barcode's 100 pairs drawn on the repeat copies, 95 on unique sequence (the primary
+    # contigs outside the copies' windows), interleaved per barcode (workload.interleave_reads) — repeat-regime reads and unique reads side by side in every kernel's waves and in every
+    # barcode's inference: 200 barcodes against the oracle, every field
+    primary = workload.outside_windows(g["contigs"], g["alt_flags"], g["windows"])
+    assert sum(c[1] for c in primary) > 0.5 * g["l_pac"]
+    ra = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 42, n_barcodes=200, pairs_per_barcode=5)
+    rb = lib.synth_reads(g["pac"], g["l_pac"], primary, seed=workload.READS_SEED + 43, n_barcodes=200, pairs_per_barcode=95)
+    m = workload.interleave_reads(ra, rb)
+    assert m["n_pairs"] == 20000 and int(m["from_first"].sum()) == 1000 and (np.diff(m["bc_pair_off"]) == 100).all()
+    bm = capi.Batch.from_arrays(m["seq"], m["seq_off"], m["bc_pair_off"], m["name_seed"])
+    got = idx.context(m["n_pairs"]).align_barcodes(bm)
+    ncm = np.diff(got.cand_off).reshape(-1, 2).sum(axis=1)
+    print("mixed: %.1f candidates per pair on the copies, %.1f elsewhere" % (ncm[m["from_first"]].mean(), ncm[~m["from_first"]].mean()))
+    assert ncm[m["from_first"]].mean() > 10 * ncm[~m["from_first"]].mean() and np.median(ncm[~m["from_first"]]) <= 4
+    refm = oidx.align_barcodes(bm, threads=THREADS)
+    helpers.assert_same_result(got, refm, inference=True)
+    assert got.counters["n_rescue"] == refm.counters["n_rescue"] and got.counters["rescue_cells"] == refm.counters["rescue_cells"]
