@@ -28,22 +28,34 @@
 #define LH_CHAIN_CL_MAX 32       // seeds of one cluster a lane walks; a read with a larger cluster goes to k_chain
 #endif
 #ifndef LH_CHAIN_CL_CAP_A
-#define LH_CHAIN_CL_CAP_A 256    // seeds of a read the first instance holds (16 KB of LDS per wave) ...
-#define LH_CHAIN_CL_CAP_B 1024   // ... and the second, for the few reads beyond (64 KB)
+#define LH_CHAIN_CL_CAP_A 256    // seeds of a read the first instance holds (16 KB of LDS per wave: 92 % of the listed reads on repeat families) ...
+#define LH_CHAIN_CL_CAP_B 512    // ... the second (8 %) ...
+#define LH_CHAIN_CL_CAP_C 1024   // ... and the third (0.5 %)
 #endif
 
+// development aid (tools/prof_rfa.sh: -DLH_RFA_PROF): shader clocks per phase, summed over the waves
+#ifdef LH_RFA_PROF
+__device__ unsigned long long lh_chain_prof[16];
+#define CH_PROF(k_) { const unsigned long long now_ = (unsigned long long)clock64(); if (lane == 0) atomicAdd(&lh_chain_prof[k_], now_ - prof_t_); prof_t_ = (unsigned long long)clock64(); }
+#else
+#define CH_PROF(k_)
+#endif
 struct ChSlot { uint16_t head, tail, n; uint8_t wq, endq; int32_t wr, endr_rel; };   // a chain while it is being built: first / last seed, seeds, mem_chain_weight's two running sums
 static_assert(sizeof(ChSlot) == 16, "ChSlot");
 
 // ---- ks_introsort on an index space (the algorithm of dev_introsort, lh_sort.h, with get / set instead of pointers): the same comparisons
 // and moves in the same order, so the same order of equal keys.  All branches on values that get() returns: wave-uniform when get() is. ----
 template <class G, class St, class Lt> __device__ __forceinline__ void ix_insertsort(int s, int t, G& get, St& set, Lt& lt) {
-    for (int i = s + 1; i < t; ++i)
-        for (int j = i; j > s; --j) {
-            const auto x = get(j), y = get(j - 1);
+    for (int i = s + 1; i < t; ++i) {   // (the element on its way down is held in a register: the array after every outer step is the one the swaps leave)
+        const auto x = get(i);
+        int j = i;
+        for (; j > s; --j) {
+            const auto y = get(j - 1);
             if (!lt(x, y)) break;
-            set(j, y); set(j - 1, x);
+            set(j, y);
         }
+        if (j != i) set(j, x);
+    }
 }
 template <class G, class St, class Lt> __device__ __forceinline__ void ix_combsort(int n, int a, G& get, St& set, Lt& lt) {
     const double shrink_factor = 1.2473309501039786540366528676643;
@@ -91,14 +103,14 @@ template <class G, class St, class Lt> __device__ __forceinline__ void dev_intro
             }
             const auto rp = get(k);
             if (k != t) { const auto vt = get(t); set(k, vt); set(t, rp); }
-            for (;;) {
-                do { ++i; LH_WATCH_S(wdp, wd, 2, return) } while (lt(get(i), rp));
-                do { --j; LH_WATCH_S(wdp, wd, 3, return) } while (i <= j && lt(rp, get(j)));
+            auto vi = rp, vj = rp;
+            for (;;) {   // (a[t] holds the pivot throughout: j never comes back to t)
+                do { ++i; vi = get(i); LH_WATCH_S(wdp, wd, 2, return) } while (lt(vi, rp));
+                for (;;) { --j; LH_WATCH_S(wdp, wd, 3, return) if (!(i <= j)) break; vj = get(j); if (!lt(rp, vj)) break; }
                 if (j <= i) break;
-                const auto vi = get(i), vj = get(j);
                 set(i, vj); set(j, vi);
             }
-            { const auto vi = get(i), vt = get(t); set(i, vt); set(t, vi); }
+            set(i, rp); set(t, vi);
             if (i - s > t - i) {
                 if (i - s > 16) { if (top >= LH_ISORT_STK) { wdp[1] = 1; return; } stack[top].left = s; stack[top].right = i - 1; stack[top].depth = d; ++top; }
                 s = t - i > 16 ? i + 1 : t;
@@ -135,24 +147,61 @@ template <int NV> struct WaveRegs {
 };
 #endif
 
+#ifndef LH_EMU
+template <int NV, class Lt> __device__ __forceinline__ void sort_in_regs(int n, int32_t* st, int lane, Lt lt, LhIsortStk* stk, int32_t* wdp) {
+    WaveRegs<NV> w;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) w.v[t] = t * 64 + lane < n ? st[t * 64 + lane] : 0;
+    dev_introsort_ix(n, [&](int i) { return w.get(i); }, [&](int i, int x) { w.set(i, x); }, lt, stk, wdp);
+#pragma unroll
+    for (int t = 0; t < NV; ++t) if (t * 64 + lane < n) st[t * 64 + lane] = w.v[t];
+}
+#endif
+
+// mem_chain_flt's test of chain i against kept chain j, both as packed words (beg | end << 8 | weight << 16 | is_alt << 25): *ov = significant overlap,
+// returns whether j shadows i
+__device__ __forceinline__ int flt_pair(const DOpts& o, uint32_t di, uint32_t dj, int* ov) {
+    const int ib = (int)(di & 255), ie = (int)(di >> 8 & 255), iw = (int)(di >> 16 & 511), ialt = (int)(di >> 25 & 1);
+    const int jb = (int)(dj & 255), je = (int)(dj >> 8 & 255), jw = (int)(dj >> 16 & 511), jalt = (int)(dj >> 25 & 1);
+    const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
+    *ov = 0;
+    if (e_min > b_max && (!jalt || ialt)) {   // have overlap; don't consider ovlp where the kept chain is ALT while the current chain is primary
+        const int li = ie - ib, lj = je - jb;
+        const int min_l = li < lj ? li : lj;
+        if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {   // significant overlap
+            *ov = 1;
+            return iw < jw * o.drop_ratio && jw - iw >= o.min_seed_len << 1;
+        }
+    }
+    return 0;
+}
+
 template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, DOpts o, const i64* __restrict__ seq_off, const i64* __restrict__ seed_off, i64 pool_cap,
                                                                      const DSeed* __restrict__ seeds, const int32_t* __restrict__ s_rid, const int32_t* __restrict__ l_rep,
                                                                      DChain* __restrict__ chains, DSeed* __restrict__ cseeds, int32_t* __restrict__ n_chains, int32_t* __restrict__ status,
                                                                      const int32_t* __restrict__ list, const int32_t* __restrict__ list_count, int s_lo, int last,
                                                                      int32_t* __restrict__ fb_list, int32_t* __restrict__ fb_count) {
     static_assert(CAP >= 64 && CAP <= 2048 && (CAP & (CAP - 1)) == 0, "seed ids in 11 bits of the sort keys");
-    constexpr int PER = CAP / 64;
+    // LDS (60 bytes per seed slot): what lives to the end, then two regions that change hands between the phases
     __shared__ DSeed sd[CAP];
     __shared__ int32_t rids[CAP];
-    __shared__ u64 skey[CAP];            // the seeds' (rbeg << 11 | seed) sorted; once the clusters are chained: od[] (chains in the tree's order) and st[] (weight << 11 | chain)
-    int32_t* const od = (int32_t*)skey;
-    int32_t* const st = od + CAP;
     __shared__ ChSlot sl[CAP];           // chain slots: a cluster's chains sit at its first sorted position onwards (a cluster of k seeds makes at most k chains)
     __shared__ int16_t chain_of[CAP];    // seed -> chain slot, -1: in none (bridging seed, contained seed)
     __shared__ uint16_t rank_[CAP];      // seed -> its place among its chain's seeds
-    __shared__ uint16_t cstart[CAP + 1], cnc[CAP], cid[CAP], corder[CAP];
-    __shared__ uint8_t keptv[CAP];
     __shared__ int32_t sstart[CAP];      // chain slot -> first place of its seeds in the output, -1: not kept
+    __shared__ u64 skey[CAP];            // the seeds' (rbeg << 11 | seed) sorted; once the clusters are chained: od[] (chains in the tree's order) | st[] (weight << 11 | chain);
+    int32_t* const od = (int32_t*)skey;  // once st[] is made, od's half holds klist[] (the kept chains, in order) and keptv[]
+    int32_t* const st = od + CAP;
+    uint16_t* const klist = (uint16_t*)od;
+    uint8_t* const keptv = (uint8_t*)(klist + CAP);
+    __shared__ __attribute__((aligned(16))) uint16_t wreg[4 * CAP + 4];   // while the clusters are chained: cstart | cnc | cid | corder; in mem_chain_flt: Dd[] (a chain as one word) | reachv[]
+    uint16_t* const cstart = wreg;           // [CAP + 1]
+    uint16_t* const cnc = wreg + CAP + 2;
+    uint16_t* const cid = cnc + CAP;
+    uint16_t* const corder = cid + CAP;
+    uint32_t* const Dd = (uint32_t*)wreg;
+    uint16_t* const reachv = (uint16_t*)((uint32_t*)wreg + CAP);   // chain -> the kept chain that shadows it (0xffff: none)
+    static_assert(sizeof(uint16_t) * (4 * CAP + 4) >= 6 * CAP, "Dd | reachv over the cluster tables");
     const int lane = LANE();
     const int n_items = *list_count;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -170,6 +219,10 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
         }
         const int len = (int)(seq_off[r + 1] - seq_off[r]);
         WAVE_SYNC();   // the previous read's tables have been read
+#ifdef LH_RFA_PROF
+        unsigned long long prof_t_ = (unsigned long long)clock64();
+        if (lane == 0) atomicAdd(&lh_chain_prof[15], 1ull);
+#endif
         // ---- the read's seeds and their sort keys ----
         int NP = 64;
         while (NP < S) NP <<= 1;
@@ -186,6 +239,7 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
             skey[s] = key;
             V += (int)__popcll(__ballot(key != ~0ull));
         }
+        CH_PROF(0)
         // bitonic sort of skey[0, NP) (the padding sorts last)
         for (int k = 2; k <= NP; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -197,6 +251,7 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
                 }
             }
         WAVE_SYNC();
+        CH_PROF(1)
         // ---- clusters: a gap of more than len + w between neighbours ----
         const i64 GAP = (i64)len + o.w;
         int ncl = 0;
@@ -218,6 +273,7 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
                 continue;
             }
         }
+        CH_PROF(2)
         // ---- one lane per cluster: mem_chain's walk over the cluster's seeds in the read's seed order ----
         for (int c = lane; c < ncl; c += 64) {
             const int p0 = cstart[c], k = cstart[c + 1] - p0;
@@ -283,6 +339,7 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
             }
         }
         WAVE_SYNC();
+        CH_PROF(3)
         // ---- the tree's traversal order, the chains' weights: mem_chain_flt's input ----
         int nall = 0;
         for (int c0 = 0; c0 < ncl; c0 += 64) {
@@ -309,7 +366,7 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
                 key = w << 11 | slot;
             }
             const u64 m = __ballot(ok);
-            if (ok) { const int at = n + lanes_below(m, lane); st[at] = key; keptv[at] = 0; }
+            if (ok) st[n + lanes_below(m, lane)] = key;
             n += (int)__popcll(m);
         }
         WAVE_SYNC();
@@ -317,6 +374,7 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
             if (lane == 0) n_chains[r] = 0;
             continue;
         }
+        CH_PROF(4)
         // ---- mem_chain_flt: ks_introsort by weight, descending ----
         {
             auto lt = [](int x, int y) { return (x >> 11) > (y >> 11); };
@@ -324,75 +382,95 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
 #ifdef LH_EMU
             if (lane == 0) dev_introsort_ix(n, [&](int i) { return st[i]; }, [&](int i, int x) { st[i] = x; }, lt, stk, o.wd);
 #else
-            if (n <= 256) {   // keys in four registers of the wave, read and written by lane index: no memory in the sort's dependent chain
-                WaveRegs<4> w;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) w.v[t] = t * 64 + lane < n ? st[t * 64 + lane] : 0;
-                dev_introsort_ix(n, [&](int i) { return w.get(i); }, [&](int i, int x) { w.set(i, x); }, lt, stk, o.wd);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) if (t * 64 + lane < n) st[t * 64 + lane] = w.v[t];
-            } else if (lane == 0) dev_introsort_ix(n, [&](int i) { return st[i]; }, [&](int i, int x) { st[i] = x; }, lt, stk, o.wd);
+            // keys in one, two or four registers of the wave, read and written by lane index: no memory in the sort's dependent chain
+            if (n <= 64) sort_in_regs<1>(n, st, lane, lt, stk, o.wd);
+            else if (n <= 128) sort_in_regs<2>(n, st, lane, lt, stk, o.wd);
+            else if (n <= 256) sort_in_regs<4>(n, st, lane, lt, stk, o.wd);
+            else if (lane == 0) dev_introsort_ix(n, [&](int i) { return st[i]; }, [&](int i, int x) { st[i] = x; }, lt, stk, o.wd);
 #endif
         }
         WAVE_SYNC();
-        // ---- mem_chain_flt: the greedy scan.  Chain i of the sorted order as one word on lane i & 63 of register i >> 6:
+        CH_PROF(5)
+        // ---- mem_chain_flt: the greedy scan, in ROUNDS.  The reference takes the chains in order of weight and tests each against the kept ones so far, up to
+        // the first that shadows it (weight below drop_ratio x that chain's).  A chain can therefore only be shadowed by one more than 1 / drop_ratio times
+        // as heavy: the sorted order falls into rounds [s, e) with w[e - 1] >= drop_ratio x w[s] — a handful: weights lie between min_seed_len and the
+        // read's length — inside which no chain shadows another.  A round's chains are decided side by side, a lane each: against the kept chains of the
+        // earlier rounds (in order, up to the first that shadows), then — those that stay — against the round's own kept chains before them.  chain_first of
+        // a kept chain is the FIRST chain that reaches it in its scan with a significant overlap: found last, a lane per kept chain.  Chain i as one word:
         // beg | end << 8 | weight << 16 | is_alt << 25 (a chain's weight is at most the read's length) ----
-        uint32_t D[PER];
-        int F[PER];          // chain_first of a kept chain
-        u64 km[PER];         // the kept chains (wave-uniform masks)
-#pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int i = t * 64 + lane;
-            D[t] = 0; F[t] = -1; km[t] = 0;
-            if (i < n) {
-                const int key = st[i];
-                const ChSlot u = sl[key & 2047];
-                const DSeed hd = sd[u.head], tl = sd[u.tail];
-                const int alt = ix.contig_alt && ix.contig_alt[rids[u.head]];
-                D[t] = (uint32_t)hd.qbeg | (uint32_t)(tl.qbeg + tl.len) << 8 | (uint32_t)(key >> 11) << 16 | (uint32_t)alt << 25;
-            }
-        }
-        km[0] = 1;
-        if (lane == 0) keptv[0] = 3;
-        for (int i = 1; i < n; ++i) {
-            uint32_t di = 0;
-#pragma unroll
-            for (int t = 0; t < PER; ++t) if ((i >> 6) == t) di = (uint32_t)wave_readlane((int)D[t], i & 63);
-            const int ib = (int)(di & 255), ie = (int)(di >> 8 & 255), iw = (int)(di >> 16 & 511), ialt = (int)(di >> 25 & 1);
-            int large_ovlp = 0, shadowed = 0;
-#pragma unroll
-            for (int t = 0; t < PER; ++t) {
-                if (t * 64 < i && !shadowed && km[t]) {   // (kept chains come before i in the sorted order)
-                    int ov = 0, brk = 0;
-                    if (km[t] >> lane & 1) {
-                        const int jb = (int)(D[t] & 255), je = (int)(D[t] >> 8 & 255), jw = (int)(D[t] >> 16 & 511), jalt = (int)(D[t] >> 25 & 1);
-                        const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
-                        if (e_min > b_max && (!jalt || ialt)) {   // have overlap; don't consider ovlp where the kept chain is ALT while the current chain is primary
-                            const int li = ie - ib, lj = je - jb;
-                            const int min_l = li < lj ? li : lj;
-                            if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {   // significant overlap
-                                ov = 1;
-                                brk = iw < jw * o.drop_ratio && jw - iw >= o.min_seed_len << 1;
-                            }
-                        }
-                    }
-                    const u64 mbrk = __ballot(brk);
-                    const int kb = mbrk ? __ffsll((unsigned long long)mbrk) - 1 : 64;   // the scan ends AT the first shadowing chain
-                    const int mine = ov && lane <= kb;
-                    if (mine && F[t] < 0) F[t] = i;
-                    large_ovlp |= __any(mine);
-                    shadowed = mbrk != 0;
-                }
-            }
-            if (!shadowed) {
-#pragma unroll
-                for (int t = 0; t < PER; ++t) if ((i >> 6) == t) km[t] |= 1ull << (i & 63);
-                if (lane == 0) keptv[i] = large_ovlp ? 2 : 3;
-            }
+        for (int i = lane; i < n; i += 64) {
+            const int key = st[i];
+            const ChSlot u = sl[key & 2047];
+            const DSeed hd = sd[u.head], tl = sd[u.tail];
+            const int alt = ix.contig_alt && ix.contig_alt[rids[u.head]];
+            Dd[i] = (uint32_t)hd.qbeg | (uint32_t)(tl.qbeg + tl.len) << 8 | (uint32_t)(key >> 11) << 16 | (uint32_t)alt << 25;
+            keptv[i] = 0;
         }
         WAVE_SYNC();
-#pragma unroll
-        for (int t = 0; t < PER; ++t) if ((km[t] >> lane & 1) && F[t] >= 0) keptv[F[t]] = 1;
+        int nk = 0;
+        for (int s0 = 0; s0 < n;) {
+            // the round: up to the first chain lighter than drop_ratio x the round's heaviest (the same float comparison as the rule's)
+            const int ws = (int)(Dd[s0] >> 16 & 511);
+            int e0 = n;
+            for (int i0 = s0 + 1; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                const u64 m = __ballot(i < n && (int)(Dd[i] >> 16 & 511) < ws * o.drop_ratio);
+                if (m) { e0 = i0 + __ffsll((unsigned long long)m) - 1; break; }
+            }
+            const int nk_prev = nk;
+            for (int i0 = s0; i0 < e0; i0 += 64) {   // against the kept chains of the earlier rounds, in order, up to the first that shadows
+                const int i = i0 + lane;
+                int shadowed = 0, large = 0;
+                if (i < e0) {
+                    const uint32_t di = Dd[i];
+                    int reach = 0xffff;   // how far the chain's scan of the kept list gets: to the end, or to the chain that shadows it
+                    for (int k = 0; k < nk_prev; ++k) {
+                        const int j = klist[k];
+                        int ov;
+                        const int brk = flt_pair(o, di, Dd[j], &ov);
+                        large |= ov;
+                        if (brk) { shadowed = 1; reach = j; break; }
+                    }
+                    reachv[i] = (uint16_t)reach;
+                }
+                const u64 mk = __ballot(i < e0 && !shadowed);
+                if (i < e0 && !shadowed) { klist[nk + lanes_below(mk, lane)] = (uint16_t)i; keptv[i] = large ? 2 : 3; }
+                nk += (int)__popcll(mk);
+            }
+            WAVE_SYNC();
+            for (int k0 = nk_prev; k0 < nk; k0 += 64) {   // the round's kept chains: a significant overlap with one of the round's kept chains before them?
+                const int k = k0 + lane;
+                if (k < nk) {
+                    const int i = klist[k];
+                    if (keptv[i] == 3) {
+                        const uint32_t di = Dd[i];
+                        for (int k2 = k - 1; k2 >= nk_prev; --k2) {
+                            int ov;
+                            flt_pair(o, di, Dd[klist[k2]], &ov);
+                            if (ov) { keptv[i] = 2; break; }
+                        }
+                    }
+                }
+            }
+            WAVE_SYNC();
+            s0 = e0;
+        }
+        // chain_first of kept chain j = the first chain after it whose scan reaches j with a significant overlap; that chain's kept becomes 1
+        for (int k0 = 0; k0 < nk; k0 += 64) {
+            const int k = k0 + lane;
+            int f = -1;
+            if (k < nk) {
+                const int j = klist[k];
+                const uint32_t dj = Dd[j];
+                for (int i = j + 1; i < n; ++i) {
+                    if ((int)reachv[i] < j) continue;   // shadowed by a kept chain before j: its scan ended there
+                    int ov;
+                    flt_pair(o, Dd[i], dj, &ov);
+                    if (ov) { f = i; break; }
+                }
+            }
+            if (f >= 0) keptv[f] = 1;   // (several lanes may name the same chain: the same value)
+        }
         WAVE_SYNC();
         if (n >= o.max_chain_extend) {   // don't extend more than max_chain_extend .kept=1/2 chains (mem_opt_init: 1 << 30)
             if (lane == 0) {
@@ -407,6 +485,7 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
             }
             WAVE_SYNC();
         }
+        CH_PROF(6)
         // ---- emit the kept chains in sorted order, then every seed to its chain's place ----
         int m = 0;
         {
@@ -438,5 +517,6 @@ template <int CAP> __global__ void __launch_bounds__(64) k_chain_cl(DIndex ix, D
             const int c = chain_of[s];
             if (c >= 0 && sstart[c] >= 0) cseeds[base + sstart[c] + rank_[s]] = sd[s];
         }
+        CH_PROF(7)
     }
 }

@@ -569,15 +569,43 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             WAVE_SYNC();
             for (int i = lane; i < NCf; i += 64) T.plist[i] = sidx[i];
         } else {
-            // a large barcode (the reader's cap is 30,000 pairs): keys next to the list (sval is free until the molecules are scored), every
-            // contig's sort at once with the ranges of Go's quickSort spread over the lanes (lh_sort.h: wave_gosort; molraw / rdl / firstf
-            // are free until inferMolecules and hold the queue of ranges)
-            i64* const kp = (i64*)T.sval;
+            // More candidates than the LDS buffer holds (a barcode on repeat families has thousands; the reader's cap is 30,000 pairs).  Contig by contig (r05):
+            // a contig's list that fits the buffer is staged there and sorted by ranking, as above — with all keys different there is only one sorted order; two
+            // equal positions: Go's algorithm, serially, in LDS —; a longer one is sorted in memory with the ranges of Go's quickSort spread over the lanes
+            // (lh_sort.h: wave_gosort; keys next to the list in sval, free until the molecules are scored; molraw / rdl / firstf hold the queue of ranges).
+            // (All of them at once in memory, the r04 form, was 10 % of the kernel on the repeat input: the first levels of every quickSort are one lane's.)
+            i64* const kpg = (i64*)T.sval;
             int32_t* const pl = T.plist;
-            for (int i = lane; i < NCf; i += 64) kp[i] = R.pos[c_lo + pl[i]];
-            WAVE_SYNC();
-            wave_gosort(ncont, T.coff, [&](int i, int j) { return kp[i] < kp[j]; },
-                        [&](int i, int j) { i64 t = kp[i]; kp[i] = kp[j]; kp[j] = t; int u = pl[i]; pl[i] = pl[j]; pl[j] = u; }, T.molraw, T.rdl, T.firstf);
+            for (int k = 0; k < ncont; ++k) {
+                const int b0 = T.coff[k], n = T.coff[k + 1] - b0;
+                if (n < 2) continue;
+                if (n > LH_RFA_SORT_LDS) {
+                    for (int i = lane; i < n; i += 64) kpg[b0 + i] = R.pos[c_lo + pl[b0 + i]];
+                    WAVE_SYNC();
+                    wave_gosort(1, T.coff + k, [&](int i, int j) { return kpg[i] < kpg[j]; },
+                                [&](int i, int j) { i64 t = kpg[i]; kpg[i] = kpg[j]; kpg[j] = t; int u = pl[i]; pl[i] = pl[j]; pl[j] = u; }, T.molraw, T.rdl, T.firstf);
+                    WAVE_SYNC();
+                    continue;
+                }
+                WAVE_SYNC();   // the previous contig's keys have been read
+                for (int i = lane; i < n; i += 64) { const int a = pl[b0 + i]; sidx[i] = a; spos[i] = R.pos[c_lo + a]; }
+                WAVE_SYNC();
+                int tie = 0;
+                for (int e = lane; e < n; e += 64) {
+                    const i64 key = spos[e];
+                    int rank = 0;
+                    for (int j = 0; j < n; ++j) { const i64 kj = spos[j]; rank += kj < key; tie |= (kj == key) & (j != e); }
+                    pl[b0 + rank] = sidx[e];
+                }
+                if (__any(tie)) {
+                    WAVE_SYNC();
+                    if (lane == 0)
+                        dev_gosort(n, [&](int i, int j) { return spos[i] < spos[j]; },
+                                   [&](int i, int j) { i64 t = spos[i]; spos[i] = spos[j]; spos[j] = t; int u = sidx[i]; sidx[i] = sidx[j]; sidx[j] = u; }, T.gstk + lane, 64);
+                    WAVE_SYNC();
+                    for (int e = lane; e < n; e += 64) pl[b0 + e] = sidx[e];
+                }
+            }
         }
         WAVE_SYNC();
         RFA_PROF(4)
@@ -615,16 +643,32 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     int g = r0 + T.rdl[i], gm = g ^ 1;
                     double best = -1.7976931348623157e308;
                     int found = 0;
-                    for (i64 b = R.cand_off[gm]; b < R.cand_off[gm + 1]; ++b) {
-                        if (T.molc[b - c_lo] != m) continue;
-                        found = 1;
-                        double s = dev_score_aln(R, S, improper, c_lo + a, b, 0.0);
-                        if (s > best) best = s;
+                    first = 1;
+                    const int ms0 = T.mstart[m], ms1 = T.mstart[m + 1];
+                    if (ms1 - ms0 <= (int)(R.cand_off[g + 1] - R.cand_off[g]) + (int)(R.cand_off[gm + 1] - R.cand_off[gm])) {
+                        // (r05) the mate's alignments inside molecule m, and this read's own before entry i, are among the MOLECULE's entries — a handful on
+                        // repeat families, where a read has a hundred alignments spread over as many raw molecules (walking those to find the few of this
+                        // molecule was half of the kernel there).  The same set, the same maximum.
+                        const int lr = T.rdl[i], lrm = lr ^ 1;
+                        for (int j = ms0; j < ms1; ++j) {
+                            const int lj = T.rdl[j];
+                            if (lj == lrm) {
+                                found = 1;
+                                double s = dev_score_aln(R, S, improper, c_lo + a, c_lo + T.plist[j], 0.0);
+                                if (s > best) best = s;
+                            } else if (lj == lr && j < i) first = 0;
+                        }
+                    } else {
+                        for (i64 b = R.cand_off[gm]; b < R.cand_off[gm + 1]; ++b) {
+                            if (T.molc[b - c_lo] != m) continue;
+                            found = 1;
+                            double s = dev_score_aln(R, S, improper, c_lo + a, b, 0.0);
+                            if (s > best) best = s;
+                        }
+                        for (i64 b = R.cand_off[g]; b < R.cand_off[g + 1]; ++b)
+                            if (T.molc[b - c_lo] == m && T.ppos[b - c_lo] < i) first = 0;
                     }
                     T.sval[i] = found ? best : R.lap[c_lo + a];
-                    first = 1;
-                    for (i64 b = R.cand_off[g]; b < R.cand_off[g + 1]; ++b)
-                        if (T.molc[b - c_lo] == m && T.ppos[b - c_lo] < i) first = 0;
                     T.firstf[i] = first;
                     isact = S.active[c_lo + a] != 0;
                 }

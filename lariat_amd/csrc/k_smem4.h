@@ -205,6 +205,39 @@ __global__ void __launch_bounds__(256) k_smem_first(DIndex ix, DOpts o, int n_re
 // BIG: the second chance of the reads whose intervals outgrew their LH_MAX_INTV regular slots (listed by k_big_collect): the same
 // passes again, over the list, into slab slots of LH_BIG_INTV intervals (BWA's interval vector grows; no read is refused for it).
 struct K1Big { const int32_t* list; const int32_t* count; const int32_t* slot; DIntv* slab; const K1Resume* resume; };   // slot[r]: the read's big-slab slot, -1: none; slab: 2 x LH_BIG_INTV per slot (unsorted | sorted); !BIG pass 1: list / count / resume = the reads k_smem_first left, and where
+// ---- request trace of pass 1 (development aid, -DLH_K1_TRACE: tools/k1_trace.py).  Every memory request of the state machine — table, address, bytes — is
+// appended to the lane's own sequence (entry k of lane t at trace[k * T + t]); k_k1_replay then issues the same sequences with the same launch geometry and
+// nothing else: each lane one request per turn, the next one only when the last has landed (what the state machine's turn structure does), no bookkeeping.
+// Its time is the floor of this request stream on this chip; the per-table counts say what the stream is made of.
+#define K1T_OCC 0
+#define K1T_TREE 1
+#define K1T_BLOOM1 2
+#define K1T_BLOOM2 3
+#define K1T_REPT 4
+#define K1T_PLCP 5
+#define K1T_TEXT 6
+#define K1T_SA 7
+#define K1T_ISA 8
+#define K1T_SLAB_R 9
+#define K1T_SLAB_W 10
+#define K1T_INTV_W 11
+#define K1T_READS 12
+#define K1T_N 13
+#ifdef LH_K1_TRACE
+__device__ u64* lh_k1_trace;            // null: tracing off
+__device__ uint32_t lh_k1_trace_cap;    // entries per lane
+__device__ uint32_t* lh_k1_trace_n;     // [T] requests of lane t (may exceed the cap: the rest was not recorded)
+#define K1_REQ(tab_, ptr_, bytes_)                                                                                                              \
+    {                                                                                                                                            \
+        if (PASS == 1 && !BIG && lh_k1_trace) {                                                                                                  \
+            if (trace_k < lh_k1_trace_cap) lh_k1_trace[(size_t)trace_k * T + t] = (u64)(uintptr_t)(ptr_) | (u64)(bytes_) << 48 | (u64)(tab_) << 56; \
+            ++trace_k;                                                                                                                           \
+        }                                                                                                                                        \
+    }
+#else
+#define K1_REQ(tab_, ptr_, bytes_)
+#endif
+
 template <int PASS, bool BIG>
 __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pass(DIndex ix, DOpts o, int n_reads_all, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                DIntv* __restrict__ intv_out, int32_t* __restrict__ n_intv, int32_t* __restrict__ status, PEnt* __restrict__ slab,
@@ -230,6 +263,9 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
 #define UE1 ((int)(uspan >> 24))
     const int lane = LANE();
     const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)lane;
+#ifdef LH_K1_TRACE
+    uint32_t trace_k = 0;
+#endif
     PEnt* const LA = slab + t;                                    // entry e of list A at LA[e * T]
     PEnt* const LB = slab + (size_t)(LH_MAXLEN + 2) * T + t;
     const int split_len = (int)(o.min_seed_len * o.split_factor + .499);
@@ -306,7 +342,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
     }
     // issue the reads of the sixteen text bases from position p_ on (p_ >= -16); T16_A() / T16_B() assemble the first / the second
     // eight once they have arrived
-#define T16_LOAD(p_) { i64 w_ = (p_) >> 3; tw_sh = (uint32_t)((p_) & 7) * 4; tw0 = ix.tn[w_]; tw1 = ix.tn[w_ + 1]; tw2 = ix.tn[w_ + 2]; }
+#define T16_LOAD(p_) { i64 w_ = (p_) >> 3; tw_sh = (uint32_t)((p_) & 7) * 4; tw0 = ix.tn[w_]; tw1 = ix.tn[w_ + 1]; tw2 = ix.tn[w_ + 2]; K1_REQ(K1T_TEXT, ix.tn + w_, 12) }
 #define T16_A() (tw_sh ? (tw0 >> tw_sh) | (tw1 << (32 - tw_sh)) : tw0)
 #define T16_B() (tw_sh ? (tw1 >> tw_sh) | (tw2 << (32 - tw_sh)) : tw1)
 #define CURR ((rflags & RF_CURA) ? LA : LB)
@@ -337,8 +373,8 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
         if (pbits && cinfo - x <= LH_BLOOM_K) bword = (pbits >> (cinfo - x - 1)) & 1;   /* pass 2 after the probe: the text's own bit for this window (exact: no filter read) */ \
         else if (filt && cinfo >= filt_from) {                                                               \
             uint32_t w_;                                                                                     \
-            if (min_intv == 1) { dev_bloom_slot(wkey, ix.bloom1_words, &w_, &bmask); bword = ix.bloom1[w_]; } \
-            else { dev_bloom_slot(wkey, ix.bloom2_words, &w_, &bmask); bword = ix.bloom2[w_]; }              \
+            if (min_intv == 1) { dev_bloom_slot(wkey, ix.bloom1_words, &w_, &bmask); bword = ix.bloom1[w_]; K1_REQ(K1T_BLOOM1, ix.bloom1 + w_, 8) } \
+            else { dev_bloom_slot(wkey, ix.bloom2_words, &w_, &bmask); bword = ix.bloom2[w_]; K1_REQ(K1T_BLOOM2, ix.bloom2 + w_, 8) }              \
         }                                                                                                    \
     }
 #define FWD_PUSH_OK() ((bword & bmask) == bmask)
@@ -439,7 +475,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
         else if (by_text && (rflags & (RF_REV | RF_TRIF)) == RF_REV && nprev > 1 && c2 == 1 && min_intv == 1) { rflags |= RF_TRI; st = S4_BRUN_INIT; } \
         else {                                                                                               \
             ec = c_; st = S4_REQ_BWD;                                                                        \
-            if (nprev > 1) pn = PREV_AT((rflags & RF_REV) ? nprev - 2 : 1);                                                \
+            if (nprev > 1) { pn = PREV_AT((rflags & RF_REV) ? nprev - 2 : 1); K1_REQ(K1T_SLAB_R, &PREV_AT((rflags & RF_REV) ? nprev - 2 : 1), 16) }                                                \
             if (ktl) CODE16(i, rcode)                                                                        \
         }                                                                                                    \
     }
@@ -450,7 +486,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
         if (j < nprev) {                                                                                     \
             c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn); cinfo = PE_INFO(pn);                             \
             st = S4_REQ_BWD;                                                                                 \
-            if (j + 1 < nprev) pn = PREV_AT((rflags & RF_REV) ? nprev - 2 - j : j + 1);                                    \
+            if (j + 1 < nprev) { pn = PREV_AT((rflags & RF_REV) ? nprev - 2 - j : j + 1); K1_REQ(K1T_SLAB_R, &PREV_AT((rflags & RF_REV) ? nprev - 2 - j : j + 1), 16) }                                    \
         } else if (ncurr == 0) st = S4_SMEM_DONE;                                                            \
         else {                                                                                               \
             nprev = ncurr; --i;                                                                              \
@@ -466,7 +502,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             if (on >= ICAP) ovf = 1;                                                                  \
             else {                                                                                           \
                 DIntv m_; m_.x0 = c0; m_.x1 = c1; m_.x2 = c2; m_.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32; \
-                out[on] = m_; on++;                                                                          \
+                out[on] = m_; on++; K1_REQ(K1T_INTV_W, out + on - 1, 32)                                     \
             }                                                                                                \
         }                                                                                                    \
         last_mem_start = i + 1;                                                                              \
@@ -524,6 +560,8 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             }
             if (st == S4_FETCH) {
                 r = rr; len = ln; rst = 0; on = 0; ovf = 0; p2mask = 0; rflags = 0;
+                K1_REQ(K1T_READS, seq + off, 64)   // (the read's bases, staged by the wave; its offsets and its resume record)
+                K1_REQ(K1T_READS, seq_off + rr, 16)
                 if (len > LH_MAXLEN) { rst |= LH_ST_TOO_LONG; len = 0; }
                 out = BIG ? big.slab + (size_t)big.slot[r] * (2 * LH_BIG_INTV) : intv_out + (size_t)r * LH_MAX_INTV;
                 if (!DO1) { on = n_intv[r]; rst |= status[r]; }   // continue behind the intervals of the earlier passes
@@ -558,7 +596,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
         // ---- B. transitions between the loops of mem_collect_intv (rare per lane; the blocks are ordered so that the
         //         usual chains finish in one pass) ----
         if (st >= S4_FRUN_INIT) {   // ONE step of the load / use chains per turn: a value read here is used in the next turn
-            if (DO1 && st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; st = S4_FRUN_INIT2; }
+            if (DO1 && st == S4_FRUN_INIT) { ld64 = ix.sa[c0]; K1_REQ(K1T_SA, ix.sa + c0, 8) st = S4_FRUN_INIT2; }
             else if (DO1 && st == S4_FRUN_INIT2) {
                 run_p = (i64)ld64; T16_LOAD(run_p + (i - x))
                 rflags |= RF_RUNP;
@@ -574,7 +612,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                     ce = pe_pack(c0, 0, c2, cinfo);
                     ncurr++;
                     st = S4_BWD_INIT;
-                } else { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; st = S4_FRUN_END2; }
+                } else { ld64 = ix.isa[(i64)ix.seq_len - (run_p + (i - x))]; K1_REQ(K1T_ISA, ix.isa + ((i64)ix.seq_len - (run_p + (i - x))), 8) st = S4_FRUN_END2; }
             }
             else if (DO1 && st == S4_FRUN_END2) {
                 c1 = ld64;
@@ -585,7 +623,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             else if (DO1 && st == S4_BT_INIT) {   // a call by text: the comparison starts at x, the PLCP byte of (A) is read beside the first text words
                 run_p = Pk + x;
                 T16_LOAD(run_p)
-                ec = ix.plcp[run_p];
+                ec = ix.plcp[run_p]; K1_REQ(K1T_PLCP, ix.plcp + run_p, 1)
                 i = x; last_mem_start = -1; rflags |= RF_BT | RF_RUNP;
                 st = S4_REQ_FRUN;
             }
@@ -593,7 +631,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                 if (ec <= x - (i + 1)) { c0 = LH_POSF | (u64)run_p; c1 = 0; c2 = 1; rflags &= ~RF_BT; n_bt_total++; st = S4_BWD_EMIT0; }
                 else { rflags &= ~(RF_RUNP | RF_BT | RF_C1UNK); SET_BT_SKIP(x); todo |= TD_SMEM; st = S4_PENDING; }   // not provable: the call as written
             }
-            else if (DO12 && st == S4_FJUMP) { pn = kt[ld64]; st = S4_FJUMP2; }
+            else if (DO12 && st == S4_FJUMP) { pn = kt[ld64]; K1_REQ(K1T_TREE, kt + ld64, 16) st = S4_FJUMP2; }
             else if (DO12 && st == S4_FJUMP2) {
                 if (PE_X2(pn) >= (u64)min_intv) {   // as if the bwt_extend steps up to level j had been made
                     c0 = PE_X0(pn); c1 = PE_X1(pn); c2 = PE_X2(pn);
@@ -673,17 +711,17 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             }
             else if (DO1 && st == S4_BRUN_INIT) {
                 if (rflags & RF_RUNP) { T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }   // the forward run (or the call by text) left the position of read base x
-                else { ld64 = ix.sa[c0]; st = S4_BRUN_INIT2; }
+                else { ld64 = ix.sa[c0]; K1_REQ(K1T_SA, ix.sa + c0, 8) st = S4_BRUN_INIT2; }
             }
             else if (DO1 && st == S4_BRUN_INIT2) { run_p = (i64)ld64; T16_LOAD(run_p - 16) st = S4_REQ_BRUN; }
             else if (DO1 && st == S4_BRUN_END) {   // the row at i could not extend the one interval left: it is a MEM unless contained in the previous one
                 const bool edge = i < 0 || QB(i) > 3;   // stopped by the start of the read or a non-base: bwt_smem1a emits the longest entry only
                 if (rflags & RF_BT) {
                     if (edge || i == X_PREV()) { c0 = LH_POSF | (u64)run_p; c1 = 0; c2 = 1; rflags &= ~RF_BT; n_bt_total++; st = S4_BWD_EMIT0; }   // (B') see START_SMEM1
-                    else { ec = ix.plcp[run_p]; st = S4_BT_B; }
-                } else if ((rflags & RF_TRI) && !edge) { ec = ix.plcp[run_p]; st = S4_TRI_LCP2; }
+                    else { ec = ix.plcp[run_p]; K1_REQ(K1T_PLCP, ix.plcp + run_p, 1) st = S4_BT_B; }
+                } else if ((rflags & RF_TRI) && !edge) { ec = ix.plcp[run_p]; K1_REQ(K1T_PLCP, ix.plcp + run_p, 1) st = S4_TRI_LCP2; }
                 else if (by_text) { c0 = LH_POSF | (u64)run_p; c1 = 0; st = S4_BWD_EMIT0; }   // one occurrence, at run_p
-                else { ld64 = ix.isa[run_p]; st = S4_TRI_C1B; }   // (no PLCP array: the row, as before)
+                else { ld64 = ix.isa[run_p]; K1_REQ(K1T_ISA, ix.isa + run_p, 8) st = S4_TRI_C1B; }   // (no PLCP array: the row, as before)
             }
             else if (DO1 && st == S4_TRI_LCP2) {   // ec = bases the suffix at u's position shares with another suffix (u = i + 1)
                 if (ec < emin - (i + 1)) {   // the shortest entry is unique from u on: the list is its longest entry
@@ -699,7 +737,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                     // with the longest entry's second row bound, which the run did not keep: the row of the reverse strand's copy.
                     const int m_ = i + 1 + ec - emin + 1;
                     if (m_ < nprev - 1) nprev = m_ + 1;
-                    ld64 = ix.isa[(i64)ix.seq_len - (run_p + (PE_INFO(ce) - (i + 1)))];
+                    ld64 = ix.isa[(i64)ix.seq_len - (run_p + (PE_INFO(ce) - (i + 1)))]; K1_REQ(K1T_ISA, ix.isa + ((i64)ix.seq_len - (run_p + (PE_INFO(ce) - (i + 1)))), 8)
                     st = S4_TRI_C1;
                 }
             }
@@ -841,17 +879,17 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             uint32_t code;
             if (st == S4_REQ_BWD) code = rcode & ((1u << (2 * lnew)) - 1u);
             else { fcode |= (uint32_t)(3 - ec) << (2 * (lnew - 1)); code = fcode; }   // forward steps complement the base (ec = 3 - base)
-            te = kt[(((1ull << (2 * lnew)) - 4) / 3) + code];
+            te = kt[(((1ull << (2 * lnew)) - 4) / 3) + code]; K1_REQ(K1T_TREE, kt + ((((1ull << (2 * lnew)) - 4) / 3) + code), 16)
         }
         if (by_occ) {   // dev_2occ4(xa - 1, xa - 1 + c2): the records of the interval's two ends (one read if they share it)
             const u64 k = xa - 1, l = xa - 1 + c2;
             l2 = l - (l >= ix.primary);
             const uint4* pl = ix.occ + ((l2 >> 6) << 1);
-            hl = pl[0]; dl = pl[1];
+            hl = pl[0]; dl = pl[1]; K1_REQ(K1T_OCC, pl, 32)
             if (k != (u64)-1) {
                 k2 = k - (k >= ix.primary);
                 hk = hl; dk = dl;
-                if ((k2 >> 6) != (l2 >> 6)) { const uint4* pk = ix.occ + ((k2 >> 6) << 1); hk = pk[0]; dk = pk[1]; }
+                if ((k2 >> 6) != (l2 >> 6)) { const uint4* pk = ix.occ + ((k2 >> 6) << 1); hk = pk[0]; dk = pk[1]; K1_REQ(K1T_OCC, pk, 32) }
             }
         }
         if (by_tree) {
@@ -880,7 +918,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             if (ok.x2 != c2) {
                 ce = pe_pack(c0, c1, c2, cinfo);
                 if (ok.x2 < (u64)min_intv) { st = S4_BWD_INIT; ncurr++; }   // the interval is too small to be extended further: ce is the list's last entry
-                else if (FWD_PUSH_OK()) { if (!ncurr) emin = cinfo; CURR[(uint32_t)ncurr * T] = ce; ncurr++; }
+                else if (FWD_PUSH_OK()) { if (!ncurr) emin = cinfo; CURR[(uint32_t)ncurr * T] = ce; K1_REQ(K1T_SLAB_W, &CURR[(uint32_t)ncurr * T], 16) ncurr++; }
             }
             if (st == S4_REQ_FWD) {
                 c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i;
@@ -894,7 +932,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             } else if (ncurr == 0 || ok.x2 != last_size) {
                 PEnt e = pe_pack(ok.x0, ok.x1, ok.x2, cinfo);
                 if (ncurr == 0) ce = e;   // a row's first entry is only ever read through ce
-                else CURR[(uint32_t)ncurr * T] = e;
+                else { CURR[(uint32_t)ncurr * T] = e; K1_REQ(K1T_SLAB_W, &CURR[(uint32_t)ncurr * T], 16) }
                 ncurr++;
                 last_size = ok.x2;
             }
@@ -996,7 +1034,56 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
         unsigned bx = (unsigned)wave_sum_i32((int)n_bt_total);
         if (lane == 0 && bx) atomicAdd(&LH_CTR(ctr)->n_bt, (u64)bx);
     }
+#ifdef LH_K1_TRACE
+    if (PASS == 1 && !BIG && lh_k1_trace) lh_k1_trace_n[t] = trace_k;
+#endif
 }
+
+#ifdef LH_K1_TRACE
+// the recorded sequences again, with pass 1's launch geometry: lane t issues its k-th request when its (k - 1)-th has landed (the address is made to depend on
+// the value read), the wave goes on when all of its lanes' requests have — a turn of the state machine without anything between the requests
+__global__ void __launch_bounds__(64, LH_SMEM4_WAVES) k_k1_replay(const u64* __restrict__ trace, const uint32_t* __restrict__ n_req, uint32_t cap, u64* __restrict__ sink) {
+    const uint32_t T = gridDim.x * 64u, t = blockIdx.x * 64u + (uint32_t)LANE();
+    uint32_t n = n_req[t];
+    if (n > cap) n = cap;
+    uint32_t nmax = n;
+    for (int m = 32; m >= 1; m >>= 1) { const uint32_t o_ = __shfl_xor(nmax, m); nmax = nmax > o_ ? nmax : o_; }
+    u64 acc = 0;
+    for (uint32_t k = 0; k < nmax; ++k) {
+        if (k < n) {
+            const u64 e = trace[(size_t)k * T + t];
+            const int tab = (int)(e >> 56), bytes = (int)((e >> 48) & 0xff);
+            const uintptr_t a = (uintptr_t)(e & 0xffffffffffffull) + (acc == 0x9e3779b97f4a7c15ull ? 64 : 0);   // (never true: but the address now waits for the last value)
+            if (tab == K1T_SLAB_W) {   // the state machine's list stores: the same bytes to the same place (scratch that pass 1 has finished with; the
+                uint4 v = {(uint32_t)acc, 1, 2, 3};   // interval array it leaves to the later passes is read instead of written)
+                *(uint4*)a = v;
+            } else if (bytes >= 32) { const uint4 v0 = ((const uint4*)a)[0], v1 = ((const uint4*)a)[1]; acc += v0.x + v1.w; }
+            else if (bytes >= 16) { const uint4 v = *(const uint4*)a; acc += v.x + v.w; }
+            else if (bytes == 12) { const uint32_t* q = (const uint32_t*)a; acc += q[0] + q[1] + q[2]; }
+            else if (bytes == 8) acc += *(const u64*)a;
+            else acc += *(const uint8_t*)a;
+        }
+    }
+    if (acc == 0x9e3779b97f4a7c15ull) *sink = acc;
+}
+// requests and bytes per table
+__global__ void __launch_bounds__(256) k_k1_trace_hist(const u64* __restrict__ trace, const uint32_t* __restrict__ n_req, uint32_t cap, uint32_t T, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned long long h[2 * K1T_N + 2];
+    if (threadIdx.x < 2 * K1T_N + 2) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        uint32_t n = n_req[t];
+        if (n > cap) { atomicAdd(&h[2 * K1T_N], (unsigned long long)(n - cap)); n = cap; }
+        for (uint32_t k = 0; k < n; ++k) {
+            const u64 e = trace[(size_t)k * T + t];
+            const int tab = (int)(e >> 56);
+            if (tab < K1T_N) { atomicAdd(&h[2 * tab], 1ull); atomicAdd(&h[2 * tab + 1], (unsigned long long)((e >> 48) & 0xff)); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * K1T_N + 2 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+#endif
 
 // a read's interval array: its regular slots, or the sorted half of its big-slab slot
 __device__ __forceinline__ DIntv* dev_intv_of(DIntv* intv, const K1Big& big, int r, int sorted) {

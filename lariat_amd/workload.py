@@ -273,9 +273,10 @@ def interleave_reads(ra, rb, chunk_reads=400000):
     return out
 
 
-def outside_windows(contigs, alt_flags, windows, min_len=400000):
-    """[(name, len, offset)]: the stretches of the primary contigs that lie outside every window of `windows` and are at least `min_len` long (a molecule of
-    lh_synth_reads is up to 200 kb) — where config4_genome planted nothing: the "unique sequence" the mixed workload draws most of its pairs on"""
+def outside_windows(contigs, alt_flags, windows, min_len=20000):
+    """[(name, len, offset)]: the stretches of the primary contigs that lie outside every window of `windows` and are at least `min_len` long (lh_synth_reads
+    cuts a molecule to the stretch it falls on; config4_genome's copies lie 18 kb apart on average, so the stretches between them are short) — where
+    config4_genome planted nothing: the "unique sequence" the mixed workload draws most of its pairs on"""
     import numpy as np
     w = sorted((int(o), int(o + n)) for _, n, o in windows)
     ws = np.array([a for a, _ in w], dtype=np.int64)

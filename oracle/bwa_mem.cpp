@@ -6,6 +6,8 @@
 // Source of truth is absent from /root/reference (empty submodule go/src/gobwa/bwa);
 // function names below are upstream's (bwt.c, bwamem.c, bwa.c, ksw.c).
 #include "bwa_oracle.h"
+#include <atomic>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cassert>
@@ -1082,6 +1084,88 @@ static inline int mem_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* 
     return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
 }
 
+// ---- rescue probe (tools/rescue_probe.py): what an exact no-DP / banded shortcut for ksw_align2 would need to be true, counted per mem_matesw
+// attempt on the oracle's own job list.  For the window (tlen rows) and the query as aligned (qlen columns), with a = 1, b = 4, gap 6 + k:
+//   K(d)   the best ungapped local segment of diagonal d = row - column (Kadane, floor 0)
+//   V(d)   the most that disjoint segments of diagonal d can add to a path that pays one gap open + extension (7) for each: max sum of (gain - 7)+
+// Any path's score is at most 7 + sum over its diagonals of V(d) when none of its pieces lies on d0, the result's diagonal.
+std::atomic<uint64_t> g_rescue_probe[64];
+int g_rescue_probe_on = 0;
+static void rescue_probe(const MemOpt& o, int qlen, const uint8_t* q, int tlen, const uint8_t* t, const Kswr& r) {
+    auto& P = g_rescue_probe;
+    P[0]++;
+    if (r.score < o.min_seed_len || r.qb < 0) { P[1]++; return; }   // no region comes of it
+    P[2]++;
+    const int S = r.score, d0 = r.te - r.qe;
+    const int ungapped = (r.te - r.tb) == (r.qe - r.qb);
+    const int nd = tlen + qlen - 1;
+    std::vector<int> K(nd, 0), V(nd, 0);
+    int n_act = 0, qstar = 0;
+    long vsum[4] = {0, 0, 0, 0};   // V over |d - d0| > 0, 8, 16, 32
+    for (int di = 0; di < nd; ++di) {
+        const int d = di - (qlen - 1);
+        int k0 = d < 0 ? -d : 0, i0 = d < 0 ? 0 : d;
+        int h = 0, best = 0, open = -1000000, vbest = 0;
+        for (int k = k0, i = i0; k < qlen && i < tlen; ++k, ++i) {
+            const int sc = (q[k] > 3 || t[i] > 3) ? -1 : (q[k] == t[i] ? o.a : -o.b);
+            h = h + sc > 0 ? h + sc : 0;
+            if (h > best) best = h;
+            const int no = (open > vbest - (o.o_ins + o.e_ins) ? open : vbest - (o.o_ins + o.e_ins)) + sc;   // a segment that has paid its gap
+            open = no;
+            if (open > vbest) vbest = open;
+        }
+        K[di] = best; V[di] = vbest;
+        if (d != d0) {
+            if (best >= 8) { n_act++; if (best > qstar) qstar = best; }
+            const int dist = d > d0 ? d - d0 : d0 - d;
+            if (dist > 0) vsum[0] += vbest;
+            if (dist > 8) vsum[1] += vbest;
+            if (dist > 16) vsum[2] += vbest;
+            if (dist > 32) vsum[3] += vbest;
+        }
+    }
+    // the result's own diagonal: is the result its best ungapped segment, first maximum, and does no detour around a bad stretch pay (a detour costs two gaps,
+    // at least 14, and earns at most 7 on a quiet diagonal: net -7; counted as -6 so that a detour can never tie)
+    int kad_ok = 0, skip_ok = 0;
+    if (ungapped) {
+        const int di0 = d0 + (qlen - 1);
+        int k0 = d0 < 0 ? -d0 : 0, i0 = d0 < 0 ? 0 : d0;
+        int h = 0, best = 0, bi = -1, g = 0, G2 = 0, G1 = 0, gbest = 0, gi = -1;   // G2: the best g two cells back
+        for (int k = k0, i = i0; k < qlen && i < tlen; ++k, ++i) {
+            const int sc = (q[k] > 3 || t[i] > 3) ? -1 : (q[k] == t[i] ? o.a : -o.b);
+            h = h + sc > 0 ? h + sc : 0;
+            if (h > best) { best = h; bi = i; }
+            int ng = g + sc;
+            if (G2 - 6 + sc > ng) ng = G2 - 6 + sc;
+            if (ng < 0) ng = 0;
+            G2 = G1; if (g > G1) G1 = g;
+            g = ng;
+            if (g > gbest) { gbest = g; gi = i; }
+        }
+        kad_ok = best == S && bi == r.te && K[di0] == S;
+        skip_ok = kad_ok && gbest == S && gi == r.te;
+    }
+    if (ungapped) P[3]++;
+    if (kad_ok) P[4]++;
+    if (skip_ok) P[5]++;
+    if (n_act == 0) P[6]++;
+    if (skip_ok && n_act == 0) P[7]++;                       // the no-DP proof as it stands: every other diagonal quiet
+    for (int w = 0; w < 4; ++w) {
+        if (7 + vsum[w] < S) P[8 + w]++;                     // no path that avoids the band reaches the score
+        if (7 + vsum[w] < 19) P[12 + w]++;                   // ... nor min_seed_len
+        if (skip_ok && vsum[w] == 0) P[16 + w]++;
+    }
+    P[20] += (uint64_t)n_act; if ((uint64_t)qstar > P[21]) P[21] = (uint64_t)qstar;
+    if (S == qlen * o.a) { P[22]++; P[23] += (uint64_t)(tlen - 1 - r.te); }   // a perfect score: no later row can beat it, the forward pass could stop at te
+    P[24] += (uint64_t)tlen; P[25] += (uint64_t)S;
+    {   // how far the alignment strays from its end diagonal (the band a banded DP would need): from the start cell's diagonal
+        const int dev = std::abs((r.tb - r.qb) - d0);
+        if (dev <= 8) P[26]++;
+        if (dev <= 16) P[27]++;
+    }
+    if (n_act <= 3 && qstar <= 12) P[28]++;
+}
+
 int mem_matesw(const MemOpt& o, const Index& b, const PeStat pes[4], const AlnReg& a, int l_ms, const uint8_t* ms, std::vector<AlnReg>& ma, Counters* cn) {
     int64_t l_pac = b.l_pac;
     int i, r, skip[4], n = 0, rid = -1;
@@ -1123,6 +1207,7 @@ int mem_matesw(const MemOpt& o, const Index& b, const PeStat pes[4], const AlnRe
             std::vector<uint8_t> qcopy(seq, seq + l_ms);
             if (cn) ++cn->n_rescue;
             aln = ksw_align2(l_ms, qcopy.data(), (int)(re - rb), ref.data(), 5, o.mat, o.o_del, o.e_del, o.o_ins, o.e_ins, xtra, cn);
+            if (g_rescue_probe_on) rescue_probe(o, l_ms, qcopy.data(), (int)(re - rb), ref.data(), aln);
             if (aln.score >= o.min_seed_len && aln.qb >= 0) {   // something goes wrong if aln.qb < 0
                 bb.rid = a.rid;
                 bb.is_alt = a.is_alt;

@@ -17,6 +17,7 @@
 // Everything else (CIGARs, scores, MAPQ, RFA picks) is "parity unpinned": no
 // reference test asserts it and the reference cannot be built here (no Go, no BWA).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -26,6 +27,8 @@ namespace orc {
 typedef uint64_t bwtint_t;
 
 // ---- instrumentation: algorithmic-byte accounting ----------
+extern std::atomic<uint64_t> g_rescue_probe[64];   // tools/rescue_probe.py (bwa_mem.cpp: rescue_probe)
+extern int g_rescue_probe_on;
 struct Counters {
     uint64_t n_ext = 0;       // bwt_extend calls (each = one bwt_2occ4 = 2 occ-block reads of 64 B)
     uint64_t n_lf = 0;        // LF-mapping steps inside bwt_sa

@@ -349,4 +349,21 @@ int lo_stage_dump(const Index* idx, const lh_opts* opts, const lh_batch* b, lh_s
 }
 void lo_stage_dump_free(lh_stage_dump* d) { if (d) delete (DumpArena*)d->arena_; }
 
+// tests/test_oracle_middle.py: mem_matesw's Smith-Waterman as mem_matesw calls it (ksw_align2 with KSW_XSUBO | KSW_XSTART | KSW_XBYTE | min_seed_len, the
+// scoring of mem_opt_init) on a caller-supplied query and window (nt4 bytes); out = score, te, qe, tb, qb, score2, te2
+void lo_ksw_align2(int32_t qlen, const uint8_t* query, int32_t tlen, const uint8_t* target, int32_t* out) {
+    orc::MemOpt m;
+    std::vector<uint8_t> q(query, query + qlen), t(target, target + tlen);
+    const int xtra = 0x40000 | 0x80000 | (qlen * m.a < 250 ? 0x10000 : 0) | (m.min_seed_len * m.a);
+    orc::Kswr r = orc::ksw_align2(qlen, q.data(), tlen, t.data(), 5, m.mat, m.o_del, m.e_del, m.o_ins, m.e_ins, xtra, nullptr);
+    out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.tb; out[4] = r.qb; out[5] = r.score2; out[6] = r.te2;
+}
+
+// tools/rescue_probe.py: switch the per-attempt probe of mem_matesw's Smith-Waterman on (clearing its counters) or off; out (64 words) receives the counters
+void lo_rescue_probe(int on, uint64_t* out) {
+    if (out) for (int i = 0; i < 64; ++i) out[i] = orc::g_rescue_probe[i].load();
+    if (on) for (int i = 0; i < 64; ++i) orc::g_rescue_probe[i] = 0;
+    orc::g_rescue_probe_on = on;
+}
+
 }  // extern "C"

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""how many of mem_matesw's Smith-Watermans (gobwa.go:291,315 -> ksw_align2) could be settled WITHOUT the DP, counted on the oracle's own
+job list for the configs[4] input (GPU box: the index is built on the device and exported to the oracle; --small: a miniature genome, CPU only).
+
+Per attempt that yields a region (score >= min_seed_len), with K(d) = the best ungapped segment of window diagonal d and V(d) = what disjoint segments of
+d can add to a path that pays a gap (7) for each (bwa_mem.cpp: rescue_probe):
+  ungapped       the result lies on one diagonal d0
+  = Kadane       ... and is d0's best ungapped segment, first maximum (what a no-DP kernel would report)
+  no detour      ... and no path that leaves d0 around a bad stretch and comes back can tie it
+  all quiet      every other diagonal has K(d) <= 7: nothing off d0 can open a gap
+  PROVABLE       no detour AND all quiet: the proof that needs no DP at all
+  U(w) < S       no path that avoids the band |d - d0| <= w reaches the result's score (7 + sum of V(d) outside the band): necessary for a banded DP
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as C  # noqa: E402
+
+from lariat_amd import capi, workload  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--barcodes", type=int, default=100)
+    ap.add_argument("--small", action="store_true", help="helpers.repeat_family_case instead of configs[4] (no GPU needed)")
+    ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 8, 128))
+    a = ap.parse_args()
+    import helpers
+    import oracle_py
+    o = oracle_py.load()
+    o.L.lo_rescue_probe.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+    if a.small:
+        names, contigs, rs = helpers.repeat_family_case(13, a.barcodes)
+        oidx = o.index_build_naive(names, contigs)
+        b = helpers.batch_of(rs)
+        what = "helpers.repeat_family_case(13, %d)" % a.barcodes
+    else:
+        lib = capi.load_library()
+        g = workload.config4_genome(lib, 3060e6)
+        idx = lib.index_build_device(g["pac"], g["l_pac"], g["contigs"])
+        idx.set_alt(g["alt_flags"])
+        oidx = o.index_from_arrays(idx.export(), g["pac"])
+        oidx.set_alt(g["alt_flags"])
+        r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400, n_barcodes=a.barcodes, pairs_per_barcode=100)
+        b = capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"])
+        what = "configs[4] (workload.config4_genome, every read on a copy), %d barcodes x 100 pairs" % a.barcodes
+    o.L.lo_rescue_probe(1, None)
+    t0 = time.time()
+    oidx.time_align(b, threads=a.threads)
+    dt = time.time() - t0
+    out = (C.c_uint64 * 64)()
+    o.L.lo_rescue_probe(0, out)
+    P = [int(x) for x in out]
+    n, hit = P[0], P[2]
+    pc = lambda x: "%6.2f %%" % (100.0 * x / max(1, hit))
+    print("rescue probe on %s: oracle %.1f s on %d threads" % (what, dt, a.threads))
+    print("  mem_matesw Smith-Watermans        %d   (%.1f %% yield a region: score >= min_seed_len)" % (n, 100.0 * hit / max(1, n)))
+    print("  of those that yield a region:   mean score %.1f, mean window %.0f rows" % (P[25] / max(1, hit), P[24] / max(1, hit)))
+    print("    ungapped (one diagonal)         %s" % pc(P[3]))
+    print("    = its diagonal's Kadane segment %s" % pc(P[4]))
+    print("    no detour can tie it            %s" % pc(P[5]))
+    print("    all other diagonals quiet (<=7) %s   (active diagonals per window: mean %.2f, highest K %d)" % (pc(P[6]), P[20] / max(1, hit), P[21]))
+    print("    PROVABLE without any DP         %s" % pc(P[7]))
+    print("    at most 3 active, none above 12 %s" % pc(P[28]))
+    for i, w in enumerate((0, 8, 16, 32)):
+        print("    band |d - d0| <= %2d:  U < S %s   U < min_seed_len %s   no detour and V = 0 outside %s" % (w, pc(P[8 + i]), pc(P[12 + i]), pc(P[16 + i])))
+    print("    start and end diagonals within 8 / 16 of each other %s / %s" % (pc(P[26]), pc(P[27])))
+    print("    perfect score (forward pass may stop at te) %s, rows it would skip: %.1f %% of all rows" % (pc(P[22]), 100.0 * P[23] / max(1, P[24])))
+
+
+if __name__ == "__main__":
+    main()
