@@ -27,7 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")   # HBM-side counters of this workload (tools/pmc_summary.py), per kernel
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")   # HBM-side counters of this workload (tools/pmc_summary.py), per kernel
+K1_FLOOR_FILE = os.path.join(ROOT, "profiles", "r05_k1_request_floor.json")   # pass 1's request stream recorded and replayed without bookkeeping (tools/k1_trace.py)
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -43,6 +44,7 @@ def parse():
                                                           "are then execution times); 2 = every batch is cut at a barcode boundary and its halves are aligned side by side "
                                                           "inside ONE lh_align_resident call (+5 %: reported under two_lanes_pairs_per_s)")
     ap.add_argument("--repeats", action="store_true", help="only the configs[4] legs (repeats: every read on the copies of repeat families, tens to hundreds of candidates per read; mixed: 5 %% of every barcode's pairs on them); with --gpus N every rank runs them on its own batches")
+    ap.add_argument("--legs", default="repeats,mixed", help="with --repeats: which of the configs[4] legs to run")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --steps batches in total, split over the ranks (default weak: --steps per rank)")
     ap.add_argument("--cpu-sample-barcodes", type=int, default=10000, help="barcodes of the first batch timed on the host cores (cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,7 +145,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: liblariat_hip has no CPU fallback")
 
     if a.repeats:   # the configs[4] legs alone; under the launcher every rank runs them on its own batches (value = all ranks' pairs over the slowest rank's time)
-        legs = config4_legs(lib, a, local_rank, lib.opts(), rank=rank, dist=dist, share=share)
+        legs = config4_legs(lib, a, local_rank, lib.opts(), legs=tuple(a.legs.split(",")), rank=rank, dist=dist, share=share)
         if rank == 0:
             print(json.dumps(legs), flush=True)
         if dist is not None:
@@ -335,6 +337,7 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
         if k.get("FETCH_SIZE_KB") is not None and k.get("WRITE_SIZE_KB") is not None and k.get("calls"):
             traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["calls"]
             r["traffic_source"] = "profiles/%s (commit %s, %s)" % (os.path.basename(PMC_FILE), pmc.get("commit"), pmc.get("command"))
+            r["traffic_commit"] = pmc.get("commit")   # (the file's own commit: there is no git on the driver's box; the source-hash guard above is what keeps a stale file out)
             r["traffic_age_commits"] = commits_since(pmc.get("commit"))
             r["traffic_GBps"] = round(traffic / (ms * 1e-3) / 1e9, 2)
             r["traffic_frac"] = round(r["traffic_GBps"] / HBM_PEAK_GBPS, 5)
@@ -345,6 +348,22 @@ def roofline(lib, idx, avg, cnt, reads, device, a):
     r["traffic"] = traffic
     if stale:
         r["traffic_note"] = stale
+    if dom == "k_smem4" and os.path.exists(K1_FLOOR_FILE):
+        # what bounds the bracket, measured: k_smem_pass<1>'s own request stream (table, address, bytes per request: a -DLH_K1_TRACE build) replayed with the
+        # pass's launch geometry and nothing between the requests (k_k1_replay) = the floor of THIS stream on this chip; k_smem_first runs at the
+        # random-read ceiling already.  requests_by_table: [requests, bytes] of one 2 M-pair launch of k_smem_pass<1>
+        try:
+            fl = json.load(open(K1_FLOOR_FILE))
+            first_ms = fl.get("k_smem_first_ms")
+            r["request_floor"] = {"source": "profiles/%s (commit %s)" % (os.path.basename(K1_FLOOR_FILE), fl.get("commit")),
+                                  "k_smem_pass1_replay_ms": round(fl["replay_ms_avg"], 3), "k_smem_first_ms": first_ms,
+                                  "bracket_floor_ms": round(fl["replay_ms_avg"] + first_ms, 3) if first_ms else None,
+                                  "bracket_ms_when_measured": fl.get("pass1_bracket_ms"),
+                                  "headroom_frac_of_bracket": round(1.0 - (fl["replay_ms_avg"] + first_ms) / fl["pass1_bracket_ms"], 3) if first_ms else None,
+                                  "requests_total": fl.get("requests_total"), "bytes_total": fl.get("bytes_total")}
+            r["requests_by_table"] = fl.get("requests_by_table")
+        except Exception as e:   # noqa
+            r["request_floor"] = {"failed": "%s: %s" % (type(e).__name__, e)}
     # the whole K1 stage in the reference's bookkeeping (informational)
     k1_ms = sum(avg.get(k, 0.0) for k in k1)
     if k1_ms > 0:

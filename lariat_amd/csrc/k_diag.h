@@ -122,10 +122,11 @@ __global__ void __launch_bounds__(64) k_diag_resc_dedup(DIndex ix, DOpts o, int 
         u64 cells = 0;
         int n = wave_sort_dedup_patch(ix, o, nullptr, A, n0, I, T, 0, lane, &cells);   // the clean list
         const DReg b = mk(bvals + (size_t)c * 6);
-        int eq = 0;
-        for (int k = lane; k < n; k += 64) for (int u = 0; u < k; ++u) eq |= A[u].re == A[k].re;
-        if (__any(eq) || n + 1 > LH_RA_CAP) { if (lane == 0) { verdict[c] = 3; n_out[c] = n; } continue; }
+        if (n + 1 > LH_RA_CAP) { if (lane == 0) { verdict[c] = 3; n_out[c] = n; } continue; }
         for (int k = lane; k < n; k += 64) { const DReg g = A[k]; B[k] = g; W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k; }
+        WAVE_SYNC();
+        // equal end positions in the clean list: the replay keeps it in LDS only when every such tie is harmless (resc_list_ties marks the entries)
+        if (resc_list_ties(o, W, n, lane)) { if (lane == 0) { verdict[c] = 3; n_out[c] = n; } continue; }
         WAVE_SYNC();
         // (a) as written: b goes in before the first entry with a smaller score (mem_matesw), then the call
         int pos = n;

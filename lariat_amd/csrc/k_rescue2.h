@@ -73,6 +73,7 @@ struct RMeta {   // per direction, on the device
     int32_t hist[LH_RJ_NB], bstart[LH_RJ_NB + 1], bcur[LH_RJ_NB];       // forward jobs by slen; bstart: bucket starts in the order array, each padded to 8
     int32_t hist2[LH_RJ_NB], bstart2[LH_RJ_NB + 1], bcur2[LH_RJ_NB];    // reverse jobs
     int32_t list_count, long_count;   // listed pairs; those of them whose mate's list is too long for the replay's usual LDS arrays
+    int32_t heavy_count;              // pairs whose enumeration is a wave's (k_resc_enum_w)
 };
 
 // which attempts of one pair and direction get past mem_matesw's first test ("a consistent pair exists; no need to perform SW") against the
@@ -116,17 +117,21 @@ __device__ __forceinline__ int resc_fast_ok(const DOpts& o, int l_ms, i64 tlen) 
     return l_ms * o.a < 250 && o.a + o.b <= 16 && o.a > 0 && o.b >= 0 && o.o_del + o.e_del < 256 && o.o_ins + o.e_ins < 256 && tlen <= LH_RJ_TMAX && l_ms >= 1;
 }
 
+#ifndef LH_RE_HEAVY
+#define LH_RE_HEAVY 256   // anchors x mate regions from which on a pair's enumeration is a wave's (k_resc_enum_w)
+#endif
 // One lane per pair.  EMIT = false: count the pair's jobs (n_jobs[p]), their bucket's histogram, and list the pairs with any attempt to
 // replay.  EMIT = true (after the scan of n_jobs and k_resc_offsets): write the jobs and their places in the order array.
 template <int DIR, bool EMIT>
 __global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
                                                     const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, const int32_t* __restrict__ best_score, int32_t* __restrict__ n_jobs,
                                                     const i64* __restrict__ job_off, RJob* __restrict__ jobs, int32_t* __restrict__ order, RMeta* __restrict__ meta,
-                                                    int32_t* __restrict__ list) {
+                                                    int32_t* __restrict__ list, int32_t* __restrict__ heavy) {
     __shared__ int32_t sh_hist[LH_RJ_NB];
     const int slot = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     // the counting pass looks at every pair; the emitting pass only at the pairs it listed (a few thousand of two million on unique sequence)
-    const int p = EMIT ? (slot < meta->list_count ? list[slot] & 0x3fffffff : n_pairs) : slot;
+    // (EMIT: the pairs a wave enumerates — bit 29 of their entry — are that kernel's)
+    const int p = EMIT ? (slot < meta->list_count && !(list[slot] & (1 << 29)) ? list[slot] & 0x1fffffff : n_pairs) : slot;
     if (!EMIT) { if (threadIdx.x < LH_RJ_NB) sh_hist[threadIdx.x] = 0; __syncthreads(); }
     int nj = 0, need = 0, slen = 0, obase = 0;
     if (EMIT) {   // the pair's places in the order array: one reservation per wave and bucket
@@ -146,8 +151,18 @@ __global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pai
             todo &= ~__ballot(mine);
         }
     }
-    int long_list = 0;
-    if (p < n_pairs) {
+    int long_list = 0, is_heavy = 0;
+    if (!EMIT) {   // anchors x mate regions beyond what one lane should walk (reads on repeat copies: a hundred of each): listed for k_resc_enum_w
+        if (p < n_pairs) is_heavy = (i64)n_regs[DIR ? 2 * p : 2 * p + 1] * (i64)n_regs[DIR ? 2 * p + 1 : 2 * p] > LH_RE_HEAVY;
+        const u64 hm = __ballot(is_heavy);
+        if (hm) {
+            int hb = 0;
+            if (lane == 0) hb = atomicAdd(&meta->heavy_count, (int32_t)__popcll(hm));
+            hb = wave_readlane(hb, 0);
+            if (is_heavy) { heavy[hb + lanes_below(hm, lane)] = p; n_jobs[p] = 0; }
+        }
+    }
+    if (p < n_pairs && !is_heavy) {
         RescWalk w;
         w.init(DIR, p, seq_off, reg_off, regs, n_regs, best_score);
         long_list = w.nm + o.rescue_max_hits > LH_RA_CAP;
@@ -200,6 +215,95 @@ __global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pai
         }
         __syncthreads();
         if (threadIdx.x < LH_RJ_NB && sh_hist[threadIdx.x]) atomicAdd(&meta->hist[threadIdx.x], sh_hist[threadIdx.x]);
+    }
+}
+
+// The same enumeration for a pair with many anchors and many mate regions, by a whole wave (r05): a lane walking 100 x 100 region records alone was what the
+// enumeration's 10 ms per launch were.  The mate's region starts in LDS, an anchor's first test against all of them with one ballot per 64.
+#define LH_RE_CAP 1024
+template <int DIR, bool EMIT>
+__global__ void __launch_bounds__(64) k_resc_enum_w(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
+                                                     const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, const int32_t* __restrict__ best_score, int32_t* __restrict__ n_jobs,
+                                                     const i64* __restrict__ job_off, RJob* __restrict__ jobs, int32_t* __restrict__ order, RMeta* __restrict__ meta,
+                                                     int32_t* __restrict__ list, const int32_t* __restrict__ heavy) {
+    __shared__ i64 mrb[LH_RE_CAP];
+    const int lane = LANE();
+    const int n_items = meta->heavy_count;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int p = heavy[item];
+        RescWalk w;
+        w.init(DIR, p, seq_off, reg_off, regs, n_regs, best_score);
+        WAVE_SYNC();   // the previous pair's starts have been read
+        const int ncap = w.nm < LH_RE_CAP ? w.nm : LH_RE_CAP;
+        for (int j = lane; j < ncap; j += 64) mrb[j] = w.ma[j].rb;
+        WAVE_SYNC();
+        const int long_list = w.nm + o.rescue_max_hits > LH_RA_CAP;
+        const int slen = (w.l_ms + 15) / 16;
+        int nj = 0, need = 0, has_n = -1, num = 0, obase = 0;
+        const i64 jbase = EMIT ? job_off[p] : 0;
+        if (EMIT) {
+            const int want = n_jobs[p];
+            if (want) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&meta->bcur[slen], want);
+                obase = meta->bstart[slen] + wave_readlane(base, 0);
+            }
+        }
+        for (int i0 = 0; i0 < w.nf && num < o.rescue_max_hits && w.l_ms > 0; i0 += 64) {
+            int a_sc = 0, a_rid = 0;
+            i64 a_rb = 0;
+            if (i0 + lane < w.nf) { const DReg& g = w.from[i0 + lane]; a_sc = g.score; a_rb = g.rb; a_rid = g.rid; }
+            const int nu = w.nf - i0 < 64 ? w.nf - i0 : 64;
+            for (int u = 0; u < nu && num < o.rescue_max_hits; ++u) {
+                DReg a;
+                a.score = wave_readlane(a_sc, u);
+                if (a.score < w.bestf - o.rescue_score_delta) continue;
+                num++;
+                a.rb = (i64)((u64)(uint32_t)wave_readlane((int)((u64)a_rb >> 32), u) << 32 | (u64)(uint32_t)wave_readlane((int)(uint32_t)(u64)a_rb, u));
+                a.rid = wave_readlane(a_rid, u);
+                int skip1 = 0;
+                for (int j0 = 0; j0 < w.nm && !skip1; j0 += 64) {
+                    const int j = j0 + lane;
+                    int f = 0;
+                    if (j < w.nm) {
+                        i64 dist;
+                        const int r = dev_infer_dir(ix.l_pac, a.rb, j < ncap ? mrb[j] : w.ma[j].rb, &dist);
+                        f = (r == 1 && dist >= o.pes_low && dist <= o.pes_high);
+                    }
+                    skip1 = __any(f);
+                }
+                if (skip1) continue;
+                i64 rb, re;
+                if (!resc_window(ix, o, a, w.l_ms, &rb, &re)) continue;
+                need = 1;
+                if (!resc_fast_ok(o, w.l_ms, re - rb)) continue;
+                if (has_n < 0) {   // an ambiguous base in the mate scores -1 against everything: left to the wave kernel (k_resc_apply)
+                    const i64 so = seq_off[w.r_ms];
+                    int hn = 0;
+                    for (int k = lane; k < w.l_ms; k += 64) hn |= seq[so + k] > 3;
+                    has_n = __any(hn);
+                }
+                if (has_n) continue;
+                if (EMIT && lane == 0) {
+                    RJob jb;
+                    jb.t0 = rb; jb.q0 = (int32_t)(seq_off[w.r_ms] + w.l_ms - 1); jb.pair = p;
+                    jb.qlen = (int16_t)w.l_ms; jb.tlen = (int16_t)(re - rb); jb.anchor = (int16_t)(i0 + u);
+                    jb.score = 0; jb.te = -1; jb.qe = -1; jb.tb = -1; jb.qb = -1; jb.rows2 = 0; jb.pad_ = 0;
+                    jobs[jbase + nj] = jb;
+                    order[obase + nj] = (int32_t)(jbase + nj);
+                }
+                nj++;
+            }
+        }
+        if (!EMIT && lane == 0) {
+            n_jobs[p] = nj;
+            if (nj) atomicAdd(&meta->hist[slen], nj);
+            if (need) {
+                const int at = atomicAdd(&meta->list_count, 1);
+                if (long_list) atomicAdd(&meta->long_count, 1);
+                list[at] = p | (long_list ? 1 << 30 : 0) | 1 << 29;   // bit 29: enumerated by this kernel
+            }
+        }
     }
 }
 
@@ -387,6 +491,7 @@ __global__ void __launch_bounds__(64) k_resc_sw(DIndex ix, DOpts o, RJob* __rest
 template <int CAP> struct RescListT {
     i64 rb[CAP], re[CAP];   // (first: wave_sort_dedup_patch's scratch while the list is in memory)
     int32_t qb[CAP], qe[CAP], score[CAP], rid[CAP], src[CAP];   // src: the entry's place in the memory arrays when the list was loaded; -1: rescued since
+    uint8_t tied[CAP];      // the entry shares its re with another entry of its contig (a HARMLESS tie, see resc_list_ties: the two are not redundant whichever comes first)
 };
 typedef RescListT<LH_RA_CAP> RescList;
 // "one of the hits is redundant": q = the entry with the smaller re (mem_sort_dedup_patch's a[j]), p = the one with the larger
@@ -421,7 +526,7 @@ template <int CAP> __device__ __forceinline__ void resc_list_sort(RescListT<CAP>
     WAVE_SYNC();
 #pragma unroll
     for (int t = 0; t < PER; ++t)
-        if (rank[t] >= 0) { const int d = rank[t]; W.re[d] = e[t]; W.rb[d] = krb[t]; W.qb[d] = kqb[t]; W.qe[d] = kqe[t]; W.score[d] = ksc[t]; W.rid[d] = krid[t]; W.src[d] = ksrc[t]; }
+        if (rank[t] >= 0) { const int d = rank[t]; W.re[d] = e[t]; W.rb[d] = krb[t]; W.qb[d] = kqb[t]; W.qe[d] = kqe[t]; W.score[d] = ksc[t]; W.rid[d] = krid[t]; W.src[d] = ksrc[t]; }   // (W.tied is not carried: the list leaves LDS after this)
     WAVE_SYNC();
 }
 // the list in LDS back into the memory arrays: entries that were there when it was loaded (src >= 0) keep their other fields, rescued ones get mem_matesw's
@@ -461,6 +566,8 @@ template <int CAP> __device__ __forceinline__ int resc_dedup_incremental(const D
             const i64 e = W.re[k], krb = W.rb[k];
             const int ksc = W.score[k], kqb = W.qb[k];
             tie |= e == b.re || (ksc == b.score && krb == b.rb && kqb == b.qb);
+            // an entry that shares its re with another one: which of the two b's scan (or theirs, of b) meets first is the introsort's to say: the call as written
+            tie |= W.tied[k] && (e < b.re ? b.rb < e + o.max_chain_gap : krb < b.re + o.max_chain_gap);
             if (W.rid[k] != b.rid) { if (e < b.re && e > lo_bar) lo_bar = e; if (e > b.re && e < hi_bar) hi_bar = e; }
             else if (e < b.re) {
                 if (b.rb < e + o.max_chain_gap && b.score < ksc && e > r_cand && resc_redundant(o, krb, e, kqb, W.qe[k], b.rb, b.re, b.qb, b.qe)) r_cand = e;
@@ -480,7 +587,7 @@ template <int CAP> __device__ __forceinline__ int resc_dedup_incremental(const D
     for (int i0 = 0; i0 < n_ma; i0 += 64) {   // the entries b excludes: to its left while it goes left (down to r_star), to its right while it is alive (up to s_star)
         const int k = i0 + lane;
         int dead = 0;
-        i64 e = 0, krb = 0; int kqb = 0, kqe = 0, ksc = 0, krid = 0, ksrc = 0;
+        i64 e = 0, krb = 0; int kqb = 0, kqe = 0, ksc = 0, krid = 0, ksrc = 0, ktie = 0;
         if (k < n_ma) {
             e = W.re[k]; krb = W.rb[k]; kqb = W.qb[k]; kqe = W.qe[k]; ksc = W.score[k]; krid = W.rid[k];
             if (e < b.re && e > lo_bar && e > r_star && krid == b.rid && b.rb < e + o.max_chain_gap && !(b.score < ksc))
@@ -491,9 +598,9 @@ template <int CAP> __device__ __forceinline__ int resc_dedup_incremental(const D
         const u64 mk = __ballot(k < n_ma && !dead);
         compact |= __any(dead);
         if (compact) {   // (wave-uniform) from the first chunk with an excluded entry on, the survivors move up
-            if (k < n_ma) ksrc = W.src[k];
+            if (k < n_ma) { ksrc = W.src[k]; ktie = W.tied[k]; }
             WAVE_SYNC();   // every lane holds its entry before any is moved
-            if (k < n_ma && !dead) { const int d = n_new + lanes_below(mk, lane); W.re[d] = e; W.rb[d] = krb; W.qb[d] = kqb; W.qe[d] = kqe; W.score[d] = ksc; W.rid[d] = krid; W.src[d] = ksrc; }
+            if (k < n_ma && !dead) { const int d = n_new + lanes_below(mk, lane); W.re[d] = e; W.rb[d] = krb; W.qb[d] = kqb; W.qe[d] = kqe; W.score[d] = ksc; W.rid[d] = krid; W.src[d] = ksrc; W.tied[d] = (uint8_t)ktie; }
             WAVE_SYNC();
         }
         n_new += __popcll(mk);
@@ -501,13 +608,46 @@ template <int CAP> __device__ __forceinline__ int resc_dedup_incremental(const D
     n_ma = n_new;
     *appended = b_alive;
     if (b_alive) {
-        if (lane == 0) { W.re[n_ma] = b.re; W.rb[n_ma] = b.rb; W.qb[n_ma] = b.qb; W.qe[n_ma] = b.qe; W.score[n_ma] = b.score; W.rid[n_ma] = b.rid; W.src[n_ma] = -1; }
+        if (lane == 0) { W.re[n_ma] = b.re; W.rb[n_ma] = b.rb; W.qb[n_ma] = b.qb; W.qe[n_ma] = b.qe; W.score[n_ma] = b.score; W.rid[n_ma] = b.rid; W.src[n_ma] = -1; W.tied[n_ma] = 0; }
         n_ma++;
         WAVE_SYNC();
     }
     return n_ma;
 }
 
+// Equal end positions in a list just loaded into W (n entries, any order).  mem_sort_dedup_patch sorts by re with an unstable sort: which of two entries
+// with the same re its scan takes as "p" and which as "q" is the introsort's to say, call by call.  If the two — of one contig — are not redundant WHICHEVER comes first
+// (the rule's two overlap tests fail both ways) no call ever does anything to either on the other's account: the tie is harmless
+// and the entries are only marked (W.tied: a later region that comes near one of them sends its call to the code as written).  Returns 1 if the list
+// holds a tie that is not harmless (the calls run as written from then on), else 0.
+template <int CAP> __device__ __forceinline__ int resc_list_ties(const DOpts& o, RescListT<CAP>& W, int n, int lane) {
+    int harmful = 0;
+    for (int k = lane; k < n; k += 64) {
+        const i64 pre = W.re[k], prb = W.rb[k];
+        const int pqb = W.qb[k], pqe = W.qe[k], prid = W.rid[k];
+        int t = 0;
+        for (int u = 0; u < n; ++u) {
+            if (u == k || W.re[u] != pre) continue;
+            t = 1;
+            // (an equal re on ANOTHER contig cannot happen with real coordinates — a position belongs to one contig — but if it did, the entry would end
+            // the scans of its neighbours' contig or not, depending on where the sort puts it: pairs never compared before would be: not harmless)
+            if (W.rid[u] != prid) harmful = 1;
+            else harmful |= resc_redundant(o, W.rb[u], pre, W.qb[u], W.qe[u], prb, pre, pqb, pqe) || resc_redundant(o, prb, pre, pqb, pqe, W.rb[u], pre, W.qb[u], W.qe[u]);
+        }
+        W.tied[k] = (uint8_t)t;
+    }
+    return __any(harmful);
+}
+
+// development aid (-DLH_RFA_PROF): shader clocks per part of the replay, and how its calls were decided
+#ifdef LH_RFA_PROF
+__device__ unsigned long long lh_resc_prof[24];
+#define RA_PROF(k_) { const unsigned long long now_ = (unsigned long long)clock64(); if (lane == 0) atomicAdd(&lh_resc_prof[k_], now_ - prof_t_); prof_t_ = (unsigned long long)clock64(); }
+#define RA_COUNT(k_) { if (lane == 0) atomicAdd(&lh_resc_prof[k_], 1ull); }
+#else
+#define RA_PROF(k_) {}
+#define RA_COUNT(k_) {}
+#endif
 template <int DIR, int CAP>
 __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
                                                     DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool, int32_t* __restrict__ n_regs,
@@ -521,7 +661,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
         // two instances of this kernel share the list: the one with the usual LDS arrays takes the pairs whose mate's list fits them with everything that
         // may come, the one with LH_RA_CAP_BIG entries the others (k_resc_enum decided, bit 30 of the entry: every pair is replayed exactly once)
         if (((list[item] >> 30) & 1) != (CAP != LH_RA_CAP)) continue;
-        const int p = list[item] & 0x3fffffff;
+        const int p = list[item] & 0x1fffffff;
         const int r1 = 2 * p, r2 = 2 * p + 1;
         const int r_ms = DIR ? r2 : r1, r_from = DIR ? r1 : r2;
         WAVE_SYNC();   // the previous pair's query and list are no longer in use
@@ -545,24 +685,34 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
         if (jreg && lane < npj) myjob = pj[lane];
         int a_sc = 0, a_rid = 0, a_alt = 0;
         i64 a_rb = 0;
+        u64 amask = 0;
         int jp = 0;
         u64 cells = 0;
         int n_sw = 0, num = 0;
         int w_sorted = 1;   // the list in LDS is in the call's final order (until a rescued region is appended)
         int mode = 0;   // 0: the list is in memory, no dedup call yet; 1: in LDS (W), clean; 2: in memory for good (equal re left behind / too long); 3: in memory for this call
+#ifdef LH_RFA_PROF
+        unsigned long long prof_t_ = (unsigned long long)clock64();
+        RA_COUNT(8)
+#endif
         for (int i = 0; i < nf && num < o.rescue_max_hits && l_ms > 0; ++i) {
             if ((i & 63) == 0) {
                 const int k = i + lane;
                 if (k < nf) { const DReg& g = from[k]; a_sc = g.score; a_rb = g.rb; a_rid = g.rid; a_alt = g.is_alt; }
+                amask = __ballot(k < nf && a_sc >= bestf - o.rescue_score_delta);   // the chunk's anchors that pass gobwa.go's score test
+            }
+            {   // (r05) straight to the next anchor that passes: a list of several hundred regions has its fifty best in front
+                const u64 rest = amask >> (i & 63);
+                if (!(rest & 1)) { if (!rest) i |= 63; else i += __ffsll((unsigned long long)rest) - 2; continue; }
             }
             DReg a;
             a.score = wave_readlane(a_sc, i & 63);
-            if (a.score < bestf - o.rescue_score_delta) continue;
             a.rb = (i64)((u64)(uint32_t)wave_readlane((int)((u64)a_rb >> 32), i & 63) << 32 | (u64)(uint32_t)wave_readlane((int)(uint32_t)(u64)a_rb, i & 63));
             a.rid = wave_readlane(a_rid, i & 63); a.is_alt = wave_readlane(a_alt, i & 63);
             num++;
             if (jreg) jp = (int)__popcll(__ballot(lane < npj && myjob.anchor < i));   // (jobs of attempts that have become unnecessary are passed over)
             else while (jp < npj && pj[jp].anchor < i) ++jp;
+            RA_PROF(16)
             int skip1 = 0;
             for (int i0 = 0; i0 < n_ma; i0 += 64) {                 // which orientation has been found
                 int k = i0 + lane, f = 0;
@@ -573,10 +723,12 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 }
                 if (__any(f)) { skip1 = 1; break; }
             }
+            RA_PROF(0)
             if (skip1) continue;
             i64 rb, re;
             if (!resc_window(ix, o, a, l_ms, &rb, &re)) continue;
             n_sw++;
+            RA_COUNT(9)
             KswR aln;
             if (jp < npj && (jreg ? wave_readlane((int)myjob.anchor, jp) : (int)pj[jp].anchor) == i) {
                 RJob J;
@@ -589,9 +741,13 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 cells += (u64)(16 * ((l_ms + 15) / 16)) * (u64)J.tlen;
                 if (J.score >= o.min_seed_len * o.a) cells += (u64)(16 * ((J.qe + 1 + 15) / 16)) * (u64)J.rows2;
             } else {   // no job: an attempt the enumeration saw as unnecessary (or left to this kernel): k_rescue.h's wave-wide kernel
+                RA_PROF(1)
                 aln = wave_ksw_align2(ix, o, qm, l_ms - 1, -1, 1, l_ms, rb, 1, (int)(re - rb), o.min_seed_len * o.a, lane, &cells);
+                RA_PROF(17)
+                RA_COUNT(18)
             }
             const int hit = aln.score >= o.min_seed_len && aln.qb >= 0;
+            RA_PROF(1)
             DReg b;
             if (hit) {
                 b.rid = a.rid; b.is_alt = a.is_alt;
@@ -617,20 +773,25 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                         const int pqb = W.qb[k], pqe = W.qe[k], prid = W.rid[k], psc = W.score[k];
                         for (int u = 0; u < n_ma; ++u) {
                             const i64 qre = W.re[u];
-                            if (u != k && qre == pre) dirty = 1;
                             if (qre < pre && W.rid[u] == prid && prb < qre + o.max_chain_gap && resc_redundant(o, W.rb[u], qre, W.qb[u], W.qe[u], prb, pre, pqb, pqe)) dirty = 1;
                             if (u < k && (W.score[u] < psc || (W.score[u] == psc && (W.rb[u] > prb || (W.rb[u] == prb && W.qb[u] >= pqb))))) dirty = 1;   // (not in the call's final order)
                         }
                     }
                 }
                 mode = __any(dirty) ? 0 : 1;
+                if (mode == 1 && resc_list_ties(o, W, n_ma, lane)) mode = 0;   // (two entries with one re that are redundant one way round: the first call as written)
+                WAVE_SYNC();
+                RA_PROF(2)
+                if (mode == 0) RA_COUNT(10)
             }
             if (mode == 1) {
                 if (!hit) continue;   // a clean list and nothing new: the call changes nothing
                 {   // the call as a function of b
                     int app = 0;
                     const int n_inc = resc_dedup_incremental(o, W, n_ma, b, lane, &app);
-                    if (n_inc >= 0) { n_ma = n_inc; if (app) w_sorted = 0; continue; }
+                    RA_PROF(3)
+                    if (n_inc >= 0) { n_ma = n_inc; if (app) w_sorted = 0; RA_COUNT(11) continue; }
+                    RA_COUNT(12)
                 }
                 // equal keys: this call as written, on the list in memory (mode 3: it may come back if the call leaves no equal re behind)
                 resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane, w_sorted);
@@ -656,7 +817,10 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 n_ma++;
                 WAVE_SYNC();
             }
+            RA_PROF(4)
+            RA_COUNT(13)
             n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells, (i64*)&W, 2 * CAP);   // (the list is in memory during the call: W's two 64-bit arrays are the sorts' scratch)
+            RA_PROF(5)
             if (mode != 2 && n_ma + o.rescue_max_hits <= CAP) {   // (back) into LDS if the list fits with everything that may still come and no two re are equal
                 for (int k = lane; k < n_ma; k += 64) {
                     const DReg& g = ma[k];
@@ -664,18 +828,15 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 }
                 WAVE_SYNC();
                 w_sorted = 1;
-                int eq = 0;
-                if (mode == 0) {   // the first call is behind: any pair
-                    for (int k = lane; k < n_ma; k += 64) { const i64 e = W.re[k]; for (int u = 0; u < k; ++u) eq |= W.re[u] == e; }
-                } else if (hit) {  // the list was clean before b came: only b can share its re with another entry
-                    int nb_ = 0;
-                    for (int k = lane; k < n_ma; k += 64) nb_ += W.re[k] == b.re;
-                    eq = wave_sum_i32(nb_) > 1;
-                }
-                mode = __any(eq) ? 2 : 1;
-            } else mode = 2;
+                // equal end positions left behind: harmless ones are marked, one that is not keeps the list in memory for good
+                mode = resc_list_ties(o, W, n_ma, lane) ? 2 : 1;
+                WAVE_SYNC();
+                if (mode == 2) RA_COUNT(14)
+            } else { mode = 2; RA_COUNT(15) }
+            RA_PROF(6)
         }
         if (mode == 1) resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane, w_sorted);
+        RA_PROF(7)
         if (lane == 0) {
             n_regs[r_ms] = n_ma;
             if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); }

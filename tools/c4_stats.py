@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--lib", default=None, help="another build of the library (e.g. the -DLH_RFA_PROF one of tools/prof_rfa.sh)")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--frac", type=float, default=1.0, help="share of every barcode's pairs drawn on the repeat copies (bench.py's mixed leg: 0.05)")
     a = ap.parse_args()
     lib = capi.load_library(a.lib)
     g = workload.config4_genome(lib, a.genome_mb * 1e6, quiet=False)
@@ -66,7 +67,14 @@ def main():
     ctx = idx.context(n_pairs)
     opts = lib.opts(flags=a.flags)
     for s in range(a.steps):
-        r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400 + s, n_barcodes=a.barcodes, pairs_per_barcode=100)
+        if a.frac >= 1.0:
+            r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400 + s, n_barcodes=a.barcodes, pairs_per_barcode=100)
+        else:
+            uniq = workload.outside_windows(g["contigs"], g["alt_flags"], g["windows"])
+            n_rep = int(round(100 * a.frac))
+            ra = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 700 + s, n_barcodes=a.barcodes, pairs_per_barcode=n_rep)
+            rb = lib.synth_reads(g["pac"], g["l_pac"], uniq, seed=workload.READS_SEED + 100700 + s, n_barcodes=a.barcodes, pairs_per_barcode=100 - n_rep)
+            r = workload.interleave_reads(ra, rb)
         ctx.upload_slot(s, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
     ctx.select(0)
     ctx.align_resident(opts)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# kernel-trace statistics and the three PMC passes of bench.py on the GPU box (usage: bash tools/profile_all.sh <commit>); writes gpurun_out/prof_r04/
+# kernel-trace statistics and the three PMC passes of bench.py on the GPU box (usage: bash tools/profile_all.sh <commit>); writes gpurun_out/prof_r05/
 set -x
 REPO=$PWD
-OUT=$REPO/gpurun_out/prof_r04
+OUT=$REPO/gpurun_out/prof_r05
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
@@ -17,7 +17,7 @@ python3 tools/pmc_summary.py --out $OUT/pmc.json --commit $1 --command "rocprofv
 grep "^{" $OUT/kt.log | tail -n 1 > $OUT/kt_bench.json
 rm -rf $OUT/kt $OUT/p1 $OUT/p2 $OUT/p3
 ls -la $OUT
-# the configs[4] leg alone (repeat families, every read on the copies): kernel-trace statistics of `bench.py --repeats`
+# the configs[4] legs alone (repeats: every read on the copies of repeat families; mixed: 5 % of every barcode's pairs): kernel-trace statistics of `bench.py --repeats`
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt4 -- python3 $REPO/bench.py --repeats > $OUT/kt_repeats.log 2>&1
 cd $REPO
