@@ -38,6 +38,36 @@ __device__ __forceinline__ int wave_patch_reg(const DIndex& ix, const DOpts& o, 
 // lk / lk_cap: LDS scratch for the two sorts (may be null).  With it, what the introsorts move is one 64-bit word per region — the sort key with the
 // region's index in its low 9 bits, compared without them — instead of an index whose every comparison reads two region records from memory: the
 // same comparisons, the same moves, the same order for equal keys.
+// lk[0, n): 64-bit sort keys with the element's index in their low `ib` bits.  When no two keys are equal above those bits there is only one sorted order,
+// whatever the algorithm: every lane ranks its elements against all of them (n / 64 LDS sweeps) and the keys go to their places.  Returns 1 if that was done;
+// 0 (lk untouched) when two keys are equal — the introsort's order of equal keys is part of the result — or n is beyond what the lanes' registers hold.
+#define LH_RANKSORT_MAX 512
+__device__ __forceinline__ int wave_rank_sort_keys(i64* lk, int n, int ib, int lane) {
+    if (n > LH_RANKSORT_MAX) return 0;
+    constexpr int PER = LH_RANKSORT_MAX / 64;
+    i64 key[PER];
+    int rank[PER];
+    int tie = 0;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int e = t * 64 + lane;
+        rank[t] = -1;
+        if (t * 64 < n && e < n) {
+            key[t] = lk[e];
+            const i64 k = key[t] >> ib;
+            int rk = 0;
+            for (int j = 0; j < n; ++j) { const i64 kj = lk[j] >> ib; rk += kj < k; tie |= (kj == k) & (j != e); }
+            rank[t] = rk;
+        }
+    }
+    if (__any(tie)) return 0;
+    WAVE_SYNC();   // every lane has read its keys
+#pragma unroll
+    for (int t = 0; t < PER; ++t) if (rank[t] >= 0) lk[rank[t]] = key[t];
+    WAVE_SYNC();
+    return 1;
+}
+
 __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOpts& o, const uint8_t* q, DReg* av, int n, int32_t* ia, DReg* tmp,
                                                      int do_patch, int lane, u64* cells, i64* lk = nullptr, int lk_cap = 0) {
     if (n <= 1) return n;
@@ -45,7 +75,9 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     const int ib = n <= 512 ? 9 : 11;   // bits of the region index below the key
     for (int i = lane; i < n; i += 64) { ia[i] = i; av[i].n_comp = 1; if (packed) lk[i] = av[i].re << ib | (i64)i; }
     WAVE_SYNC();
-    if (lane == 0) {   // sort by the END position, not START!
+    // sort by the END position, not START!  (r05: all end positions different — the usual list — is one sorted order: ranked by the whole wave)
+    const int ranked1 = packed && wave_rank_sort_keys(lk, n, ib, lane);
+    if (!ranked1 && lane == 0) {
         if (packed) dev_introsort(n, lk, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); }, o.wd);
         else dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; }, o.wd);
     }
@@ -55,10 +87,20 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
         WAVE_SYNC();
     }
     int wd = 1000000;
-    for (int i = 1; i < n; ++i) {
+    // (r05) the scan only does something at an entry whose predecessor lies on its contig within max_chain_gap — decided for 64 entries at once from fields that
+    // no earlier step of the scan changes (an entry's own rb before its turn, its predecessor's re and rid): on repeat families most regions stand alone
+    for (int c0 = 0; c0 < n; c0 += 64) {
+    u64 act;
+    {
+        const int i = c0 + lane;
+        int a_ = 0;
+        if (i >= 1 && i < n) { const DReg& P = av[ia[i]]; const DReg& PM = av[ia[i - 1]]; a_ = !(P.rid != PM.rid || P.rb >= PM.re + o.max_chain_gap); }
+        act = __ballot(a_);
+    }
+    while (act) {
+        const int i = c0 + __ffsll((unsigned long long)act) - 1;
+        act &= act - 1;
         DReg p = av[ia[i]];
-        DReg pm = av[ia[i - 1]];
-        if (p.rid != pm.rid || p.rb >= pm.re + o.max_chain_gap) continue;   // then no need to go into the loop below
         for (int j = i - 1; j >= 0; --j) {
             DReg qq = av[ia[j]];
             LH_WATCH_D(o.wd, wd, 4, break)
@@ -92,6 +134,7 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
         }
         WAVE_SYNC();
     }
+    }
     WAVE_SYNC();   // all lanes are done reading ia[]/av[] before lane 0 compacts and re-sorts them
     int m = 0;
     if (lane == 0) {
@@ -117,7 +160,7 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     }
     WAVE_SYNC();
     if (pk2) {
-        if (lane == 0) dev_introsort(m, lk, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); }, o.wd);
+        if (!wave_rank_sort_keys(lk, m, ib, lane) && lane == 0) dev_introsort(m, lk, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); }, o.wd);
         WAVE_SYNC();
         for (int i = lane; i < m; i += 64) ia[i] = (int)(lk[i] & ((1 << ib) - 1));
         WAVE_SYNC();

@@ -273,108 +273,67 @@ __device__ __forceinline__ void dev_tag_pair_serial(const DCand& R, const DInf& 
 #endif
 static_assert(24 * LH_RFA_MQ_CHUNK <= LH_RFA_LDS_BYTES, "mate staging of estimateMapQualities");
 
-// One wavefront per barcode; barcodes are handed out through the device counter *bc_next (their costs differ widely).
-// A barcode whose tables do not fit the wave's slab (the reader caps a work unit at 30,000 pairs, fastqreader/reader.go:205,
-// far above the common few hundred) is appended to ovf_list and processed by a second launch whose few waves own much
-// larger slabs (work_list = that list); only there an overflow is final (LH_ST_POOL_OVERFLOW).
-// development aid (tools/prof_rfa.sh builds a library with -DLH_RFA_PROF): shader-clock time per phase of the barcode program, summed over the waves
-#ifdef LH_RFA_PROF
-__device__ unsigned long long lh_rfa_prof[24];
-#define RFA_PROF(k_) { const unsigned long long now_ = (unsigned long long)clock64(); if (lane == 0) atomicAdd(&lh_rfa_prof[k_], now_ - prof_t_); prof_t_ = (unsigned long long)clock64(); }
-#else
-#define RFA_PROF(k_)
-#endif
-#ifndef LH_RFA_WAVES
-#define LH_RFA_WAVES 4   // waves per SIMD the register budget is sized for (128 VGPRs + 64 spilled: the kernel waits on memory, 4 waves hide more of it than 2 waves of 190 registers)
-#endif
-__global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
-                                             const u64* __restrict__ name_seed, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S, i64 cand_cap,
-                                             uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status, int32_t* __restrict__ bc_next,
-                                             const int32_t* __restrict__ work_list, const int32_t* __restrict__ work_count, int32_t* __restrict__ ovf_list,
-                                             int32_t* __restrict__ ovf_count) {
-    __shared__ int32_t shi[8];
-    __shared__ double shd[4];
-    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LH_RFA_LDS_BYTES];   // one buffer, re-used phase by phase
-    i64* const spos = (i64*)lds_raw;                                               // position sort
-    int32_t* const sidx = (int32_t*)(lds_raw + 8 * LH_RFA_SORT_LDS);
-    int32_t* const sLr = (int32_t*)lds_raw;                                        // fastScore source staging
-    int32_t* const sFl = sLr + LH_RFA_SRC_CHUNK;
-    double* const sLap = (double*)(sFl + LH_RFA_SRC_CHUNK);
+
+// ---- K8 in pieces (r05).  What a barcode's wave did for its heavy pairs and reads one after the other — tagBestAlignments for a pair with thousands of
+// (alignment, mate alignment) combinations, estimateMapQualities for a read with a hundred alignments — needs nothing of the barcode's tables: a pair's
+// candidates and its name's seed; a read's candidates, the active links and the barcode's molecule penalty.  Those run as kernels of their own, a wave
+// per listed PAIR / READ over the whole batch (k_rfa_tag_w, k_rfa_mq_w), and with them the defaults (k_rfa_init: a thread per candidate) and the light pairs
+// (k_rfa_tag: a thread per pair).  The barcode program (k_rfa) starts at the positions and ends with the light reads' map qualities; markDuplicates and the
+// split reads, which read what estimateMapQualities leaves for EVERY read of the barcode, follow in k_rfa_post.  Scratch of the wave kernels: the slabs
+// of the barcode program, free while they run.
+__global__ void __launch_bounds__(256) k_rfa_init(int n_reads, DCand R, DInf S, i64 cand_cap) {
+    // Alignment defaults, lariat.go:1655-1689 (S.cand_read was written by k_aln_prep)
+    const i64 n_cand = R.cand_off[n_reads] < cand_cap ? R.cand_off[n_reads] : cand_cap;
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < n_cand; g += (i64)gridDim.x * blockDim.x) {
+        S.active[g] = 0; S.is_proper[g] = 0; S.bwa_pick[g] = 0; S.active_molecule[g] = 0; S.duplicate[g] = 0; S.molecule_id[g] = -1; S.mapq[g] = 0;
+        S.mol_diff[g] = 0; S.mol_conf[g] = 0.00075 * 0.025; S.sum_move[g] = 1.0; S.mate[g] = -1;
+    }
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (i64)gridDim.x * blockDim.x) {
+        S.active_idx[r] = -1; S.second_best_idx[r] = -1; S.split_idx[r] = -1; S.second_best_score[r] = 0; S.as_score[r] = 0;
+        S.split_second_best[r] = 0; S.split_score[r] = 0; S.split_mapq[r] = 0;
+        for (i64 g = R.cand_off[r]; g < R.cand_off[r + 1] && g < cand_cap; ++g) S.cand_read[g] = (int32_t)r;
+    }
+}
+// tagBestAlignments, one thread per pair (lariat.go:1474-1543).  Read 2 of a pair is always "touched" by read 1 (every read has >= 1 filtered candidate), so
+// only read 1's scan decides; its jitter stream is Go's, seeded from the read name: a pair with up to LH_RFA_TAG_WAVE combinations draws that often, within
+// what the state-free generator gives.  The others (a read on a repeat family has tens of candidates, its mate as many: thousands of combinations, each with
+// its own draw) are listed for k_rfa_tag_w.
+__global__ void __launch_bounds__(256) k_rfa_tag(DOpts o, int n_pairs, const u64* __restrict__ name_seed, DCand R, DInf S, i64 cand_cap, int32_t* __restrict__ hp_list,
+                                                  int32_t* __restrict__ hp_count) {
+    static_assert(LH_RFA_TAG_WAVE <= LH_GO_FAST_DRAWS, "a light pair's draws come from the state-free generator");
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    int hv = 0;
+    if (p < n_pairs && R.cand_off[2 * p + 2] <= cand_cap) {
+        int nA = 0, nM = 0;
+        for (i64 a = R.cand_off[2 * p]; a < R.cand_off[2 * p + 1]; ++a) nA += R.in_filtered[a] != 0;
+        for (i64 m = R.cand_off[2 * p + 1]; m < R.cand_off[2 * p + 2]; ++m) nM += R.in_filtered[m] != 0;
+        hv = (i64)nA * nM > LH_RFA_TAG_WAVE;
+        if (!hv) dev_tag_pair_serial(R, S, o.improper_pair_penalty, name_seed[p], p, nA, nM, (u64*)nullptr);
+    }
+    const u64 mh = __ballot(hv);
+    if (mh) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(hp_count, (int32_t)__popcll(mh));
+        basep = wave_readlane(basep, 0);
+        if (hv) hp_list[basep + lanes_below(mh, lane)] = p;
+    }
+}
+// ... a pair with many combinations, by a whole wave: 64 draws of Go's generator and 64 combinations per turn
+__global__ void __launch_bounds__(64) k_rfa_tag_w(DOpts o, const u64* __restrict__ name_seed, DCand R, DInf S, uint8_t* __restrict__ slab_pool, i64 slab_bytes,
+                                                   const int32_t* __restrict__ hp_list, const int32_t* __restrict__ hp_count, int32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[8 * 1024];
     const int lane = LANE();
     uint8_t* slab = slab_pool + (size_t)blockIdx.x * (size_t)slab_bytes;
     const double improper = o.improper_pair_penalty;
-    const int n_work = work_list ? *work_count : n_bc;
-#define RFA_OVERFLOW()                                                                                 \
-    {                                                                                                  \
-        if (lane == 0) {                                                                               \
-            if (ovf_list) ovf_list[atomicAdd(ovf_count, 1)] = bc;                                      \
-            else status[r0] |= LH_ST_POOL_OVERFLOW;                                                    \
-        }                                                                                              \
-        continue;                                                                                      \
-    }
-    int wd_main = 1 << 24;
-    for (;;) {
-        LH_WATCH(o.wd, wd_main, 12, break)
-        if (lane == 0) shi[5] = atomicAdd(bc_next, 1);
-        WAVE_SYNC();
-        const int widx = shi[5];
-        WAVE_SYNC();
-        if (widx >= n_work) break;
-        const int bc = work_list ? work_list[widx] : widx;
-        int p0 = bc_pair_off[bc], p1 = bc_pair_off[bc + 1];
-        int nR = 2 * (p1 - p0), r0 = 2 * p0;
-        i64 c_lo = R.cand_off[r0], c_hi = R.cand_off[r0 + nR];
-        int NC = (int)(c_hi - c_lo);
-        if (c_hi > cand_cap) continue;   // flagged by k_aln
-#ifdef LH_RFA_PROF
-        unsigned long long prof_t_ = (unsigned long long)clock64();
-#endif
-        // ---- init per-candidate and per-read state (Alignment defaults, lariat.go:1655-1689) ----
-        for (int r = lane; r < nR; r += 64) {
-            for (i64 g = R.cand_off[r0 + r]; g < R.cand_off[r0 + r + 1]; ++g) {
-                S.active[g] = 0; S.is_proper[g] = 0; S.bwa_pick[g] = 0; S.active_molecule[g] = 0; S.duplicate[g] = 0; S.molecule_id[g] = -1; S.mapq[g] = 0;
-                S.mol_diff[g] = 0; S.mol_conf[g] = 0.00075 * 0.025; S.sum_move[g] = 1.0; S.mate[g] = -1; S.cand_read[g] = r0 + r;
+    const int n_items = *hp_count;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+            const int p = hp_list[item];
+            WAVE_SYNC();   // the previous pair's ring and lists have been read
+            if ((size_t)(R.cand_off[2 * p + 2] - R.cand_off[2 * p]) * 12 + 16 > (size_t)slab_bytes || LH_GO_RING_BYTES > (size_t)slab_bytes) {   // (thousands of candidates in a slab of a few KB: refused)
+                if (lane == 0) status[2 * p] |= LH_ST_POOL_OVERFLOW;
+                continue;
             }
-            S.active_idx[r0 + r] = -1; S.second_best_idx[r0 + r] = -1; S.split_idx[r0 + r] = -1; S.second_best_score[r0 + r] = 0; S.as_score[r0 + r] = 0;
-            S.split_second_best[r0 + r] = 0; S.split_score[r0 + r] = 0; S.split_mapq[r0 + r] = 0;
-        }
-        WAVE_SYNC();
-        RFA_PROF(0)
-        // ---- tagBestAlignments: one lane per pair.  Read 2 of a pair is always "touched" by read 1 (every read has >= 1
-        // filtered candidate), so only read 1's scan decides; its jitter stream is Go's, seeded from the read name. ----
-        {   // a read that draws more often than the state-free path allows keeps its generator state in the (still unused) slab
-            int big = 0;
-            for (int p = p0 + lane; p < p1; p += 64) {
-                int nA = 0, nM = 0;
-                for (i64 a = R.cand_off[2 * p]; a < R.cand_off[2 * p + 1]; ++a) nA += R.in_filtered[a] != 0;
-                for (i64 m = R.cand_off[2 * p + 1]; m < R.cand_off[2 * p + 2]; ++m) nM += R.in_filtered[m] != 0;
-                big |= (i64)nA * nM > LH_GO_FAST_DRAWS;
-            }
-            if (__ballot(big) && (size_t)slab_bytes < LH_GO_RING_BYTES) RFA_OVERFLOW()
-        }
-        // Pairs with few combinations: one lane per pair, the state-free generator.  The others (a read on a repeat family has tens of
-        // candidates, its mate as many: thousands of combinations, each with its own draw) are listed and scored by the whole wave, below.
-        int n_heavy = 0;
-        int32_t* const heavy = (int32_t*)(slab + (size_t)slab_bytes) - (p1 - p0);   // the slab's last words: free until the carve's tables fill up (bestT, much later)
-        for (int pb = p0; pb < p1; pb += 64) {
-            const int p = pb + lane;
-            int hv = 0;
-            if (p < p1) {
-                int ra = 2 * p, rb = 2 * p + 1;
-                int nA = 0, nM = 0;
-                for (i64 a = R.cand_off[ra]; a < R.cand_off[ra + 1]; ++a) nA += R.in_filtered[a] != 0;
-                for (i64 m = R.cand_off[rb]; m < R.cand_off[rb + 1]; ++m) nM += R.in_filtered[m] != 0;
-                hv = (i64)nA * nM > LH_RFA_TAG_WAVE && (size_t)(p1 - p0) * 4 + LH_GO_RING_BYTES < (size_t)slab_bytes;
-                if (!hv) dev_tag_pair_serial(R, S, improper, name_seed[p], p, nA, nM, (i64)nA * nM > LH_GO_FAST_DRAWS ? (u64*)slab + lane : (u64*)nullptr);
-            }
-            const u64 mh = __ballot(hv);
-            if (hv) heavy[n_heavy + lanes_below(mh, lane)] = p;
-            n_heavy += __popcll(mh);
-        }
-        WAVE_SYNC();
-        RFA_PROF(1)
-        for (int hi = 0; hi < n_heavy; ++hi) {
-            const int p = heavy[hi];
+            const i64 c_lo = R.cand_off[2 * p];
             // the pair's filtered candidates and their single-read scores (scoreAlignment's two sums: exact multiples of 0.5), compacted in the slab
             const i64 a0 = R.cand_off[2 * p], a1 = R.cand_off[2 * p + 1], m1 = R.cand_off[2 * p + 2];
             int32_t* const fa = (int32_t*)slab;                                   // [nA | nM] candidate ids
@@ -444,8 +403,65 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 S.active[bm] = 1; S.bwa_pick[bm] = 1;
             }
             WAVE_SYNC();
-        }
+    }
+}
+
+// One wavefront per barcode; barcodes are handed out through the device counter *bc_next (their costs differ widely).
+// A barcode whose tables do not fit the wave's slab (the reader caps a work unit at 30,000 pairs, fastqreader/reader.go:205,
+// far above the common few hundred) is appended to ovf_list and processed by a second launch whose few waves own much
+// larger slabs (work_list = that list); only there an overflow is final (LH_ST_POOL_OVERFLOW).
+// development aid (tools/prof_rfa.sh builds a library with -DLH_RFA_PROF): shader-clock time per phase of the barcode program, summed over the waves
+#ifdef LH_RFA_PROF
+__device__ unsigned long long lh_rfa_prof[24];
+#define RFA_PROF(k_) { const unsigned long long now_ = (unsigned long long)clock64(); if (lane == 0) atomicAdd(&lh_rfa_prof[k_], now_ - prof_t_); prof_t_ = (unsigned long long)clock64(); }
+#else
+#define RFA_PROF(k_)
+#endif
+#ifndef LH_RFA_WAVES
+#define LH_RFA_WAVES 4   // waves per SIMD the register budget is sized for (128 VGPRs + 64 spilled: the kernel waits on memory, 4 waves hide more of it than 2 waves of 190 registers)
+#endif
+__global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
+                                             const u64* __restrict__ name_seed, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S, i64 cand_cap,
+                                             uint8_t* __restrict__ slab_pool, i64 slab_bytes, int32_t* __restrict__ status, int32_t* __restrict__ bc_next,
+                                             const int32_t* __restrict__ work_list, const int32_t* __restrict__ work_count, int32_t* __restrict__ ovf_list,
+                                             int32_t* __restrict__ ovf_count, int32_t* __restrict__ hr_list, int32_t* __restrict__ hr_count, double* __restrict__ bc_lmp) {
+    __shared__ int32_t shi[8];
+    __shared__ double shd[4];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LH_RFA_LDS_BYTES];   // one buffer, re-used phase by phase
+    i64* const spos = (i64*)lds_raw;                                               // position sort
+    int32_t* const sidx = (int32_t*)(lds_raw + 8 * LH_RFA_SORT_LDS);
+    int32_t* const sLr = (int32_t*)lds_raw;                                        // fastScore source staging
+    int32_t* const sFl = sLr + LH_RFA_SRC_CHUNK;
+    double* const sLap = (double*)(sFl + LH_RFA_SRC_CHUNK);
+    const int lane = LANE();
+    uint8_t* slab = slab_pool + (size_t)blockIdx.x * (size_t)slab_bytes;
+    const double improper = o.improper_pair_penalty;
+    const int n_work = work_list ? *work_count : n_bc;
+#define RFA_OVERFLOW()                                                                                 \
+    {                                                                                                  \
+        if (lane == 0) {                                                                               \
+            if (ovf_list) ovf_list[atomicAdd(ovf_count, 1)] = bc;                                      \
+            else status[r0] |= LH_ST_POOL_OVERFLOW;                                                    \
+        }                                                                                              \
+        continue;                                                                                      \
+    }
+    int wd_main = 1 << 24;
+    for (;;) {
+        LH_WATCH(o.wd, wd_main, 12, break)
+        if (lane == 0) shi[5] = atomicAdd(bc_next, 1);
         WAVE_SYNC();
+        const int widx = shi[5];
+        WAVE_SYNC();
+        if (widx >= n_work) break;
+        const int bc = work_list ? work_list[widx] : widx;
+        int p0 = bc_pair_off[bc], p1 = bc_pair_off[bc + 1];
+        int nR = 2 * (p1 - p0), r0 = 2 * p0;
+        i64 c_lo = R.cand_off[r0], c_hi = R.cand_off[r0 + nR];
+        int NC = (int)(c_hi - c_lo);
+        if (c_hi > cand_cap) continue;   // flagged by k_aln
+#ifdef LH_RFA_PROF
+        unsigned long long prof_t_ = (unsigned long long)clock64();
+#endif
         RFA_PROF(2)
         // ---- slab carve (sizes depend on NC, nR) ----
         size_t so = 0;
@@ -888,15 +904,19 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         WAVE_SYNC();
         // ---- estimateMapQualities per read (lariat.go:887-990).  A read with few (alignment, mate alignment) combinations: one lane; the others
         // (a read on a repeat family and its mate: thousands) are listed and done by the whole wave below, a lane per alignment ----
-        int n_heavy_r = 0;
-        int32_t* const heavy_r = T.tdel;   // [nR] free after the optimizer
+        // the reads with many combinations: listed for k_rfa_mq_w (with the barcode, whose molecule penalty they need)
+        if (lane == 0) bc_lmp[bc] = lmp;
         for (int rb_ = 0; rb_ < nR; rb_ += 64) {
             const int r = rb_ + lane;
             int hv = 0;
             if (r < nR) hv = (R.cand_off[r0 + r + 1] - R.cand_off[r0 + r]) * (R.cand_off[r0 + (r ^ 1) + 1] - R.cand_off[r0 + (r ^ 1)]) > LH_RFA_MAPQ_WAVE;
             const u64 mh = __ballot(hv);
-            if (hv) heavy_r[n_heavy_r + lanes_below(mh, lane)] = r;
-            n_heavy_r += __popcll(mh);
+            if (mh) {
+                int basep = 0;
+                if (lane == 0) basep = atomicAdd(hr_count, (int32_t)__popcll(mh));
+                basep = wave_readlane(basep, 0);
+                if (hv) { const int at = basep + lanes_below(mh, lane); hr_list[2 * at] = r0 + r; hr_list[2 * at + 1] = bc; }
+            }
         }
         WAVE_SYNC();
         RFA_PROF(10)
@@ -971,10 +991,27 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         }
         WAVE_SYNC();
         RFA_PROF(11)
-        for (int hi = 0; hi < n_heavy_r; ++hi) {
-            const int r = heavy_r[hi];
-            const int gr = r0 + r, gm = r0 + (r ^ 1);
+    }
+}
+
+// estimateMapQualities for a read with many (alignment, mate alignment) combinations (lariat.go:887-990), by a whole wave: a lane per alignment, the mate's
+// alignments staged in LDS; hr_list holds (read, barcode) pairs, bc_lmp the barcode's log molecule penalty (calculateLogMoleculePenalty, left by k_rfa)
+__global__ void __launch_bounds__(64) k_rfa_mq_w(DOpts o, const i64* __restrict__ cen_start, const i64* __restrict__ cen_end, DCand R, DInf S, uint8_t* __restrict__ slab_pool,
+                                                  i64 slab_bytes, const int32_t* __restrict__ hr_list, const int32_t* __restrict__ hr_count, const double* __restrict__ bc_lmp,
+                                                  int32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LH_RFA_LDS_BYTES];
+    const int lane = LANE();
+    uint8_t* slab = slab_pool + (size_t)blockIdx.x * (size_t)slab_bytes;
+    const double improper = o.improper_pair_penalty;
+    const int n_items = *hr_count;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+            const int gr = hr_list[2 * item], gm = gr ^ 1;
+            const double lmp = bc_lmp[hr_list[2 * item + 1]];
             const i64 a0 = R.cand_off[gr], a1 = R.cand_off[gr + 1], m0 = R.cand_off[gm], m1 = R.cand_off[gm + 1];
+            WAVE_SYNC();   // the previous read's staging has been read
+            if ((size_t)(a1 - a0 + 2) * 8 > (size_t)slab_bytes) { if (lane == 0) status[gr] |= LH_ST_POOL_OVERFLOW; continue; }
+            const i64 c_lo = m0;
+            double* const sc_all = (double*)slab;   // the read's scores: the pseudo-count entry, then one per alignment
             // the mate's filtered alignments staged in LDS, LH_RFA_MQ_CHUNK at a time: single-read score, strand, contig, position
             double* const ms = (double*)lds_raw;                                    // [CH]
             i64* const mp = (i64*)(lds_raw + 8 * LH_RFA_MQ_CHUNK);                  // [CH]
@@ -984,7 +1021,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             double pseudo = 0.0, g_sb = -1000.0;   // second best: the running maximum over the inactive alignments before this lane's
             i64 sb_aln = -1;
             double sb_raw = 0.0;
-            double* const sc_all = T.sval;   // the read's scores (free after markBest): the pseudo-count entry, then one per alignment
             int n_sc = 0;
             i64 first = -1;
             for (i64 ab = a0; ab < a1; ab += 64) {
@@ -1097,8 +1133,41 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 S.mapq[a] = (mapq != mapq) ? (int)0x80000000 : (int)mapq;
             }
             WAVE_SYNC();
-        }
-        RFA_PROF(12)
+    }
+}
+
+
+// markDuplicates (lariat.go:655-685) and CheckSplitReads (split.go:29-158), a wave per barcode, after every read's map qualities are in
+__global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa_post(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const i64* __restrict__ cen_start,
+                                                  const i64* __restrict__ cen_end, DCand R, DInf S, i64 cand_cap, uint8_t* __restrict__ slab_pool, i64 slab_bytes,
+                                                  int32_t* __restrict__ status, int32_t* __restrict__ bc_next, const int32_t* __restrict__ work_list,
+                                                  const int32_t* __restrict__ work_count, int32_t* __restrict__ ovf_list, int32_t* __restrict__ ovf_count) {
+    __shared__ int32_t shi[8];
+    const int lane = LANE();
+    uint8_t* slab = slab_pool + (size_t)blockIdx.x * (size_t)slab_bytes;
+    const double improper = o.improper_pair_penalty;
+    const int n_work = work_list ? *work_count : n_bc;
+    int wd_main = 1 << 24;
+    for (;;) {
+        LH_WATCH(o.wd, wd_main, 12, break)
+        if (lane == 0) shi[5] = atomicAdd(bc_next, 1);
+        WAVE_SYNC();
+        const int widx = shi[5];
+        WAVE_SYNC();
+        if (widx >= n_work) break;
+        const int bc = work_list ? work_list[widx] : widx;
+        const int p0 = bc_pair_off[bc], p1 = bc_pair_off[bc + 1];
+        const int nR = 2 * (p1 - p0), r0 = 2 * p0;
+        if (R.cand_off[r0 + nR] > cand_cap) continue;   // flagged by k_aln
+        int hbits = 6;
+        while ((1 << hbits) < 2 * nR) ++hbits;
+        size_t so = 0;
+        RfaTab T;
+#define CARVE(ptr, type, count) { so = (so + 7) & ~(size_t)7; T.ptr = (type*)(slab + so); so += sizeof(type) * (size_t)(count); }
+        CARVE(dk0, u64, nR) CARVE(dk1, u64, nR) CARVE(dk2, u64, nR) CARVE(dk3, u64, nR) CARVE(htab, int32_t, (size_t)1 << hbits)
+        CARVE(gstk, int32_t, 3 * LH_GOSORT_STK * 64)
+#undef CARVE
+        if (so > (size_t)slab_bytes) RFA_OVERFLOW()   // barcode too large for the slab
         // ---- markDuplicates: first-seen wins on (read1?, reversed, contig, pos, mate contig, mate pos) in read order ----
         {   // open-addressing table over the keys; a slot ends up holding the smallest read index of its key
             const int hmask = (1 << hbits) - 1;
@@ -1138,7 +1207,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
         }
         WAVE_SYNC();
-        RFA_PROF(13)
         // ---- CheckSplitReads / GetSplitAlignment over the unfiltered candidates (split.go) ----
         for (int r = lane; r < nR; r += 64) {
             int gr = r0 + r;
@@ -1179,6 +1247,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             S.split_score[gr] = dev_score_aln(R, S, improper, c, S.mate[P], 0.0);
         }
         WAVE_SYNC();
-        RFA_PROF(14)
     }
 }
+#undef RFA_OVERFLOW
+

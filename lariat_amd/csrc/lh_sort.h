@@ -32,7 +32,8 @@ template <class T, class Lt> __device__ inline void dev_combsort(int n, T* a, Lt
     if (gap != 1) dev_insertsort(a, a + n, lt);
 }
 
-// (its stack lives in LDS: one lane of a single-wave block runs it; a private array would be 1.7 KB of scratch in every kernel that sorts)
+// (its stack lives in LDS: ONE lane of a SINGLE-WAVE block runs it — k_chain, k_dedup, k_resc_apply, k_diag_resc_dedup: __launch_bounds__(64), lane 0;
+// checked at entry — a private array would be 1.7 KB of scratch in every kernel that sorts; dev_introsort_ix, k_chain_cl.h, takes its stack as an argument)
 #define LH_ISORT_STK 64
 struct LhIsortStk { int32_t left, right, depth; };
 __device__ __forceinline__ LhIsortStk* lh_isort_stack_ptr() {   // ONE array per kernel, whatever the number of element types and orders it sorts by (a template's own __shared__ array exists once per instantiation)
@@ -42,6 +43,9 @@ __device__ __forceinline__ LhIsortStk* lh_isort_stack_ptr() {   // ONE array per
 template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, Lt lt, int32_t* wdp) {
     typedef LhIsortStk Stk;
     Stk* const stack = lh_isort_stack_ptr();
+#ifndef LH_EMU
+    if (blockDim.x != 64) { wdp[1] = 1; return; }   // the stack is ONE shared array per kernel: a single-wave block, one lane (a wider block's waves would share it: refused, the watchdog slot says so)
+#endif
     int d;
     T rp, swap_tmp;
     T *s, *t, *i, *j, *k;

@@ -9,15 +9,24 @@ concatenation of the per-GPU BAM shards in range order (lh_bam_concat).
 import numpy as np
 
 
-def barcode_ranges(bc_pair_off, world):
-    """split barcodes [0,nb) into `world` contiguous ranges with ~equal pair counts; returns [(b0,b1)] * world"""
+def barcode_ranges(bc_pair_off, world, weights=None):
+    """split barcodes [0,nb) into `world` contiguous ranges; returns [(b0,b1)] * world.  Without `weights`: ~equal pair counts.  With `weights` (one number per
+    barcode: what the barcode costs — its pairs where all pairs cost alike; a pair on a repeat family costs two orders of magnitude more than one on unique
+    sequence (bench.py's `repeats` and `mixed` legs), so a host that knows, say from an earlier pass, which barcodes are repeat-rich passes the cells or the
+    candidates it counted): ~equal weight."""
     bc_pair_off = np.asarray(bc_pair_off, dtype=np.int64)
     nb = len(bc_pair_off) - 1
-    total = int(bc_pair_off[-1])
+    if weights is None:
+        cum = bc_pair_off.astype(np.float64)
+    else:
+        w = np.asarray(weights, dtype=np.float64)
+        assert len(w) == nb and (w >= 0).all()
+        cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = float(cum[-1])
     cuts = [0]
     for r in range(1, world):
         target = total * r / world
-        b = int(np.searchsorted(bc_pair_off, target, side="left"))
+        b = int(np.searchsorted(cum, target, side="left"))
         b = min(max(b, cuts[-1]), nb)
         cuts.append(b)
     cuts.append(nb)
