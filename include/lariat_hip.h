@@ -76,8 +76,8 @@ typedef struct lh_opts {
 #define LH_F_NO_SWEEP_FILTER 1u  /* K1 sweeps every interval like bwt_smem1a does (n_ext then counts every bwt_extend of the reference) */
 #define LH_F_EXT_WAVE 16u        /* K4 wave-per-read only */
 #define LH_F_EXT_SERIAL 32u      /* K4's rounds and wave-kernel launches one after the other on one stream (per-round timings) */
+#define LH_F_P2_TASKS 128u       /* K1 pass 2: a read's re-seeding calls shared by up to four lanes whatever the previous batch looked like (default: only after a repeat-rich batch) */
 #define LH_F_CHAIN_WAVE 64u      /* K3: the reads a lane does not chain all go to the wave-per-seed kernel (k_chain), none to the cluster kernel (k_chain_cl) */
-#define LH_F_RESCUE_FULL 128u    /* K6: every mem_matesw attempt runs ksw_align2's full Smith-Waterman (no banded shortcut) */
 
 /* how an index is made resident (lh_index_load / lh_index_from_arrays / lh_index_build_device); NULL = defaults */
 typedef struct lh_index_opts {

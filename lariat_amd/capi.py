@@ -17,7 +17,7 @@ LH_ABI_VERSION = 4
 LH_E_ARG, LH_E_IO, LH_E_HIP, LH_E_CAPACITY, LH_E_NODEVICE, LH_E_LIMIT = 1, 2, 3, 4, 5, 6
 # lh_opts.flags
 LH_REC_DEBUG_TAGS = 1
-LH_F_NO_SWEEP_FILTER, LH_F_EXT_WAVE, LH_F_EXT_SERIAL, LH_F_CHAIN_WAVE, LH_F_RESCUE_FULL = 1, 16, 32, 64, 128
+LH_F_NO_SWEEP_FILTER, LH_F_EXT_WAVE, LH_F_EXT_SERIAL, LH_F_CHAIN_WAVE, LH_F_P2_TASKS = 1, 16, 32, 64, 128
 LH_MAX_READ_LEN = 250
 
 c_i32p = C.POINTER(C.c_int32)

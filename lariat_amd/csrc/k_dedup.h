@@ -39,33 +39,22 @@ __device__ __forceinline__ int wave_patch_reg(const DIndex& ix, const DOpts& o, 
 // region's index in its low 9 bits, compared without them — instead of an index whose every comparison reads two region records from memory: the
 // same comparisons, the same moves, the same order for equal keys.
 // lk[0, n): 64-bit sort keys with the element's index in their low `ib` bits.  When no two keys are equal above those bits there is only one sorted order,
-// whatever the algorithm: every lane ranks its elements against all of them (n / 64 LDS sweeps) and the keys go to their places.  Returns 1 if that was done;
-// 0 (lk untouched) when two keys are equal — the introsort's order of equal keys is part of the result — or n is beyond what the lanes' registers hold.
-#define LH_RANKSORT_MAX 512
-__device__ __forceinline__ int wave_rank_sort_keys(i64* lk, int n, int ib, int lane) {
-    if (n > LH_RANKSORT_MAX) return 0;
-    constexpr int PER = LH_RANKSORT_MAX / 64;
-    i64 key[PER];
-    int rank[PER];
+// whatever the algorithm: every lane ranks its elements against all of them (n / 64 LDS sweeps) and writes the element's index to its place in ia[] — what the
+// callers read off the sorted keys.  Returns 1 if that was done; 0 when two keys are equal (the introsort's order of equal keys is part of the result: the
+// caller runs it on lk, which is untouched, and fills ia from it).
+__device__ __forceinline__ int wave_rank_sort_keys(const i64* lk, int n, int ib, int lane, int32_t* ia) {
     int tie = 0;
-#pragma unroll
-    for (int t = 0; t < PER; ++t) {
-        const int e = t * 64 + lane;
-        rank[t] = -1;
-        if (t * 64 < n && e < n) {
-            key[t] = lk[e];
-            const i64 k = key[t] >> ib;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        if (e < n) {
+            const i64 key = lk[e], k = key >> ib;
             int rk = 0;
             for (int j = 0; j < n; ++j) { const i64 kj = lk[j] >> ib; rk += kj < k; tie |= (kj == k) & (j != e); }
-            rank[t] = rk;
+            ia[rk] = (int)(key & (((i64)1 << ib) - 1));
         }
     }
-    if (__any(tie)) return 0;
-    WAVE_SYNC();   // every lane has read its keys
-#pragma unroll
-    for (int t = 0; t < PER; ++t) if (rank[t] >= 0) lk[rank[t]] = key[t];
     WAVE_SYNC();
-    return 1;
+    return !__any(tie);
 }
 
 __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOpts& o, const uint8_t* q, DReg* av, int n, int32_t* ia, DReg* tmp,
@@ -76,13 +65,13 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     for (int i = lane; i < n; i += 64) { ia[i] = i; av[i].n_comp = 1; if (packed) lk[i] = av[i].re << ib | (i64)i; }
     WAVE_SYNC();
     // sort by the END position, not START!  (r05: all end positions different — the usual list — is one sorted order: ranked by the whole wave)
-    const int ranked1 = packed && wave_rank_sort_keys(lk, n, ib, lane);
+    const int ranked1 = packed && wave_rank_sort_keys(lk, n, ib, lane, ia);
     if (!ranked1 && lane == 0) {
         if (packed) dev_introsort(n, lk, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); }, o.wd);
         else dev_introsort(n, ia, [&](int x, int y) { return av[x].re < av[y].re; }, o.wd);
     }
     WAVE_SYNC();
-    if (packed) {
+    if (packed && !ranked1) {
         for (int i = lane; i < n; i += 64) ia[i] = (int)(lk[i] & ((1 << ib) - 1));
         WAVE_SYNC();
     }
@@ -160,9 +149,13 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     }
     WAVE_SYNC();
     if (pk2) {
-        if (!wave_rank_sort_keys(lk, m, ib, lane) && lane == 0) dev_introsort(m, lk, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); }, o.wd);
-        WAVE_SYNC();
-        for (int i = lane; i < m; i += 64) ia[i] = (int)(lk[i] & ((1 << ib) - 1));
+        // (the keys hold ia[i]: every lane has read its own before the ranking overwrites ia — the WAVE_SYNC above)
+        const int ranked2 = wave_rank_sort_keys(lk, m, ib, lane, ia);
+        if (!ranked2) {
+            if (lane == 0) dev_introsort(m, lk, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); }, o.wd);
+            WAVE_SYNC();
+            for (int i = lane; i < m; i += 64) ia[i] = (int)(lk[i] & ((1 << ib) - 1));
+        }
         WAVE_SYNC();
     }
     if (lane == 0) {

@@ -246,6 +246,13 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
     constexpr int ICAP = BIG ? LH_BIG_INTV : LH_MAX_INTV;
     __shared__ uint32_t qn[32 * 64];
     constexpr bool DO1 = PASS == 1, DO2 = PASS == 2, DO12 = DO1 || DO2, DO3 = PASS == 3, P3T = PASS == 3;
+    // PASS 2 BY TASKS (r05).  A read's re-seeding calls — one bwt_smem1 from the middle of each long, rare SMEM — are independent of each other, and on repeat
+    // families a single call sweeps a forward list of dozens of entries over a hundred rows: a read with ten of them kept its lane for tens of milliseconds
+    // after every other lane had finished.  With a task list (k_p2_tasks: big.list / big.count) a read's calls are dealt out to up to LH_P2_SPLIT lanes; what
+    // they emit goes to the read's interval slots through an atomic counter, in whatever order — k_smem_fin sorts the intervals by position, and two
+    // intervals with equal positions are the same interval.  Reads without such an SMEM are not listed at all.
+    const bool P2TASK = PASS == 2 && !BIG && big.list != nullptr;
+    int task_k = 0;
     // PASS 3 BY TEXT (with a dense suffix array).  A walk of bwt_seed_strategy1 from x ends at the first length L >= min_seed_len + 1
     // where the match occurs fewer than max_mem_intv times.  If [x, x + Lw), Lw = min_seed_len + 1, lies inside a UNIQUE SMEM of the read
     // (pass 1 left it in the read's interval array, usually with its text position), the read equals the text there: the Lw-mer is unique
@@ -499,11 +506,12 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
 #define EMIT_MEM()                                                                                           \
     {                                                                                                        \
         if (cinfo - (i + 1) >= o.min_seed_len) {                                                             \
-            if (on >= ICAP) ovf = 1;                                                                  \
-            else {                                                                                           \
-                DIntv m_; m_.x0 = c0; m_.x1 = c1; m_.x2 = c2; m_.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32; \
-                out[on] = m_; on++; K1_REQ(K1T_INTV_W, out + on - 1, 32)                                     \
-            }                                                                                                \
+            DIntv m_; m_.x0 = c0; m_.x1 = c1; m_.x2 = c2; m_.info = (u64)(uint32_t)cinfo | (u64)(i + 1) << 32;  \
+            if (P2TASK) {   /* the read's other calls run on other lanes: a slot from the read's counter */     \
+                const int slot_ = atomicAdd(&n_intv[r], 1);                                                  \
+                if (slot_ >= ICAP) ovf = 1; else out[slot_] = m_;                                            \
+            } else if (on >= ICAP) ovf = 1;                                                                  \
+            else { out[on] = m_; on++; K1_REQ(K1T_INTV_W, out + on - 1, 32) }                                \
         }                                                                                                    \
         last_mem_start = i + 1;                                                                              \
     }
@@ -527,7 +535,11 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                 int idx = chunk_next + lanes_below(need, lane);
                 rr = idx < chunk_end ? idx : newbase + (idx - chunk_end);
                 if (rr >= n_reads) st = S4_DONE;
-                else { if (BIG || big.list) rr = big.list[rr]; off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off); }
+                else {
+                    if (BIG || big.list) rr = big.list[rr];
+                    if (P2TASK) { task_k = rr & 15; rr >>= 4; }   // pass 2 by tasks: (read, j << 2 | m - 1): every m-th of the read's re-seeding calls, from the j-th on
+                    off = seq_off[rr]; ln = (int)(seq_off[rr + 1] - off);
+                }
             }
             if (chunk_next + cnt > chunk_end) { chunk_next = newbase + (chunk_next + cnt - chunk_end); chunk_end = newbase + 64; }
             else chunk_next += cnt;
@@ -586,9 +598,14 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
                     if (UE0 > US0) st = S4_P3_PREP;
                 }
                 if (DO2 && st == S4_P2_NEXT) {   // the long, rare SMEMs among pass 1's intervals (EMIT_MEM's test)
-                    for (int k = 0; k < on; ++k) {
+                    const int on1 = P2TASK ? big.slot[r] : on;   // (by tasks: the read's other calls may have emitted already: the SMEMs to re-seed inside are PASS 1's — k_p2_tasks noted how many there are)
+                    int ord = 0;
+                    for (int k = 0; k < on1; ++k) {
                         DIntv p = out[k];
-                        if ((int)(uint32_t)p.info - (int)(p.info >> 32) >= split_len && p.x2 <= (u64)o.split_width) p2mask |= 1ull << k;
+                        if ((int)(uint32_t)p.info - (int)(p.info >> 32) >= split_len && p.x2 <= (u64)o.split_width) {
+                            if (!P2TASK || ord % ((task_k & 3) + 1) == (task_k >> 2)) p2mask |= 1ull << k;   // this lane's share of the read's calls
+                            ++ord;
+                        }
                     }
                 }
             }
@@ -844,8 +861,8 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             if (st == S4_READ_DONE) {
                 rst &= ~P3_NOTEXT;
                 if (ovf) rst |= LH_ST_INTV_OVERFLOW;
-                n_intv[r] = on;
-                status[r] = rst;
+                if (P2TASK) { if (rst) atomicOr(&status[r], rst); }   // (the counter is the calls' own; k_p2_clamp brings it back to the slots there are)
+                else { n_intv[r] = on; status[r] = rst; }
                 st = S4_FETCH;
             }
         }
@@ -1084,6 +1101,36 @@ __global__ void __launch_bounds__(256) k_k1_trace_hist(const u64* __restrict__ t
     if (threadIdx.x < 2 * K1T_N + 2 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 #endif
+
+// pass 2's tasks (see P2TASK): a read with c long, rare SMEMs among pass 1's intervals (mem_collect_intv's test: length >= min_seed_len * split_factor, at most
+// split_width occurrences) is listed m = min(c, LH_P2_SPLIT) times, entry read << 4 | j << 2 | m - 1: the lane that takes it makes the read's j-th, (j + m)-th
+// ... re-seeding call.  One thread per read; at most LH_P2_SPLIT entries per read: the list never overflows its LH_P2_SPLIT x n_reads slots.
+#define LH_P2_SPLIT 4
+__global__ void __launch_bounds__(256) k_p2_tasks(DOpts o, int n_reads, const DIntv* __restrict__ intv, const int32_t* __restrict__ n_intv, int32_t* __restrict__ tasks,
+                                                   int32_t* __restrict__ n_tasks, int32_t* __restrict__ n_pass1) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
+    int m = 0;
+    if (r < n_reads) {
+        const int split_len = (int)(o.min_seed_len * o.split_factor + .499);
+        const int on = n_intv[r] < LH_MAX_INTV ? n_intv[r] : LH_MAX_INTV;
+        n_pass1[r] = on;
+        for (int k = 0; k < on; ++k) {
+            const DIntv p = intv[(size_t)r * LH_MAX_INTV + k];
+            m += (int)(uint32_t)p.info - (int)(p.info >> 32) >= split_len && p.x2 <= (u64)o.split_width;
+        }
+        m = m < LH_P2_SPLIT ? m : LH_P2_SPLIT;
+    }
+    const int incl = wave_scan_add_i32(m);
+    const int tot = wave_readlane(incl, 63);
+    int basep = 0;
+    if (lane == 0 && tot) basep = atomicAdd(n_tasks, tot);
+    basep = wave_readlane(basep, 0);
+    for (int j = 0; j < m; ++j) tasks[basep + incl - m + j] = r << 4 | j << 2 | (m - 1);
+}
+__global__ void __launch_bounds__(256) k_p2_clamp(int n_reads, int32_t* __restrict__ n_intv) {   // (a read whose calls asked for more slots than it has: flagged by the call that was refused)
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads && n_intv[r] > LH_MAX_INTV) n_intv[r] = LH_MAX_INTV;
+}
 
 // a read's interval array: its regular slots, or the sorted half of its big-slab slot
 __device__ __forceinline__ DIntv* dev_intv_of(DIntv* intv, const K1Big& big, int r, int sorted) {

@@ -399,6 +399,22 @@ def test_emu_repeat_families(emu, oracle, build):
             assert res.counters[k] == ref.counters[k], k
 
 
+def test_emu_k3_cluster_kernel_and_wave_kernel_agree(emu, oracle):
+    """K3's two ways for a read with many seeds — k_chain_cl (seeds sorted by position, one lane per cluster, mem_chain_flt's greedy scan in rounds) and
+    k_chain (one wave-wide look-up per seed, the scan as written), chosen by LH_F_CHAIN_WAVE — give the chains the oracle gives: seeds, weights, kept marks,
+    order (stage dump), and the same final result."""
+    names, contigs, rs = helpers.repeat_family_case(41, 8)
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    b = helpers.batch_of(rs)
+    want = oidx.stage_dump(b)
+    ref = oidx.align_barcodes(b, threads=8)
+    for flags in (0, capi.LH_F_CHAIN_WAVE, capi.LH_F_P2_TASKS):   # (... and K1's pass 2 with a read's re-seeding calls dealt out to several lanes)
+        ctx = idx.context(rs.n_pairs)
+        helpers.assert_same_dump(ctx.stage_dump(b, emu.opts(flags=flags)), want, helpers.DUMP_FRONT + helpers.DUMP_REGS)
+        helpers.assert_same_result(ctx.align_barcodes(b, emu.opts(flags=flags)), ref, inference=True)
+
+
 def test_emu_context_moves_between_regimes(emu, oracle):
     """which way K4 takes the wave-chained reads rests on the PREVIOUS batch of the context (lh_host_stage2.inc: the long queue when that batch had many of
     them, the wave-per-read kernel at once when it had few) — a choice of path, never of result.  One context, a repeat-family batch, then reads on unique
