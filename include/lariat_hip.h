@@ -361,6 +361,10 @@ int lh_synth_reads(const uint8_t* pac, int64_t l_pac, int32_t n_contigs, const i
  * index spaces [first[k], first[k+1]) of keys[] (first[0] = 0) sorted by the serial restatement (one sort per lane) and by the wave-wide one;
  * each returns the permutation of every index space (position -> original index inside its space) */
 int lh_diag_gosort(int device, int32_t n_sorts, const int32_t* first, const int64_t* keys, int32_t* perm_serial, int32_t* perm_wave);
+/* diagnostics: klib's ks_introsort as K5 / K6 restate it for the region sorts of mem_sort_dedup_patch (bwamem.c via gobwa.go:244,253,291,315; its order of equal keys is part
+ * of the result): n_sorts index spaces of keys[] (at most 1024 elements each, keys below 2^50) sorted by the one-lane restatement and by the wave-wide one; each returns the
+ * permutation of every index space (position -> original index inside its space) */
+int lh_diag_introsort(int device, int32_t n_sorts, const int32_t* first, const int64_t* keys, int32_t* perm_serial, int32_t* perm_wave);
 int lh_diag_go_rand(int device, int64_t seed, int32_t n, uint64_t* out_fast, uint64_t* out_ring, double* out_f64);
 /* diagnostics: K6's exact shortcut for the mem_sort_dedup_patch(opt, 0, 0, 0, ...) that follows every mem_matesw attempt (gobwa.go:291,315 -> bwamem
  * mem_matesw), against the call as written.  n_cases lists of regions [first[c], first[c+1]) (6 int64 each: rb, re, qb, qe, score, rid) and one region

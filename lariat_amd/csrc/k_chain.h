@@ -318,5 +318,7 @@ __global__ void __launch_bounds__(64) k_chain(DIndex ix, DOpts o, int n_reads, c
 #define LH_EXT_HEAVY_COLS 64     // a full-band extension of this many query columns or more is "heavy" for a lane (k_extend2.h); measured 32 / 48 / 64 / 80 / 96: K4 8.87 / 8.68 / 8.33 / 8.79 / 8.99 ms (the deferred reads run in the wave kernel beside the rounds just as well: no difference)
 #endif
 #ifndef LH_NARROW_MAX_LOSS
-#define LH_NARROW_MAX_LOSS 26    // diagonal loss up to which the lane DP runs in a narrow band (5 mismatches with the default scoring)
+#define LH_NARROW_MAX_LOSS 36    // diagonal loss up to which the lane DP runs in a narrow band: 7 mismatches with the default scoring, band 29 — the widest the circular 64-word window holds
+                                 // (LH_EXT_CIRC_MAX_W).  r05: 26 -> 36; between two copies of a repeat family 6 or 7 mismatches in a 100-base side are common, and at 26 those sides ran the full
+                                 // band in a live-interval window that outgrows a lane (1.32 M -> 0.96 M calls for k_ext_wround per 400 k pairs of configs[4], K4 124 -> 108 ms)
 #endif

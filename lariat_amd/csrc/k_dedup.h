@@ -58,8 +58,13 @@ __device__ __forceinline__ int wave_rank_sort_keys(const i64* lk, int n, int ib,
 }
 
 __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOpts& o, const uint8_t* q, DReg* av, int n, int32_t* ia, DReg* tmp,
-                                                     int do_patch, int lane, u64* cells, i64* lk = nullptr, int lk_cap = 0) {
+                                                     int do_patch, int lane, u64* cells, i64* lk = nullptr, int lk_cap = 0, int* clean_out = nullptr) {
+    // *clean_out (r05): 1 if the list that comes out is known to be one that a further call without patching leaves alone AND holds no two equal end positions — no region
+    // was merged (a merged region has grown past entries its walk had already compared it with) and the first sort found all end positions different; K6's replay then
+    // skips its own look at the list (k_rescue2.h).  0 says nothing.
+    if (clean_out) *clean_out = 1;
     if (n <= 1) return n;
+    int merged = 0;
     const bool packed = lk && n <= lk_cap && n <= 2048;
     const int ib = n <= 512 ? 9 : 11;   // bits of the region index below the key
     for (int i = lane; i < n; i += 64) { ia[i] = i; av[i].n_comp = 1; if (packed) lk[i] = av[i].re << ib | (i64)i; }
@@ -110,6 +115,7 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
                     if (lane == 0) av[ia[j]].qe = qq.qb;
                 }
             } else if (do_patch && qq.rb < p.rb && (score = wave_patch_reg(ix, o, q, qq, p, &w, lane, cells)) > 0) {   // then merge q into p
+                merged = 1;
                 p.n_comp += qq.n_comp + 1;
                 p.seedcov = p.seedcov > qq.seedcov ? p.seedcov : qq.seedcov;
                 p.sub = p.sub > qq.sub ? p.sub : qq.sub;
@@ -177,6 +183,7 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     WAVE_SYNC();
     for (int i = lane; i < m; i += 64) av[i] = tmp[i];
     WAVE_SYNC();
+    if (clean_out) *clean_out = ranked1 && !merged;
     return m;
 }
 
@@ -197,11 +204,12 @@ __device__ __forceinline__ int dev_patch_needs_dp(const DIndex& ix, const DOpts&
     return 1;
 }
 __global__ void __launch_bounds__(256) k_dedup_fast(DIndex ix, DOpts o, int n_reads, const i64* __restrict__ reg_off, DReg* __restrict__ regs, int32_t* __restrict__ n_regs,
-                                                     int32_t* __restrict__ best_score, int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
+                                                     int32_t* __restrict__ best_score, int32_t* __restrict__ list, int32_t* __restrict__ list_count, uint8_t* __restrict__ clean) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = LANE();
     int need = 0;
     if (r < n_reads) {
         int n = n_regs[r];
+        clean[r] = 1;   // (nothing to compare, or two regions that were — unless they end at the same position, below; a listed read: k_dedup's word)
         if (n <= 1) best_score[r] = n == 1 ? regs[reg_off[r]].score : 0;
         else if (n == 2) {
             // (the decisions read six fields of each record; the records themselves move at most once, as 8-byte words: whole-record
@@ -256,6 +264,7 @@ __global__ void __launch_bounds__(256) k_dedup_fast(DIndex ix, DOpts o, int n_re
                 if (m >= 1) av[0].n_comp = 1;
                 if (m == 2) av[1].n_comp = 1;
                 n_regs[r] = m;
+                if (m == 2 && re0 == re1) clean[r] = 0;
                 const int f_sc = first ? sc1 : sc0, o_sc = first ? sc0 : sc1;
                 best_score[r] = m == 0 ? 0 : (m == 2 && o_sc > f_sc ? o_sc : f_sc);
             }
@@ -274,7 +283,7 @@ __global__ void __launch_bounds__(256) k_dedup_fast(DIndex ix, DOpts o, int n_re
 __global__ void __launch_bounds__(64) k_dedup(DIndex ix, DOpts o, int n_reads, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off,
                                                const i64* __restrict__ reg_off, DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool,
                                                int32_t* __restrict__ n_regs, int32_t* __restrict__ best_score, DCounters* __restrict__ ctr,
-                                               const int32_t* __restrict__ list, const int32_t* __restrict__ list_count) {
+                                               const int32_t* __restrict__ list, const int32_t* __restrict__ list_count, uint8_t* __restrict__ clean) {
     __shared__ uint8_t q[LH_MAXLEN + 6];
     __shared__ i64 lk[512];
     const int lane = LANE();
@@ -291,12 +300,13 @@ __global__ void __launch_bounds__(64) k_dedup(DIndex ix, DOpts o, int n_reads, c
     DReg* av = regs + ro;
     int n = n_regs[r];
     u64 cells = 0;
-    n = wave_sort_dedup_patch(ix, o, q, av, n, ia_pool + ro + r, regs_tmp + ro, 1, lane, &cells, lk, 512);
+    int is_clean = 0;
+    n = wave_sort_dedup_patch(ix, o, q, av, n, ia_pool + ro + r, regs_tmp + ro, 1, lane, &cells, lk, 512, &is_clean);
     int best = 0;
     for (int i = lane; i < n; i += 64) { int s = av[i].score; best = best > s ? best : s; }
     best = wave_max_i32(best);
     if (lane == 0) {
-        n_regs[r] = n; best_score[r] = best;
+        n_regs[r] = n; best_score[r] = best; clean[r] = (uint8_t)is_clean;
         if (ctr && cells) atomicAdd(&LH_CTR(ctr)->glob_cells, cells);
     }
     }

@@ -101,14 +101,42 @@ __global__ void __launch_bounds__(64) k_diag_gosort(int n_sorts, const int32_t* 
                 [&](int i, int j) { i64 t = keys_b[i]; keys_b[i] = keys_b[j]; keys_b[j] = t; int u = perm_wave[i]; perm_wave[i] = perm_wave[j]; perm_wave[j] = u; }, qa, qb, qd);
 }
 
+// klib's introsort as the region sorts run it (lh_sort.h): every index space of keys[] as packed words (key << 11 | index, compared above the index) sorted (a) by one lane
+// (dev_introsort), (b) by the wave (wave_introsort_i64); both must leave equal keys where ks_introsort does.  At most LH_DIAG_ISORT_MAX elements per sort.
+#define LH_DIAG_ISORT_MAX 1024
+__global__ void __launch_bounds__(64) k_diag_introsort(int n_sorts, const int32_t* __restrict__ first, const i64* __restrict__ keys, int32_t* __restrict__ perm_serial,
+                                                       int32_t* __restrict__ perm_wave, int32_t* __restrict__ wd) {
+    __shared__ i64 lk[LH_DIAG_ISORT_MAX];
+    __shared__ uint16_t pa[LH_DIAG_ISORT_MAX], pb[LH_DIAG_ISORT_MAX];
+    const int lane = LANE();
+    for (int c = blockIdx.x; c < n_sorts; c += gridDim.x) {
+        const int f0 = first[c], n = first[c + 1] - f0;
+        if (n > LH_DIAG_ISORT_MAX) continue;
+        WAVE_SYNC();
+        for (int k = lane; k < n; k += 64) lk[k] = keys[f0 + k] << 11 | (i64)k;
+        WAVE_SYNC();
+        if (lane == 0) dev_introsort(n, lk, [&](i64 x, i64 y) { return (x >> 11) < (y >> 11); }, wd);
+        WAVE_SYNC();
+        for (int k = lane; k < n; k += 64) perm_serial[f0 + k] = (int)(lk[k] & 2047);
+        WAVE_SYNC();
+        for (int k = lane; k < n; k += 64) lk[k] = keys[f0 + k] << 11 | (i64)k;
+        WAVE_SYNC();
+        wave_introsort_i64<LH_DIAG_ISORT_MAX / 64>(n, lk, 11, lane, pa, pb, wd);
+        WAVE_SYNC();
+        for (int k = lane; k < n; k += 64) perm_wave[f0 + k] = (int)(lk[k] & 2047);
+    }
+}
+
 // K6's exact shortcut (k_rescue2.h: resc_dedup_incremental) against what it replaces, on arbitrary region lists: per case a list of regions
 // (6 values each: rb, re, qb, qe, score, rid) and one more region b.  The wave makes the list clean as the pipeline does (mem_sort_dedup_patch
 // once), then runs (a) the call as written on list + b in memory, (b) the incremental form on the list in LDS.  verdict[c]: 0 = equal, 1 = the
-// incremental form declined (equal keys), 2 = THEY DIFFER, 3 = the cleaned list has equal re (the pipeline would not use the LDS form).
+// incremental form declined (equal keys), 2 = THEY DIFFER, 3 = the cleaned list has equal re or contigs that interleave (the pipeline would not use the incremental form), 4 = THE CALL AS WRITTEN ON THE
+// LIST IN LDS (resc_dedup_lds; run for every case) DIFFERS from the one in memory — in a field, or in which of two identical hits it kept.
 __global__ void __launch_bounds__(64) k_diag_resc_dedup(DIndex ix, DOpts o, int n_cases, const int32_t* __restrict__ first, const i64* __restrict__ vals, const i64* __restrict__ bvals,
                                                         DReg* __restrict__ ra, DReg* __restrict__ rb_, DReg* __restrict__ tmp, int32_t* __restrict__ ia, int32_t* __restrict__ verdict,
                                                         int32_t* __restrict__ n_out) {
     __shared__ RescList W;
+    __shared__ RescScratchT<LH_RA_CAP> S;
     const int lane = LANE();
     for (int c = blockIdx.x; c < n_cases; c += gridDim.x) {
         WAVE_SYNC();
@@ -120,13 +148,22 @@ __global__ void __launch_bounds__(64) k_diag_resc_dedup(DIndex ix, DOpts o, int 
         for (int k = lane; k < n0; k += 64) A[k] = mk(vals + (size_t)(f0 + k) * 6);
         WAVE_SYNC();
         u64 cells = 0;
-        int n = wave_sort_dedup_patch(ix, o, nullptr, A, n0, I, T, 0, lane, &cells);   // the clean list
-        const DReg b = mk(bvals + (size_t)c * 6);
+        int n = wave_sort_dedup_patch(ix, o, nullptr, A, n0, I, T, 0, lane, &cells);   // the clean list: a list a further call leaves alone (with real coordinates one call does
+        for (int it = 0; it < 16; ++it) {                                               // that; contigs that interleave can take more, and the pipeline runs such a list's calls as written)
+            const int n2 = wave_sort_dedup_patch(ix, o, nullptr, A, n, I, T, 0, lane, &cells);
+            if (n2 == n) break;
+            n = n2;
+        }
+        DReg b = mk(bvals + (size_t)c * 6);
+        b.seedcov = -1;
         if (n + 1 > LH_RA_CAP) { if (lane == 0) { verdict[c] = 3; n_out[c] = n; } continue; }
-        for (int k = lane; k < n; k += 64) { const DReg g = A[k]; B[k] = g; W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k; }
-        WAVE_SYNC();
-        // equal end positions in the clean list: the replay keeps it in LDS only when every such tie is harmless (resc_list_ties marks the entries)
-        if (resc_list_ties(o, W, n, lane)) { if (lane == 0) { verdict[c] = 3; n_out[c] = n; } continue; }
+        // (seedcov = the entry's place in the clean list, -1 for b: WHICH of two identical hits a call keeps is part of its result)
+        auto load_w = [&]() {
+            WAVE_SYNC();
+            for (int k = lane; k < n; k += 64) { const DReg g = A[k]; W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k; }
+            WAVE_SYNC();
+        };
+        for (int k = lane; k < n; k += 64) { A[k].seedcov = k; B[k] = A[k]; }
         WAVE_SYNC();
         // (a) as written: b goes in before the first entry with a smaller score (mem_matesw), then the call
         int pos = n;
@@ -135,7 +172,29 @@ __global__ void __launch_bounds__(64) k_diag_resc_dedup(DIndex ix, DOpts o, int 
         if (lane == 0) { for (int k = n; k > pos; --k) B[k] = B[k - 1]; B[pos] = b; }
         WAVE_SYNC();
         const int n_full = wave_sort_dedup_patch(ix, o, nullptr, B, n + 1, I, T, 0, lane, &cells);
-        // (b) incremental
+        // (c) as written, on the list in LDS (resc_dedup_lds): every case, equal keys or not
+        int bad_lds = 0;
+        {
+            load_w();
+            int smax = 0;
+            if (resc_lds_keys_ok(W, n, &b, lane, &smax)) {
+                const int n1 = resc_list_insert(W, n, b, lane);
+                const int n_lds = resc_dedup_lds(o, W, S, n1, smax, lane);
+                bad_lds = n_lds != n_full;
+                for (int k = lane; k < n_full && k < n_lds; k += 64)
+                    bad_lds |= B[k].rb != W.rb[k] || B[k].re != W.re[k] || B[k].qb != W.qb[k] || B[k].qe != W.qe[k] || B[k].score != W.score[k] || B[k].rid != W.rid[k] || B[k].seedcov != W.src[k];
+                bad_lds = __any(bad_lds);
+            }
+        }
+        if (bad_lds) { if (lane == 0) { verdict[c] = 4; n_out[c] = n_full | n << 16; } continue; }
+        load_w();
+        // equal end positions in the clean list: the replay takes the incremental form only when every such tie is harmless (resc_list_ties marks the entries)
+        if (resc_list_ties(o, W, n, lane) | resc_list_interleaved(o, W, n, lane)) { if (lane == 0) { verdict[c] = 3; n_out[c] = n; } continue; }
+        WAVE_SYNC();
+        // (b) incremental (an entry that IS b counts as rescued earlier in the same replay: the form's shortcut for a twin)
+        for (int k = lane; k < n; k += 64)
+            if (W.re[k] == b.re && W.rb[k] == b.rb && W.qb[k] == b.qb && W.qe[k] == b.qe && W.score[k] == b.score && W.rid[k] == b.rid) W.src[k] = -1;
+        WAVE_SYNC();
         int app = 0;
         const int n_inc = resc_dedup_incremental(o, W, n, b, lane, &app);
         if (n_inc >= 0 && app) resc_list_sort(W, n_inc, lane);

@@ -241,6 +241,7 @@ struct DExtJobs {
     int32_t range[2 * (LH_EXT_ROUNDS + 2)];   // [2k, 2k+1] = the sorted order's slice round k runs
     int32_t next[LH_EXT_ROUNDS + 2];          // round k's slice counter: its waves take slices of 64 jobs in the sorted order (heaviest bins first)
     int32_t kinds[3 * (LH_EXT_ROUNDS + 2)];   // diagnostics: narrow / live-interval / short full-band jobs of round k
+    int32_t wnext;                            // (the long queue) k_ext_wround's next call
     int32_t wave_range[2], heavy_range[2], defer_range[2];   // [0, n): the reads the wave kernels chain and extend (k_chain_lane's list); the reads round 0 / the later rounds left to the wave extension kernel
 };
 // job key: bins 0..959 = narrow band in the circular window (same w: same cells per row), 960..1215 = full band in the live-interval window, 1216..1471 = full band, fewer than 64 columns
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(256) k_extj_offsets(DExtJobs* __restrict__ jb,
     for (int u = 0; u < per; ++u) { jb->cursor[t * per + u] = excl + loc[u]; jb->hist[t * per + u] = 0; }
     if (t == 255) {
         jb->range[2 * round] = 0; jb->range[2 * round + 1] = part[255];
-        if (reuse >= 0) { jb->count[reuse] = 0; jb->next[round] = 0; jb->count[3] = 0; }   // (count[3]: the calls listed for k_ext_wround, consumed by now)
+        if (reuse >= 0) { jb->count[reuse] = 0; jb->next[round] = 0; jb->count[3] = 0; jb->wnext = 0; }   // (count[3]: the calls listed for k_ext_wround, consumed by now)
     }
 }
 __global__ void __launch_bounds__(256) k_extj_scatter(const int32_t* __restrict__ n_jobs, const int32_t* __restrict__ key, const int32_t* __restrict__ list,
@@ -693,13 +694,17 @@ __global__ void __launch_bounds__(64) k_ext_round0(DIndex ix, DOpts o, const int
     }
 }
 // the calls a lane could not hold, one WAVE per unit; the unit's next call goes back to the lanes' queue
-__global__ void __launch_bounds__(64) k_ext_wround(DIndex ix, DOpts o, const int32_t* __restrict__ list, const int32_t* __restrict__ count, ExtArgs A,
+__global__ void __launch_bounds__(64) k_ext_wround(DIndex ix, DOpts o, const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ wnext, ExtArgs A,
                                                     int32_t* __restrict__ next_count, int32_t* __restrict__ next_list, int32_t* __restrict__ next_key, DCounters* __restrict__ ctr) {
     __shared__ uint8_t q[LH_MAXLEN + 6];
     const int lane = LANE();
     const int n = *count;
     u64 cells = 0;
-    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+    for (;;) {   // (r05) calls handed out one at a time: a fixed share per wave left the kernel waiting for its unluckiest wave (a seventh of the resident waves busy on average)
+        int it = 0;
+        if (lane == 0) it = atomicAdd(wnext, 1);
+        it = wave_readlane(it, 0);
+        if (it >= n) break;
         const int id = list[it];
         const int r = A.u_read[id];
         const i64 off = A.seq_off[r];

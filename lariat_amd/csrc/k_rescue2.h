@@ -74,6 +74,7 @@ struct RMeta {   // per direction, on the device
     int32_t hist2[LH_RJ_NB], bstart2[LH_RJ_NB + 1], bcur2[LH_RJ_NB];    // reverse jobs
     int32_t list_count, long_count;   // listed pairs; those of them whose mate's list is too long for the replay's usual LDS arrays
     int32_t heavy_count;              // pairs whose enumeration is a wave's (k_resc_enum_w)
+    int32_t apply_next[2];            // k_resc_apply (the usual instance): the next list entry to look at
 };
 
 // which attempts of one pair and direction get past mem_matesw's first test ("a consistent pair exists; no need to perform SW") against the
@@ -559,13 +560,19 @@ template <int CAP> __device__ __forceinline__ void resc_list_store(const DIndex&
 template <int CAP> __device__ __forceinline__ int resc_dedup_incremental(const DOpts& o, RescListT<CAP>& W, int n_ma, const DReg& b, int lane, int* appended) {
     const i64 NINF = -0x7fffffffffffffffll, PINF = 0x7fffffffffffffffll;
     i64 lo_bar = NINF, hi_bar = PINF, r_cand = NINF, s_cand = PINF;
-    int tie = 0;
+    int tie = 0, same = 0;
     for (int i0 = 0; i0 < n_ma; i0 += 64) {
         const int k = i0 + lane;
         if (k < n_ma) {
             const i64 e = W.re[k], krb = W.rb[k];
             const int ksc = W.score[k], kqb = W.qb[k];
-            tie |= e == b.re || (ksc == b.score && krb == b.rb && kqb == b.qb);
+            // (r05) b IS an entry, and one that was rescued earlier in this replay (src < 0: its record is b's, field for field): the two are redundant with equal scores, the
+            // scan excludes whichever the first sort puts first and keeps the other — the same record either way — and neither does anything to a third entry that the
+            // entry did not do in the call before: the list stays as it is.  (An entry that was there from the start carries its own seedcov, w, ..: which of the two
+            // survives is the introsort's to say: declined.)
+            const int twin = e == b.re && krb == b.rb && kqb == b.qb && W.qe[k] == b.qe && ksc == b.score && W.rid[k] == b.rid && W.src[k] < 0 && !W.tied[k];
+            same |= twin;
+            tie |= !twin && (e == b.re || (ksc == b.score && krb == b.rb && kqb == b.qb));
             // an entry that shares its re with another one: which of the two b's scan (or theirs, of b) meets first is the introsort's to say: the call as written
             tie |= W.tied[k] && (e < b.re ? b.rb < e + o.max_chain_gap : krb < b.re + o.max_chain_gap);
             if (W.rid[k] != b.rid) { if (e < b.re && e > lo_bar) lo_bar = e; if (e > b.re && e < hi_bar) hi_bar = e; }
@@ -577,6 +584,7 @@ template <int CAP> __device__ __forceinline__ int resc_dedup_incremental(const D
         }
     }
     if (__any(tie) || n_ma + 1 > CAP) return -1;
+    if (__any(same)) { *appended = 0; return n_ma; }
     lo_bar = wave_max_i64(lo_bar); hi_bar = wave_min_i64(hi_bar);
     r_cand = wave_max_i64(r_cand); s_cand = wave_min_i64(s_cand);
     const i64 r_star = r_cand > lo_bar ? r_cand : NINF;   // (beyond an entry of another contig the scan to the left never gets)
@@ -639,6 +647,187 @@ template <int CAP> __device__ __forceinline__ int resc_list_ties(const DOpts& o,
     return __any(harmful);
 }
 
+// ---- (r05) the call AS WRITTEN on the list in LDS.  A call that resc_dedup_incremental declines (the added region shares its end position, or its whole sort key, with
+// an entry: typically it IS an entry — the window of a later anchor holds a region the mate already has, just outside the insert-size bounds of the first test) used to
+// send the list to memory for wave_sort_dedup_patch and back: a serial introsort and a scan whose every step reads two 72-byte records from memory.  A pair in which one
+// attempt does that, does it in most of its fifty: 0.1 % of the pairs took 5 .. 40 ms each while the others take 0.15 ms, and k_resc_apply lasted as long as its slowest
+// pair (profiles/r05_resc_apply_pair_times.log).  Here the same call — same two sorts (ranked when all keys differ, else klib's introsort on the same packed keys by the whole wave, lh_sort.h,
+// so equal keys end up where klib leaves them), same scan, same removal of identical hits — reads and writes LDS only, and the scan's walk to the left looks at 64 entries at
+// once: for a fixed p no step depends on an earlier step of the same walk (without patching p never changes, and excluding q only concerns q), so the walk ends at the nearest
+// entry that is off p's contig / beyond max_chain_gap / redundant with a higher score, and every redundant live entry nearer than that is excluded.
+template <int CAP> struct RescScratchT { i64 lk[CAP]; uint16_t ord[CAP], ord2[CAP]; };
+// lk[0, n): keys with their index in the low ib bits; all different above them: ord[rank] = index (one sorted order whatever the algorithm), returns 1; else returns 0
+__device__ __forceinline__ int resc_rank_keys(const i64* lk, int n, int ib, int lane, uint16_t* ord) {
+    int tie = 0;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        if (e < n) {
+            const i64 key = lk[e], k = key >> ib;
+            int rk = 0;
+            for (int j = 0; j < n; ++j) { const i64 kj = lk[j] >> ib; rk += kj < k; tie |= (kj == k) & (j != e); }
+            ord[rk] = (uint16_t)(key & (((i64)1 << ib) - 1));
+        }
+    }
+    WAVE_SYNC();
+    return !__any(tie);
+}
+// can the second sort's packed key — (largest score - score) | rb (33 bits) | qb (8 bits) | index — hold every entry of the list and b?  (else: the call on the records in memory)
+template <int CAP> __device__ __forceinline__ int resc_lds_keys_ok(const RescListT<CAP>& W, int n, const DReg* b, int lane, int* smax_out) {
+    int smax = 0, bad = 0;
+    if (b) { smax = b->score; bad = b->score < 0 || b->rb < 0 || b->rb >= (1ll << 33) || b->qb < 0 || b->qb > 255; }
+    for (int k = lane; k < n; k += 64) {
+        const int sc = W.score[k];
+        smax = smax > sc ? smax : sc;
+        bad |= sc < 0 || W.rb[k] < 0 || W.rb[k] >= (1ll << 33) || W.qb[k] < 0 || W.qb[k] > 255;
+    }
+    smax = wave_max_i32(smax);
+    const int ib = n + 1 <= 512 ? 9 : 11;
+    *smax_out = smax;
+    return !__any(bad) && (32 - __clz(smax | 1)) + 33 + 8 + ib <= 63 && n + 1 <= CAP && n + 1 <= 2048;
+}
+// b into the list in its final order (score desc, rb, qb), before the first entry with a smaller score (mem_matesw); returns the new length
+template <int CAP> __device__ __forceinline__ int resc_list_insert(RescListT<CAP>& W, int n, const DReg& b, int lane) {
+    constexpr int PER = (CAP + 63) / 64;
+    int pos = n;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int k = i0 + lane;
+        const u64 bm = __ballot(k < n && W.score[k] < b.score);
+        if (bm) { pos = i0 + __ffsll((unsigned long long)bm) - 1; break; }
+    }
+    i64 e[PER], krb[PER]; int kqb[PER], kqe[PER], ksc[PER], krid[PER], ksrc[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int k = t * 64 + lane;
+        if (k >= pos && k < n) { e[t] = W.re[k]; krb[t] = W.rb[k]; kqb[t] = W.qb[k]; kqe[t] = W.qe[k]; ksc[t] = W.score[k]; krid[t] = W.rid[k]; ksrc[t] = W.src[k]; }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int k = t * 64 + lane;
+        if (k >= pos && k < n) { const int d = k + 1; W.re[d] = e[t]; W.rb[d] = krb[t]; W.qb[d] = kqb[t]; W.qe[d] = kqe[t]; W.score[d] = ksc[t]; W.rid[d] = krid[t]; W.src[d] = ksrc[t]; }
+    }
+    if (lane == 0) { W.re[pos] = b.re; W.rb[pos] = b.rb; W.qb[pos] = b.qb; W.qe[pos] = b.qe; W.score[pos] = b.score; W.rid[pos] = b.rid; W.src[pos] = -1; }
+    WAVE_SYNC();
+    return n + 1;
+}
+// mem_sort_dedup_patch(opt, 0, 0, 0, n, list) on W[0, n) in the order the call finds it (resc_lds_keys_ok said yes; smax from there); W is left in the call's final order
+// (W.tied is not maintained: resc_list_ties follows).  Returns the new length.
+template <int CAP> __device__ __forceinline__ int resc_dedup_lds(const DOpts& o, RescListT<CAP>& W, RescScratchT<CAP>& S, int n, int smax, int lane) {
+    if (n <= 1) return n;
+    constexpr int PER = (CAP + 63) / 64;
+    const int ib = n <= 512 ? 9 : 11;
+    const i64 imask = ((i64)1 << ib) - 1;
+    WAVE_SYNC();
+    for (int k = lane; k < n; k += 64) S.lk[k] = W.re[k] << ib | (i64)k;
+    WAVE_SYNC();
+    // sort by the END position
+    if (!resc_rank_keys(S.lk, n, ib, lane, S.ord)) {
+        wave_introsort_i64<PER>(n, S.lk, ib, lane, S.ord, S.ord2, o.wd);   // (klib's introsort move for move, by the wave: lh_sort.h)
+        WAVE_SYNC();
+        for (int k = lane; k < n; k += 64) S.ord[k] = (uint16_t)(S.lk[k] & imask);
+        WAVE_SYNC();
+    }
+    // the scan
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        u64 act;
+        {
+            const int i = c0 + lane;
+            int a_ = 0;
+            if (i >= 1 && i < n) { const int e = S.ord[i], em = S.ord[i - 1]; a_ = !(W.rid[e] != W.rid[em] || W.rb[e] >= W.re[em] + o.max_chain_gap); }
+            act = __ballot(a_);
+        }
+        while (act) {
+            const int i = c0 + __ffsll((unsigned long long)act) - 1;
+            act &= act - 1;
+            const int pe = S.ord[i];
+            const i64 p_rb = W.rb[pe], p_re = W.re[pe];
+            const int p_qb = W.qb[pe], p_qe = W.qe[pe], p_sc = W.score[pe], p_rid = W.rid[pe];
+            for (int j0 = i - 1; j0 >= 0; j0 -= 64) {
+                const int j = j0 - lane;
+                int stop = 1, kp = 0, kq = 0, qx = 0, q_qb = 0;
+                if (j >= 0) {
+                    qx = S.ord[j];
+                    const i64 q_re = W.re[qx];
+                    if (p_rid == W.rid[qx] && p_rb < q_re + o.max_chain_gap) {
+                        stop = 0;
+                        q_qb = W.qb[qx];
+                        const int q_qe = W.qe[qx];
+                        if (q_qe != q_qb && resc_redundant(o, W.rb[qx], q_re, q_qb, q_qe, p_rb, p_re, p_qb, p_qe)) { if (p_sc < W.score[qx]) kp = 1; else kq = 1; }
+                    }
+                }
+                const u64 sm = __ballot(stop || kp);
+                const int first = sm ? __ffsll((unsigned long long)sm) - 1 : 64;
+                if (kq && lane < first) W.qe[qx] = q_qb;          // a[j] is excluded
+                if (kp && lane == first) W.qe[pe] = p_qb;         // p is, by a better entry: the end of its walk
+                if (sm) break;
+            }
+            WAVE_SYNC();
+        }
+    }
+    WAVE_SYNC();
+    // exclude what the scan marked (in the order of the first sort: the second sort's input), and the second sort's keys
+    int m = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        int e = 0, alive = 0;
+        if (i < n) { e = S.ord[i]; alive = W.qe[e] > W.qb[e]; }
+        const u64 mk = __ballot(alive);
+        if (alive) S.lk[m + lanes_below(mk, lane)] = (i64)(smax - W.score[e]) << (41 + ib) | W.rb[e] << (8 + ib) | (i64)W.qb[e] << ib | (i64)e;
+        m += (int)__popcll(mk);
+    }
+    WAVE_SYNC();
+    if (!resc_rank_keys(S.lk, m, ib, lane, S.ord)) {
+        wave_introsort_i64<PER>(m, S.lk, ib, lane, S.ord, S.ord2, o.wd);
+        WAVE_SYNC();
+        // identical hits (score, rb, qb: the key above the index): all but the first of a run go
+        int m2 = 0;
+        for (int c0 = 0; c0 < m; c0 += 64) {
+            const int i = c0 + lane;
+            int keep = 0;
+            i64 key = 0;
+            if (i < m) { key = S.lk[i]; keep = i == 0 || (S.lk[i - 1] >> ib) != (key >> ib); }
+            const u64 mk = __ballot(keep);
+            WAVE_SYNC();
+            if (keep) S.ord[m2 + lanes_below(mk, lane)] = (uint16_t)(key & imask);
+            m2 += (int)__popcll(mk);
+        }
+        m = m2;
+        WAVE_SYNC();
+    }
+    // the survivors into their places
+    i64 e_[PER], rb_[PER]; int qb_[PER], qe_[PER], sc_[PER], rid_[PER], src_[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int k = t * 64 + lane;
+        if (k < m) { const int x = S.ord[k]; e_[t] = W.re[x]; rb_[t] = W.rb[x]; qb_[t] = W.qb[x]; qe_[t] = W.qe[x]; sc_[t] = W.score[x]; rid_[t] = W.rid[x]; src_[t] = W.src[x]; }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int k = t * 64 + lane;
+        if (k < m) { W.re[k] = e_[t]; W.rb[k] = rb_[t]; W.qb[k] = qb_[t]; W.qe[k] = qe_[t]; W.score[k] = sc_[t]; W.rid[k] = rid_[t]; W.src[k] = src_[t]; }
+    }
+    WAVE_SYNC();
+    return m;
+}
+
+// Contigs that INTERLEAVE in the order of end positions — an entry of another contig between two entries of one — cannot happen with real coordinates (a contig is an
+// interval of the concatenated reference, forward or reverse), and the incremental form relies on it: the scan's walk stops at an entry of another contig, so excluding such an
+// entry would let two entries meet that no call has compared.  Checked when a list is loaded (a list that fails has every call run as written); a rescued region lies in its
+// anchor's contig, so a list stays as it was found.  Returns 1 if some entry has an entry of another contig and, beyond that but within max_chain_gap, one of its own to its left.
+template <int CAP> __device__ __forceinline__ int resc_list_interleaved(const DOpts& o, const RescListT<CAP>& W, int n, int lane) {
+    int bad = 0;
+    for (int k = lane; k < n; k += 64) {
+        const i64 pre = W.re[k], prb = W.rb[k];
+        const int prid = W.rid[k];
+        i64 lo = -0x7fffffffffffffffll;   // the nearest entry of another contig to the left
+        for (int u = 0; u < n; ++u) { const i64 e = W.re[u]; if (W.rid[u] != prid && e <= pre && e > lo) lo = e; }
+        // (within the scan's reach only: a contig's forward and reverse strands are two intervals with other contigs in between, and far apart)
+        for (int u = 0; u < n; ++u) { const i64 e = W.re[u]; bad |= W.rid[u] == prid && e <= lo && prb < e + o.max_chain_gap; }
+    }
+    return __any(bad);
+}
+
 // development aid (-DLH_RFA_PROF): shader clocks per part of the replay, and how its calls were decided
 #ifdef LH_RFA_PROF
 __device__ unsigned long long lh_resc_prof[24];
@@ -648,16 +837,29 @@ __device__ unsigned long long lh_resc_prof[24];
 #define RA_PROF(k_) {}
 #define RA_COUNT(k_) {}
 #endif
+#ifdef LH_RA_HIST   // development aid: pairs by log2 of their replay's duration in 10 ns ticks (wall_clock64): [0, 32) pairs whose calls were all decided incrementally, [32, 64) pairs with a call run as written; [64], [65]: the longest of each kind
+__device__ unsigned long long lh_resc_hist[2 * 32 + 2];
+#endif
 template <int DIR, int CAP>
 __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pairs, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
                                                     DReg* __restrict__ regs, DReg* __restrict__ regs_tmp, int32_t* __restrict__ ia_pool, int32_t* __restrict__ n_regs,
-                                                    const int32_t* __restrict__ best_score, DCounters* __restrict__ ctr, const int32_t* __restrict__ list, const RMeta* __restrict__ meta,
+                                                    const int32_t* __restrict__ best_score, const uint8_t* __restrict__ clean, DCounters* __restrict__ ctr, const int32_t* __restrict__ list, RMeta* __restrict__ meta,
                                                     const int32_t* __restrict__ n_jobs, const i64* __restrict__ job_off, const RJob* __restrict__ jobs) {
     __shared__ uint8_t qm[LH_MAXLEN + 6];
     __shared__ RescListT<CAP> W;
+    __shared__ RescScratchT<CAP> S;
     const int lane = LANE();
     const int n_items = meta->list_count;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // (r05) the entries are handed out one at a time: with a fixed share per wave (18 entries) the kernel's duration was that of its unluckiest wave — the SQ
+    // counters showed a third of the resident waves on average (profiles/r05_pmc_repeats.json) — and a pair's cost spans two orders of magnitude
+    // (the long-list instance — a handful of pairs — keeps its fixed stride: its waves would each walk the whole list through the counter)
+    for (int turn = 0;; ++turn) {
+        int item = (int)blockIdx.x + turn * (int)gridDim.x;
+        if (CAP == LH_RA_CAP) {
+            if (lane == 0) item = atomicAdd(&meta->apply_next[0], 1);
+            item = wave_readlane(item, 0);
+        }
+        if (item >= n_items) break;
         // two instances of this kernel share the list: the one with the usual LDS arrays takes the pairs whose mate's list fits them with everything that
         // may come, the one with LH_RA_CAP_BIG entries the others (k_resc_enum decided, bit 30 of the entry: every pair is replayed exactly once)
         if (((list[item] >> 30) & 1) != (CAP != LH_RA_CAP)) continue;
@@ -690,10 +892,21 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
         u64 cells = 0;
         int n_sw = 0, num = 0;
         int w_sorted = 1;   // the list in LDS is in the call's final order (until a rescued region is appended)
-        int mode = 0;   // 0: the list is in memory, no dedup call yet; 1: in LDS (W), clean; 2: in memory for good (equal re left behind / too long); 3: in memory for this call
+        int mode = 0;   // 0: the list is in memory, no dedup call yet; 1: in LDS (W), clean; 2: in memory for good (too long); 3: in memory for this call; 4: in LDS with a tie that is not harmless (every call as written, resc_dedup_lds)
+        // (r05) the first test below reads every mate region's rb, per anchor — fifty anchors a pair, most of them skipped by that very test, so that many
+        // pairs never get as far as loading the list (mode 0 for good): a gather of 72-byte records from memory per anchor and 64 regions was the replay's
+        // largest part.  The rb alone are in LDS from the start; W.rb is the as-written call's scratch, so they are loaded again after every such call.
+        int inter = 0;   // the list in LDS has contigs that interleave (see resc_list_interleaved)
+        int rb_lds = 0;
+        if (n_ma <= CAP) { for (int k = lane; k < n_ma; k += 64) W.rb[k] = ma[k].rb; rb_lds = 1; }
+        WAVE_SYNC();
 #ifdef LH_RFA_PROF
         unsigned long long prof_t_ = (unsigned long long)clock64();
         RA_COUNT(8)
+#endif
+#ifdef LH_RA_HIST
+        const unsigned long long pair_t0_ = (unsigned long long)wall_clock64();
+        int n_asw_ = 0;
 #endif
         for (int i = 0; i < nf && num < o.rescue_max_hits && l_ms > 0; ++i) {
             if ((i & 63) == 0) {
@@ -718,7 +931,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 int k = i0 + lane, f = 0;
                 if (k < n_ma) {
                     i64 dist;
-                    int r = dev_infer_dir(ix.l_pac, a.rb, mode == 1 ? W.rb[k] : ma[k].rb, &dist);
+                    int r = dev_infer_dir(ix.l_pac, a.rb, (mode == 1 || mode == 4 || rb_lds) ? W.rb[k] : ma[k].rb, &dist);
                     f = (r == 1 && dist >= o.pes_low && dist <= o.pes_high);
                 }
                 if (__any(f)) { skip1 = 1; break; }
@@ -765,8 +978,11 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                     W.rb[k] = g.rb; W.re[k] = g.re; W.qb[k] = g.qb; W.qe[k] = g.qe; W.score[k] = g.score; W.rid[k] = g.rid; W.src[k] = k;
                 }
                 WAVE_SYNC();
+                // (r05) K5 says when there is nothing to look for: no region of the list was merged and no two end where another does (k_dedup.h: clean) — the pass below was a
+                // third of the replay of a pair whose calls are all incremental
+                const int known = clean[r_ms];
                 int dirty = 0;
-                for (int k0 = 0; k0 < n_ma; k0 += 64) {
+                for (int k0 = 0; k0 < n_ma && !known; k0 += 64) {
                     const int k = k0 + lane;
                     if (k < n_ma) {
                         const i64 pre = W.re[k], prb = W.rb[k];
@@ -779,21 +995,38 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                     }
                 }
                 mode = __any(dirty) ? 0 : 1;
-                if (mode == 1 && resc_list_ties(o, W, n_ma, lane)) mode = 0;   // (two entries with one re that are redundant one way round: the first call as written)
+                if (mode == 1 && resc_list_interleaved(o, W, n_ma, lane)) mode = 0;   // (not with real coordinates; the reload below keeps such a list's calls as written)
+                if (mode == 1 && known) { for (int k = lane; k < n_ma; k += 64) W.tied[k] = 0; }
+                else if (mode == 1 && resc_list_ties(o, W, n_ma, lane)) mode = 0;   // (two entries with one re that are redundant one way round: the first call as written)
                 WAVE_SYNC();
                 RA_PROF(2)
                 if (mode == 0) RA_COUNT(10)
             }
-            if (mode == 1) {
-                if (!hit) continue;   // a clean list and nothing new: the call changes nothing
-                {   // the call as a function of b
+            if (mode == 1 || mode == 4) {   // the list is in LDS
+                if (mode == 1) {
+                    if (!hit) continue;   // a clean list and nothing new: the call changes nothing
+                    // the call as a function of b
                     int app = 0;
                     const int n_inc = resc_dedup_incremental(o, W, n_ma, b, lane, &app);
                     RA_PROF(3)
                     if (n_inc >= 0) { n_ma = n_inc; if (app) w_sorted = 0; RA_COUNT(11) continue; }
                     RA_COUNT(12)
                 }
-                // equal keys: this call as written, on the list in memory (mode 3: it may come back if the call leaves no equal re behind)
+                // equal keys: this call as written — in LDS if the packed sort keys hold the list (resc_dedup_lds), else on the list in memory (mode 3: it comes back)
+                int smax = 0;
+                if (resc_lds_keys_ok(W, n_ma, hit ? &b : nullptr, lane, &smax)) {
+                    if (!w_sorted) { resc_list_sort(W, n_ma, lane); w_sorted = 1; }   // the order the previous call left: what this one finds
+                    if (hit) n_ma = resc_list_insert(W, n_ma, b, lane);
+                    n_ma = resc_dedup_lds(o, W, S, n_ma, smax, lane);
+                    mode = (resc_list_ties(o, W, n_ma, lane) | inter) ? 4 : 1;   // (4: a tie that is not harmless stays: every further call as written)
+                    WAVE_SYNC();
+                    RA_PROF(5)
+                    RA_COUNT(13)
+#ifdef LH_RA_HIST
+                    ++n_asw_;
+#endif
+                    continue;
+                }
                 resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane, w_sorted);
                 mode = 3;
             }
@@ -819,6 +1052,9 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
             }
             RA_PROF(4)
             RA_COUNT(13)
+#ifdef LH_RA_HIST
+            ++n_asw_;
+#endif
             n_ma = wave_sort_dedup_patch(ix, o, qm, ma, n_ma, ia_pool + ro_ms + r_ms, regs_tmp + ro_ms, 0, lane, &cells, (i64*)&W, 2 * CAP);   // (the list is in memory during the call: W's two 64-bit arrays are the sorts' scratch)
             RA_PROF(5)
             if (mode != 2 && n_ma + o.rescue_max_hits <= CAP) {   // (back) into LDS if the list fits with everything that may still come and no two re are equal
@@ -829,14 +1065,30 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 WAVE_SYNC();
                 w_sorted = 1;
                 // equal end positions left behind: harmless ones are marked, one that is not keeps the list in memory for good
-                mode = resc_list_ties(o, W, n_ma, lane) ? 2 : 1;
+                inter = resc_list_interleaved(o, W, n_ma, lane);
+                mode = (resc_list_ties(o, W, n_ma, lane) | inter) ? 4 : 1;   // (4: the list stays in LDS, every call as written)
                 WAVE_SYNC();
-                if (mode == 2) RA_COUNT(14)
-            } else { mode = 2; RA_COUNT(15) }
+                rb_lds = 1;
+                if (mode == 4) RA_COUNT(14)
+            } else {
+                mode = 2; RA_COUNT(15)
+                rb_lds = n_ma <= CAP;
+                if (rb_lds) for (int k = lane; k < n_ma; k += 64) W.rb[k] = ma[k].rb;
+                WAVE_SYNC();
+            }
             RA_PROF(6)
         }
-        if (mode == 1) resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane, w_sorted);
+        if (mode == 1 || mode == 4) resc_list_store(ix, W, n_ma, ma, regs_tmp + ro_ms, lane, w_sorted);
         RA_PROF(7)
+#ifdef LH_RA_HIST
+        if (lane == 0) {
+            const unsigned long long dt_ = (unsigned long long)wall_clock64() - pair_t0_;
+            int b_ = 0;
+            while (b_ < 31 && (dt_ >> (b_ + 1))) ++b_;
+            atomicAdd(&lh_resc_hist[(n_asw_ != 0) * 32 + b_], 1ull);
+            atomicMax(&lh_resc_hist[64 + (n_asw_ != 0)], dt_);
+        }
+#endif
         if (lane == 0) {
             n_regs[r_ms] = n_ma;
             if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); }

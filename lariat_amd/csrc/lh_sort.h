@@ -95,6 +95,118 @@ template <class T, class Lt> __device__ inline void dev_introsort(int n, T* a, L
     }
 }
 
+// ---- (r05) klib's introsort by a whole wave, move for move.  a[0, n): 64-bit words in LDS compared above their low `ib` bits (the sort keys of k_dedup.h / k_rescue2.h: the
+// element's index sits below the key, so equal keys are told apart afterwards — and where the introsort leaves them is part of the result).  What is serial in
+// ks_introsort is the sequence of partitions, not a partition: its two scans only ever look at positions neither has passed (a swap writes behind them), so on the
+// array as the partition finds it the i-scan stops, in turn, at the positions of (s, t] whose element is not below the pivot — ascending: I_1 < I_2 < .. — and the j-scan at the
+// positions of [s, t) whose element is not above it — descending: J_1 > J_2 > .. —; the r-th swap is a[I_r] <-> a[J_r], they go on while J_r > I_r (a condition that, once
+// false, stays false), and the scan ends with i on the next I (or on J_R, where the last swap put an element that stops it, if that comes first).  Both lists come from ballots, the swaps are independent, the pivot rule and the stack are ks_introsort's.
+// The closing insertion sort is stable: its result is the array ranked by (key, place before it).  The depth limit's comb sort (never seen on region lists) stays one lane's.
+// pa, pb: LDS scratch, n 16-bit entries each.  One single-wave block (the stack is dev_introsort's).
+template <int PER> __device__ inline void wave_introsort_i64(int n, i64* a, int ib, int lane, uint16_t* pa, uint16_t* pb, int32_t* wdp) {
+    typedef LhIsortStk Stk;
+    Stk* const stack = lh_isort_stack_ptr();
+#ifndef LH_EMU
+    if (blockDim.x != 64) { wdp[1] = 1; return; }
+#endif
+    if (n < 2) return;
+    WAVE_SYNC();
+    if (n == 2) {
+        if (lane == 0 && (a[1] >> ib) < (a[0] >> ib)) { const i64 x = a[0]; a[0] = a[1]; a[1] = x; }
+        WAVE_SYNC();
+        return;
+    }
+    int d;
+    for (d = 2; (1ul << d) < (unsigned long)n; ++d) {}
+    int top = 0, s = 0, t = n - 1;
+    d <<= 1;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) {
+                if (lane == 0) dev_combsort(t - s + 1, a + s, [&](i64 x, i64 y) { return (x >> ib) < (y >> ib); });
+                WAVE_SYNC();
+                t = s;
+                continue;
+            }
+            int k = s + ((t - s) >> 1) + 1;
+            {
+                const i64 vs = a[s] >> ib, vk = a[k] >> ib, vt = a[t] >> ib;
+                if (vk < vs) { if (vk < vt) k = t; }
+                else k = vt < vs ? s : t;
+            }
+            const i64 rpw = a[k], rp = rpw >> ib;
+            WAVE_SYNC();
+            if (k != t && lane == 0) { a[k] = a[t]; a[t] = rpw; }
+            WAVE_SYNC();
+            // the i-scan's stops, ascending (a[t] is the pivot: the last of them), and the j-scan's, descending
+            int ni = 0, nj = 0;
+            for (int x0 = s + 1; x0 <= t; x0 += 64) {
+                const int x = x0 + lane;
+                const int isI = x <= t && !((a[x] >> ib) < rp);
+                const u64 m = __ballot(isI);
+                if (isI) pa[ni + lanes_below(m, lane)] = (uint16_t)x;
+                ni += (int)__popcll(m);
+            }
+            for (int x0 = t - 1; x0 >= s; x0 -= 64) {
+                const int x = x0 - lane;
+                const int isJ = x >= s && !(rp < (a[x] >> ib));
+                const u64 m = __ballot(isJ);
+                if (isJ) pb[nj + lanes_below(m, lane)] = (uint16_t)x;
+                nj += (int)__popcll(m);
+            }
+            WAVE_SYNC();
+            const int np = ni < nj ? ni : nj;
+            int R = 0;
+            for (int r0 = 0; r0 < np; r0 += 64) {
+                const int r = r0 + lane;
+                const int sw = r < np && pb[r] > pa[r];
+                const u64 m = __ballot(sw);
+                if (sw) { const int xi = pa[r], xj = pb[r]; const i64 u = a[xi]; a[xi] = a[xj]; a[xj] = u; }
+                R += (int)__popcll(m);
+                if (m != ~0ull) break;
+            }
+            WAVE_SYNC();
+            // where the i-scan ends: at the next of its stops — or before that on the place of the last swap's j, which now holds an element that is not below the pivot
+            // (R < ni: the swaps stop at the latest when the i-scan is at t, where no j is above it)
+            int i = pa[R];
+            if (R > 0 && pb[R - 1] < i) i = pb[R - 1];
+            WAVE_SYNC();
+            if (lane == 0) { const i64 u = a[i]; a[i] = a[t]; a[t] = u; }
+            WAVE_SYNC();
+            if (i - s > t - i) {
+                if (i - s > 16) { if (top >= LH_ISORT_STK) { wdp[1] = 1; return; } if (lane == 0) { stack[top].left = s; stack[top].right = i - 1; stack[top].depth = d; } ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { if (top >= LH_ISORT_STK) { wdp[1] = 1; return; } if (lane == 0) { stack[top].left = i + 1; stack[top].right = t; stack[top].depth = d; } ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+        } else {
+            if (top == 0) break;
+            WAVE_SYNC();
+            --top; s = stack[top].left; t = stack[top].right; d = stack[top].depth;
+        }
+    }
+    // the insertion sort over the whole array
+    WAVE_SYNC();
+    i64 v[PER]; int rk[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int x = u * 64 + lane;
+        rk[u] = -1;
+        if (x < n) {
+            v[u] = a[x];
+            const i64 kx = v[u] >> ib;
+            int c = 0;   // (the whole array: klib's median rule can leave a[s] above the pivot on the pivot's left — the partitions do not bound how far an element still has to go)
+            for (int y = 0; y < n; ++y) { const i64 ky = a[y] >> ib; c += ky < kx || (ky == kx && y < x); }
+            rk[u] = c;
+        }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) if (rk[u] >= 0) a[rk[u]] = v[u];
+    WAVE_SYNC();
+}
+
 // ---- Go 1.9 sort.Sort over an index space [0,n): less(i,j), swp(i,j) ----
 // NOTE: called lane-parallel (one independent sort per lane) by k_rfa, so its branches must stay per-lane: no LH_UNI here.
 template <class L, class S> __device__ inline void gs_insertion(L& less, S& swp, int a, int b) {

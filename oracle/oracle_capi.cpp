@@ -13,6 +13,7 @@
 #include "lariat_oracle.h"
 
 #include "gosort_impl.h"
+#include "ksort_impl.h"
 using namespace orc;
 
 namespace {
@@ -76,6 +77,19 @@ void lo_gosort(int32_t n_sorts, const int32_t* first, int64_t* keys, int32_t* pe
         int32_t* ip = perm + first[k];
         orc::go19_sort(first[k + 1] - first[k], [&](int i, int j) { return kp[i] < kp[j]; },
                        [&](int i, int j) { std::swap(kp[i], kp[j]); std::swap(ip[i], ip[j]); });
+    }
+}
+
+// klib's ks_introsort over `n_sorts` index spaces of keys[]: (key, index) pairs compared by key alone; perm[] = the index each position ends up holding
+// (tests/test_sort.py checks the device's one-lane and wave-wide restatements against it)
+void lo_ks_introsort(int32_t n_sorts, const int32_t* first, const int64_t* keys, int32_t* perm) {
+    struct KI { int64_t k; int32_t i; };
+    for (int c = 0; c < n_sorts; ++c) {
+        const int n = first[c + 1] - first[c];
+        std::vector<KI> v((size_t)n);
+        for (int i = 0; i < n; ++i) { v[(size_t)i].k = keys[first[c] + i]; v[(size_t)i].i = i; }
+        orc::ks_introsort((size_t)n, v.data(), [](const KI& a, const KI& b) { return a.k < b.k; });
+        for (int i = 0; i < n; ++i) perm[first[c] + i] = v[(size_t)i].i;
     }
 }
 

@@ -72,3 +72,9 @@ def test_gosort_serial_and_wave(lib, oracle):
     """K8's two restatements of Go's sort.Sort (equal keys end up where Go leaves them) against the oracle's, on the GPU"""
     import test_sort
     test_sort.check(lib, oracle)
+
+
+def test_introsort_one_lane_and_wave(lib, oracle):
+    """K5 / K6's two restatements of klib's ks_introsort (equal keys end up where klib leaves them) against the oracle's, on the GPU"""
+    import test_sort
+    test_sort.check_introsort(lib, oracle)

@@ -55,3 +55,52 @@ def check(lib, oracle):
 
 def test_emu_gosort_serial_and_wave(emu, oracle):
     check(emu, oracle)
+
+
+# ---- klib's ks_introsort (the region sorts of mem_sort_dedup_patch, reached from gobwa.go:244,253,291,315): K5 / K6 run it by one lane (dev_introsort) and, when a rescue
+# replay has to run a call as written, by the whole wave (wave_introsort_i64: the partitions from ballots, the closing insertion sort as a stable ranking).  Equal keys must
+# end up where klib leaves them: both against the oracle's restatement (oracle/ksort_impl.h).
+def oracle_introsort(oracle, first, keys):
+    first = np.ascontiguousarray(first, dtype=np.int32)
+    k = np.ascontiguousarray(keys, dtype=np.int64)
+    perm = np.zeros(int(first[-1]), dtype=np.int32)
+    oracle.L.lo_ks_introsort.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    oracle.L.lo_ks_introsort.restype = None
+    oracle.L.lo_ks_introsort(len(first) - 1, first.ctypes.data_as(C.POINTER(C.c_int32)), k.ctypes.data_as(C.POINTER(C.c_int64)), perm.ctypes.data_as(C.POINTER(C.c_int32)))
+    return perm
+
+
+def introsort_cases():
+    rng = np.random.default_rng(21)
+    out = []
+    for sizes, hi in (([0, 1, 2, 3, 5, 16, 17, 18, 33, 34, 40, 64, 65, 100, 127, 128, 129], 4), ([200] * 40, 8), ([300] * 30, 1 << 40), ([1024, 1000, 513], 3),
+                      (list(rng.integers(17, 400, size=120)), 30), (list(rng.integers(17, 400, size=120)), 2), ([1024] * 4, 1)):
+        first = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        out.append((first, rng.integers(0, hi, size=int(first[-1]))))
+    # end positions of a region list: mostly distinct, a few equal pairs (the case the pipeline meets)
+    sizes = list(rng.integers(30, 320, size=150))
+    first = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    keys = rng.integers(0, 1 << 33, size=int(first[-1]))
+    for k in range(len(sizes)):
+        a, b = int(first[k]), int(first[k + 1])
+        for _ in range(int(rng.integers(1, 4))):
+            keys[a + int(rng.integers(0, b - a))] = keys[a + int(rng.integers(0, b - a))]
+    out.append((first, keys))
+    n = 1000   # sorted, reversed, sawtooth, organ pipe: the patterns that drive the partitions towards the depth limit
+    out.append((np.array([0, n, 2 * n, 3 * n, 4 * n], dtype=np.int32), np.concatenate([np.arange(n), np.arange(n)[::-1], np.arange(n) % 7, np.minimum(np.arange(n), n - np.arange(n))])))
+    return out
+
+
+def check_introsort(lib, oracle):
+    for first, keys in introsort_cases():
+        want = oracle_introsort(oracle, first, keys)
+        ps, pw = lib.diag_introsort(first, keys)
+        assert np.array_equal(ps, want), ("one-lane introsort", np.nonzero(ps != want)[0][:8])
+        assert np.array_equal(pw, want), ("wave introsort", np.nonzero(pw != want)[0][:8])
+        for k in range(len(first) - 1):   # and it IS a sort
+            a, b = int(first[k]), int(first[k + 1])
+            assert np.all(np.diff(np.asarray(keys[a:b])[want[a:b]]) >= 0)
+
+
+def test_emu_introsort_one_lane_and_wave(emu, oracle):
+    check_introsort(emu, oracle)
