@@ -179,8 +179,19 @@ __global__ void __launch_bounds__(64) k_diag_resc_dedup(DIndex ix, DOpts o, int 
             int smax = 0;
             if (resc_lds_keys_ok(W, n, &b, lane, &smax)) {
                 const int n1 = resc_list_insert(W, n, b, lane);
-                const int n_lds = resc_dedup_lds(o, W, S, n1, smax, lane);
-                bad_lds = n_lds != n_full;
+                int harmful_lds = 0;
+                const int n_lds = resc_dedup_lds(o, W, S, n1, smax, lane, c & 1, &harmful_lds);
+                if (n_lds >= 0) {   // its marks and verdict against resc_list_ties' on the same list (a mark too many is allowed, see resc_dedup_lds)
+                    int t0[(LH_RA_CAP + 63) / 64];
+#pragma unroll
+                    for (int u = 0; u < (LH_RA_CAP + 63) / 64; ++u) { const int k = u * 64 + lane; t0[u] = k < n_lds ? W.tied[k] : 0; }
+                    WAVE_SYNC();
+                    const int h2 = resc_list_ties(o, W, n_lds, lane);
+#pragma unroll
+                    for (int u = 0; u < (LH_RA_CAP + 63) / 64; ++u) { const int k = u * 64 + lane; if (k < n_lds && W.tied[k] && !t0[u]) bad_lds = 1; }
+                    if (h2 && !harmful_lds) bad_lds = 1;
+                }
+                bad_lds |= n_lds != n_full;
                 for (int k = lane; k < n_full && k < n_lds; k += 64)
                     bad_lds |= B[k].rb != W.rb[k] || B[k].re != W.re[k] || B[k].qb != W.qb[k] || B[k].qe != W.qe[k] || B[k].score != W.score[k] || B[k].rid != W.rid[k] || B[k].seedcov != W.src[k];
                 bad_lds = __any(bad_lds);

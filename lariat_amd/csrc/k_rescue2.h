@@ -711,17 +711,19 @@ template <int CAP> __device__ __forceinline__ int resc_list_insert(RescListT<CAP
     return n + 1;
 }
 // mem_sort_dedup_patch(opt, 0, 0, 0, n, list) on W[0, n) in the order the call finds it (resc_lds_keys_ok said yes; smax from there); W is left in the call's final order
-// (W.tied is not maintained: resc_list_ties follows).  Returns the new length.
-template <int CAP> __device__ __forceinline__ int resc_dedup_lds(const DOpts& o, RescListT<CAP>& W, RescScratchT<CAP>& S, int n, int smax, int lane) {
-    if (n <= 1) return n;
+// and W.tied / *harmful_out as resc_list_ties would set them (an entry whose twin the second sort's removal of identical hits takes away may keep its mark: a mark only
+// ever sends a call here).  Returns the new length.
+template <int CAP> __device__ __forceinline__ int resc_dedup_lds(const DOpts& o, RescListT<CAP>& W, RescScratchT<CAP>& S, int n, int smax, int lane, int known_tie, int* harmful_out) {
+    *harmful_out = 0;
+    if (n <= 1) { if (n == 1 && lane == 0) W.tied[0] = 0; WAVE_SYNC(); return n; }
     constexpr int PER = (CAP + 63) / 64;
     const int ib = n <= 512 ? 9 : 11;
     const i64 imask = ((i64)1 << ib) - 1;
     WAVE_SYNC();
     for (int k = lane; k < n; k += 64) S.lk[k] = W.re[k] << ib | (i64)k;
     WAVE_SYNC();
-    // sort by the END position
-    if (!resc_rank_keys(S.lk, n, ib, lane, S.ord)) {
+    // sort by the END position (known_tie: the caller has seen two equal end positions — no point in trying to rank)
+    if (known_tie || !resc_rank_keys(S.lk, n, ib, lane, S.ord)) {
         wave_introsort_i64<PER>(n, S.lk, ib, lane, S.ord, S.ord2, o.wd);   // (klib's introsort move for move, by the wave: lh_sort.h)
         WAVE_SYNC();
         for (int k = lane; k < n; k += 64) S.ord[k] = (uint16_t)(S.lk[k] & imask);
@@ -772,8 +774,32 @@ template <int CAP> __device__ __forceinline__ int resc_dedup_lds(const DOpts& o,
         int e = 0, alive = 0;
         if (i < n) { e = S.ord[i]; alive = W.qe[e] > W.qb[e]; }
         const u64 mk = __ballot(alive);
-        if (alive) S.lk[m + lanes_below(mk, lane)] = (i64)(smax - W.score[e]) << (41 + ib) | W.rb[e] << (8 + ib) | (i64)W.qb[e] << ib | (i64)e;
+        if (alive) {
+            const int d = m + lanes_below(mk, lane);
+            S.lk[d] = (i64)(smax - W.score[e]) << (41 + ib) | W.rb[e] << (8 + ib) | (i64)W.qb[e] << ib | (i64)e;
+            S.ord2[d] = (uint16_t)e;
+        }
         m += (int)__popcll(mk);
+    }
+    WAVE_SYNC();
+    // equal end positions among the survivors (resc_list_ties' marks and verdict, read off the sorted order: equal ends are neighbours)
+    {
+        int harmful = 0;
+        for (int d = lane; d < m; d += 64) {
+            const int e = S.ord2[d];
+            const i64 pre = W.re[e], prb = W.rb[e];
+            const int pqb = W.qb[e], pqe = W.qe[e], prid = W.rid[e];
+            int t = d > 0 && W.re[S.ord2[d - 1]] == pre;
+            for (int u = d + 1; u < m; ++u) {
+                const int x = S.ord2[u];
+                if (W.re[x] != pre) break;
+                t = 1;
+                if (W.rid[x] != prid) harmful = 1;
+                else harmful |= resc_redundant(o, W.rb[x], pre, W.qb[x], W.qe[x], prb, pre, pqb, pqe) || resc_redundant(o, prb, pre, pqb, pqe, W.rb[x], pre, W.qb[x], W.qe[x]);
+            }
+            W.tied[e] = (uint8_t)t;
+        }
+        *harmful_out = __any(harmful);
     }
     WAVE_SYNC();
     if (!resc_rank_keys(S.lk, m, ib, lane, S.ord)) {
@@ -795,17 +821,17 @@ template <int CAP> __device__ __forceinline__ int resc_dedup_lds(const DOpts& o,
         WAVE_SYNC();
     }
     // the survivors into their places
-    i64 e_[PER], rb_[PER]; int qb_[PER], qe_[PER], sc_[PER], rid_[PER], src_[PER];
+    i64 e_[PER], rb_[PER]; int qb_[PER], qe_[PER], sc_[PER], rid_[PER], src_[PER], tie_[PER];
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int k = t * 64 + lane;
-        if (k < m) { const int x = S.ord[k]; e_[t] = W.re[x]; rb_[t] = W.rb[x]; qb_[t] = W.qb[x]; qe_[t] = W.qe[x]; sc_[t] = W.score[x]; rid_[t] = W.rid[x]; src_[t] = W.src[x]; }
+        if (k < m) { const int x = S.ord[k]; e_[t] = W.re[x]; rb_[t] = W.rb[x]; qb_[t] = W.qb[x]; qe_[t] = W.qe[x]; sc_[t] = W.score[x]; rid_[t] = W.rid[x]; src_[t] = W.src[x]; tie_[t] = W.tied[x]; }
     }
     WAVE_SYNC();
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int k = t * 64 + lane;
-        if (k < m) { W.re[k] = e_[t]; W.rb[k] = rb_[t]; W.qb[k] = qb_[t]; W.qe[k] = qe_[t]; W.score[k] = sc_[t]; W.rid[k] = rid_[t]; W.src[k] = src_[t]; }
+        if (k < m) { W.re[k] = e_[t]; W.rb[k] = rb_[t]; W.qb[k] = qb_[t]; W.qe[k] = qe_[t]; W.score[k] = sc_[t]; W.rid[k] = rid_[t]; W.src[k] = src_[t]; W.tied[k] = (uint8_t)tie_[t]; }
     }
     WAVE_SYNC();
     return m;
@@ -1017,8 +1043,9 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 if (resc_lds_keys_ok(W, n_ma, hit ? &b : nullptr, lane, &smax)) {
                     if (!w_sorted) { resc_list_sort(W, n_ma, lane); w_sorted = 1; }   // the order the previous call left: what this one finds
                     if (hit) n_ma = resc_list_insert(W, n_ma, b, lane);
-                    n_ma = resc_dedup_lds(o, W, S, n_ma, smax, lane);
-                    mode = (resc_list_ties(o, W, n_ma, lane) | inter) ? 4 : 1;   // (4: a tie that is not harmless stays: every further call as written)
+                    int harmful = 0;
+                    n_ma = resc_dedup_lds(o, W, S, n_ma, smax, lane, mode == 1 && hit, &harmful);   // (mode 1: the incremental form declined: equal keys, nearly always equal ends)
+                    mode = (harmful | inter) ? 4 : 1;   // (4: a tie that is not harmless stays: every further call as written)
                     WAVE_SYNC();
                     RA_PROF(5)
                     RA_COUNT(13)
