@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--dump-barcodes", type=int, default=200)
     ap.add_argument("--barcodes", type=int, default=4000)
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--pairs-per-barcode", type=int, default=100, help="the timed steps' barcode size (the same pairs in fewer, larger barcodes: K8 works one barcode per wave)")
     ap.add_argument("--lib", default=None, help="another build of the library (e.g. the -DLH_RFA_PROF one of tools/prof_rfa.sh)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--frac", type=float, default=1.0, help="share of every barcode's pairs drawn on the repeat copies (bench.py's mixed leg: 0.05)")
@@ -63,17 +64,17 @@ def main():
     res = ctx.align_barcodes(b)
     dist("candidates per read", np.diff(res.cand_off))
     ctx.close()
-    n_pairs = a.barcodes * 100
+    n_pairs = a.barcodes * a.pairs_per_barcode
     ctx = idx.context(n_pairs)
     opts = lib.opts(flags=a.flags)
     for s in range(a.steps):
         if a.frac >= 1.0:
-            r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400 + s, n_barcodes=a.barcodes, pairs_per_barcode=100)
+            r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400 + s, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode)
         else:
             uniq = workload.outside_windows(g["contigs"], g["alt_flags"], g["windows"])
-            n_rep = int(round(100 * a.frac))
+            n_rep = int(round(a.pairs_per_barcode * a.frac))
             ra = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 700 + s, n_barcodes=a.barcodes, pairs_per_barcode=n_rep)
-            rb = lib.synth_reads(g["pac"], g["l_pac"], uniq, seed=workload.READS_SEED + 100700 + s, n_barcodes=a.barcodes, pairs_per_barcode=100 - n_rep)
+            rb = lib.synth_reads(g["pac"], g["l_pac"], uniq, seed=workload.READS_SEED + 100700 + s, n_barcodes=a.barcodes, pairs_per_barcode=a.pairs_per_barcode - n_rep)
             r = workload.interleave_reads(ra, rb)
         ctx.upload_slot(s, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
     ctx.select(0)
