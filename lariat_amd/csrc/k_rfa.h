@@ -418,6 +418,9 @@ __device__ unsigned long long lh_rfa_prof[24];
 #define RFA_PROF(k_)
 #endif
 #ifndef LH_RFA_WAVES
+#ifdef LH_RA_HIST
+__device__ unsigned long long lh_rfa_hist[34];
+#endif
 #define LH_RFA_WAVES 4   // waves per SIMD the register budget is sized for (128 VGPRs + 64 spilled: the kernel waits on memory, 4 waves hide more of it than 2 waves of 190 registers)
 #endif
 __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, int n_bc, const int32_t* __restrict__ bc_pair_off, const uint8_t* __restrict__ bc_do_rfa,
@@ -463,6 +466,9 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         unsigned long long prof_t_ = (unsigned long long)clock64();
 #endif
         RFA_PROF(2)
+#ifdef LH_RA_HIST
+        const unsigned long long bc_t0_ = (unsigned long long)wall_clock64();
+#endif
         // ---- slab carve (sizes depend on NC, nR) ----
         size_t so = 0;
         RfaTab T;
@@ -484,6 +490,8 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         size_t best_cap = ((size_t)slab_bytes > so) ? ((size_t)slab_bytes - so) / 4 : 0;
 #undef CARVE
         if (so > (size_t)slab_bytes) RFA_OVERFLOW()   // barcode too large for the slab
+        // (measured, r05: guessing from NC and nR that the molecule x read table will not fit — to spare a barcode three phases in a tier it outgrows — sends on too many that do fit:
+        // one candidate in four to sixteen starts a molecule, and a barcode sent on waits for one of fewer waves; 4,000 x 100 pairs 108 -> 155 ms, 1,000 x 400 pairs 0.44 -> 1.1 s)
         // ---- positions: filtered candidates grouped by contig in first-seen order, candidate order inside a contig ----
         // pass A: contig slot of every candidate (first-seen numbering) and the slot sizes
         int32_t* const seen = ncmax <= LH_RFA_NCONT_LDS ? (int32_t*)lds_raw : T.seen_rid;
@@ -991,6 +999,16 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         }
         WAVE_SYNC();
         RFA_PROF(11)
+#ifdef LH_RA_HIST
+        if (lane == 0) {   // barcodes by log2 of the time k_rfa spent on them (10 ns ticks), and by candidates
+            const unsigned long long dt_ = (unsigned long long)wall_clock64() - bc_t0_;
+            int b_ = 0;
+            while (b_ < 31 && (dt_ >> (b_ + 1))) ++b_;
+            atomicAdd(&lh_rfa_hist[b_], 1ull);
+            atomicMax(&lh_rfa_hist[32], dt_);
+            atomicAdd(&lh_rfa_hist[33], dt_);
+        }
+#endif
     }
 }
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--pairs-per-barcode", type=int, default=100, help="the timed steps' barcode size (the same pairs in fewer, larger barcodes: K8 works one barcode per wave)")
     ap.add_argument("--lib", default=None, help="another build of the library (e.g. the -DLH_RFA_PROF one of tools/prof_rfa.sh)")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--rfa-slab-kb", type=int, default=0, help="K8's regular slab per wave (default 2048): a small value sends every barcode to the next tier")
     ap.add_argument("--frac", type=float, default=1.0, help="share of every barcode's pairs drawn on the repeat copies (bench.py's mixed leg: 0.05)")
     a = ap.parse_args()
     lib = capi.load_library(a.lib)
@@ -65,7 +66,7 @@ def main():
     dist("candidates per read", np.diff(res.cand_off))
     ctx.close()
     n_pairs = a.barcodes * a.pairs_per_barcode
-    ctx = idx.context(n_pairs)
+    ctx = idx.context(n_pairs, **({"rfa_slab_kb": a.rfa_slab_kb} if a.rfa_slab_kb else {}))
     opts = lib.opts(flags=a.flags)
     for s in range(a.steps):
         if a.frac >= 1.0:
