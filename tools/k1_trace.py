@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--commit", default=None, help="recorded in the output (the GPU box has no git)")
+    ap.add_argument("--kernel-stats", default=None, help="a tools/rocpd_stats.py CSV of the same build: k_smem_first's average duration goes into the output")
     a = ap.parse_args()
     if a.child:
         return child(a)
@@ -62,6 +64,12 @@ def main():
             tr = json.loads(m[-1].split("K1TRACE", 1)[1])
             out.update(tr)
             out["pass1_bracket_ms_while_tracing"] = round(tim[-1]["k_smem4"], 3)
+    out["commit"] = a.commit
+    if a.kernel_stats and os.path.exists(a.kernel_stats):
+        import csv
+        for row in csv.DictReader(open(a.kernel_stats)):
+            if row["Name"].startswith("k_smem_first"):
+                out["k_smem_first_ms"] = round(float(row["AverageNs"]) / 1e6, 3)
     rq = out["requests_by_table"]
     out["requests_total"] = sum(v[0] for v in rq.values())
     out["bytes_total"] = sum(v[1] for v in rq.values())
