@@ -73,6 +73,24 @@ def test_emu_inference_slab_overflow_pass(emu, oracle):
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
 
 
+def test_emu_inference_slab_tiers(emu, oracle, monkeypatch):
+    """(r05) between the regular slabs and the few large ones there are two tiers; a barcode that outgrows one is listed for the next.  With tiers of 48 and 256 KiB
+    (LH_RFA_MID_KB, a test aid) and 4-KiB regular slabs the suite's barcodes go through all of them: some finish in the second tier, the largest in the last launch"""
+    monkeypatch.setenv("LH_RFA_MID_KB", "48,256")
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    idx = emu.index_from_arrays(oidx.arrays())
+    from lariat_amd import synth
+    rs = synth.make_reads(contigs, names, n_barcodes=5, pairs_per_barcode=30, seed=77, junk_frac=0.05)
+    big = synth.make_reads(contigs, names, n_barcodes=1, pairs_per_barcode=400, seed=78, junk_frac=0.05)
+    b = helpers.batch_of(rs)
+    res = idx.context(rs.n_pairs, rfa_slab_kb=4).align_barcodes(b)
+    helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
+    b2 = helpers.batch_of(big)
+    res2 = idx.context(big.n_pairs, rfa_slab_kb=4).align_barcodes(b2)
+    helpers.assert_same_result(res2, oidx.align_barcodes(b2), inference=True)
+
+
 def test_emu_long_noisy_reads(emu, oracle):
     """240-bp reads with substitutions and indels: the 128/256-column classes of the lane-per-read extension, deferred reads,
     gapped global alignments"""
