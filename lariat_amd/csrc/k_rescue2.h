@@ -40,6 +40,12 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_l
 __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return pk_lanes(a, b, 3); }   // saturating at 0
 __device__ __forceinline__ uint32_t pk_subw(uint32_t a, uint32_t b) { return pk_lanes(a, b, 4); }   // wrapping
 __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) { uint32_t o = __shfl_up(v, 1); return (LANE() & 15) == 0 ? 0u : o; }
+// v_perm_b32: byte i of the result = byte sel[i] of {lo: 0..3, hi: 4..7}; selector 0x0c: 0x00 (the selectors 8..11 and >= 13 are not used here)
+__device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) { const uint32_t c = (sel >> (8 * i)) & 0xffu; const uint32_t b = c < 4 ? (lo >> (8 * c)) & 0xffu : c < 8 ? (hi >> (8 * (c - 4))) & 0xffu : 0u; r |= b << (8 * i); }
+    return r;
+}
 #else
 typedef unsigned short lh_us2 __attribute__((ext_vector_type(2)));
 #define LH_US2(x) __builtin_bit_cast(lh_us2, (uint32_t)(x))
@@ -49,6 +55,7 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __bu
 __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(LH_US2(a), LH_US2(b))); }
 __device__ __forceinline__ uint32_t pk_subw(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (lh_us2)(LH_US2(a) - LH_US2(b))); }
 __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); }   // row_shr:1, lane 0 of a row: 0
+__device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 #endif
 __device__ __forceinline__ int grp16_min(int v) { for (int m = 8; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v < o ? v : o; } return v; }
 __device__ __forceinline__ int grp16_max(int v) { for (int m = 8; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v > o ? v : o; } return v; }
@@ -354,8 +361,9 @@ template <int SLEN, bool REV>
 __device__ __forceinline__ void resc_sw_run(const DIndex& ix, const DOpts& o, RJob* __restrict__ jobs, const int32_t* __restrict__ ord, const uint8_t* __restrict__ seq, uint8_t* tl,
                                             RMeta* __restrict__ meta, int lane) {
     const int g = lane >> 4, L = lane & 15;
-    // ---- the windows' bases into LDS, one-hot (16 << base): row i of slot u at tl[u * LH_RJ_TSLOT + 16 + i]
-    for (int i = lane; i < 8 * LH_RJ_TSLOT / 4; i += 64) ((uint32_t*)tl)[i] = 0;
+    // ---- the windows' bases into LDS as the BYTE SELECTOR the row's v_perm needs: row i of slot u at tl[u * LH_RJ_TSLOT + 16 + i] = base (the wave's even slots: a lane's
+    // low half) or 4 + base (odd slots: its high half); 0x0c — "a zero byte" — outside the window
+    for (int i = lane; i < 8 * LH_RJ_TSLOT / 4; i += 64) ((uint32_t*)tl)[i] = 0x0c0c0c0cu;
     WAVE_SYNC();
     int max_t = 0;
     for (int u = 0; u < 8; ++u) {
@@ -364,7 +372,7 @@ __device__ __forceinline__ void resc_sw_run(const DIndex& ix, const DOpts& o, RJ
         const RJob& J = jobs[ju];
         const int tlen = REV ? J.te + 1 : J.tlen;
         const i64 t0 = REV ? J.t0 + J.te : J.t0;
-        for (int i = lane; i < tlen; i += 64) tl[u * LH_RJ_TSLOT + 16 + i] = (uint8_t)(16 << dev_ref_base(ix, REV ? t0 - i : t0 + i));
+        for (int i = lane; i < tlen; i += 64) tl[u * LH_RJ_TSLOT + 16 + i] = (uint8_t)((u & 1) * 4 + dev_ref_base(ix, REV ? t0 - i : t0 + i));
         max_t = max_t > tlen ? max_t : tlen;
     }
     WAVE_SYNC();
@@ -374,16 +382,19 @@ __device__ __forceinline__ void resc_sw_run(const DIndex& ix, const DOpts& o, RJ
     i64 qbA = 0, qbB = 0;
     if (jA >= 0) { const RJob& J = jobs[jA]; qlenA = REV ? J.qe + 1 : J.qlen; qbA = REV ? (i64)J.q0 - J.qe : (i64)J.q0; endA = J.score; }
     if (jB >= 0) { const RJob& J = jobs[jB]; qlenB = REV ? J.qe + 1 : J.qlen; qbB = REV ? (i64)J.q0 - J.qe : (i64)J.q0; endB = J.score; }
-    uint32_t Hp[SLEN], E[SLEN], Q[SLEN], Bc[SLEN];
+    // (r05) the query as a PROFILE: byte t of PA[j] / PB[j] = a + b if column j's base pairs with reference base t (the mate is read as its reverse complement: base v
+    // pairs with 3 - v), else 0; one v_perm_b32 per column picks both jobs' bytes for the row's two reference bases (was: one-hot AND, then a packed min)
+    uint32_t Hp[SLEN], E[SLEN], PA[SLEN], PB[SLEN], Bc[SLEN];
+    const uint32_t ab = (uint32_t)(o.a + o.b);
 #pragma unroll
     for (int j = 0; j < SLEN; ++j) {
         const int k = L * SLEN + j;
-        uint32_t q = 0, bc = 0;
-        if (k < qlenA) { const int v = seq[REV ? qbA + k : qbA - k]; q |= v < 4 ? 16u << (3 - v) : 0u; bc |= (uint32_t)(v < 4 ? o.b : 1); }
-        if (k < qlenB) { const int v = seq[REV ? qbB + k : qbB - k]; q |= (v < 4 ? 16u << (3 - v) : 0u) << 16; bc |= (uint32_t)(v < 4 ? o.b : 1) << 16; }
-        Hp[j] = 0; E[j] = 0; Q[j] = q; Bc[j] = bc;
+        uint32_t pa = 0, pb = 0, bc = 0;
+        if (k < qlenA) { const int v = seq[REV ? qbA + k : qbA - k]; pa = v < 4 ? ab << (8 * (3 - v)) : 0u; bc |= (uint32_t)(v < 4 ? o.b : 1); }
+        if (k < qlenB) { const int v = seq[REV ? qbB + k : qbB - k]; pb = v < 4 ? ab << (8 * (3 - v)) : 0u; bc |= (uint32_t)(v < 4 ? o.b : 1) << 16; }
+        Hp[j] = 0; E[j] = 0; PA[j] = pa; PB[j] = pb; Bc[j] = bc;
     }
-    const uint32_t c_ab = (uint32_t)(o.a + o.b) * 0x10001u, c_ed = (uint32_t)o.e_del * 0x10001u, c_oed = (uint32_t)(o.o_del + o.e_del) * 0x10001u;
+    const uint32_t c_ed = (uint32_t)o.e_del * 0x10001u, c_oed = (uint32_t)(o.o_del + o.e_del) * 0x10001u;
     const uint32_t c_ei = (uint32_t)o.e_ins * 0x10001u, c_oei = (uint32_t)(o.o_ins + o.e_ins) * 0x10001u;
     uint32_t pubH = 0, pubF = 0, inH = 0, brow = 0, bkey = 0, fnd = 0;
     uint32_t bestv = REV ? ((uint32_t)(endA - 1) << 8 | (uint32_t)(endB - 1) << 24) : 0u;   // REV: "greater than endsc - 1" = "reaches endsc"
@@ -394,22 +405,23 @@ __device__ __forceinline__ void resc_sw_run(const DIndex& ix, const DOpts& o, RJ
         const uint32_t fin = dpp_row_shr1(pubF), hin = dpp_row_shr1(pubH);   // lane L - 1's row s - L: its last column's H', its F_full carry
         uint32_t hd = inH;                                                   // ... and its row s - L - 1: the diagonal of this lane's first column
         inH = hin;
-        const uint32_t t1h = (uint32_t)tA[s] | (uint32_t)tB[s] << 16;
-        uint32_t fseg = 0, ffull = fin, rowkey = 0;
+        const uint32_t sel = 0x0c000c00u | (uint32_t)tA[s] | (uint32_t)tB[s] << 16;   // result bytes: PA[tA], 0, PB[tB], 0
+        // (r05) the F that carries across stripes is the stripe's own F or what came in from the left, decayed: F_full(j) = max(F_seg(j), fin - j * e_ins) — both chains apply
+        // the same max(f - e_ins, u) with saturating subtraction, which distributes over max — so the second chain is one subtraction per column, not a subtraction and a max
+        uint32_t fseg = 0, carry = fin, rowkey = 0;
 #pragma unroll
         for (int j = 0; j < SLEN; ++j) {
-            const uint32_t m = pk_min(Q[j] & t1h, c_ab);                     // a + b where the bases match
+            const uint32_t m = perm_b32(PB[j], PA[j], sel);                  // a + b where the bases match
             uint32_t hnf = pk_subs(pk_add(hd, m), Bc[j]);                    // H'(i-1,k-1) + S, floored at 0 (S = a | -b | -1 | 0 past the query)
             hnf = pk_max(hnf, E[j]);
-            const uint32_t hmain = pk_max(hnf, fseg), hfull = pk_max(hnf, ffull);
+            const uint32_t hmain = pk_max(hnf, fseg), hfull = pk_max(hmain, carry);
             rowkey = pk_max(rowkey, hmain << 8 | (uint32_t)(255 - j) * 0x10001u);   // the row's maximum and, in its low byte, the smallest column that has it
             E[j] = pk_max(pk_subs(E[j], c_ed), pk_subs(hmain, c_oed));
-            const uint32_t u = pk_subs(hnf, c_oei);
-            fseg = pk_max(pk_subs(fseg, c_ei), u);
-            ffull = pk_max(pk_subs(ffull, c_ei), u);
+            fseg = pk_max(pk_subs(fseg, c_ei), pk_subs(hnf, c_oei));
+            carry = pk_subs(carry, c_ei);
             hd = Hp[j]; Hp[j] = hfull;
         }
-        pubH = Hp[SLEN - 1]; pubF = ffull;
+        pubH = Hp[SLEN - 1]; pubF = pk_max(fseg, carry);
         // the stripe's first row that beats its maximum so far (REV: that reaches endsc; then it is locked)
         const uint32_t nb = pk_max(bestv, rowkey & 0xff00ff00u);
         const uint32_t msk = pk_subw(0u, pk_min(nb ^ bestv, 0x10001u));     // 0xffff in the halves that improved

@@ -419,7 +419,7 @@ __device__ unsigned long long lh_rfa_prof[24];
 #endif
 #ifndef LH_RFA_WAVES
 #ifdef LH_RA_HIST
-__device__ unsigned long long lh_rfa_hist[34];
+__device__ unsigned long long lh_rfa_hist[40];
 #endif
 #define LH_RFA_WAVES 4   // waves per SIMD the register budget is sized for (128 VGPRs + 64 spilled: the kernel waits on memory, 4 waves hide more of it than 2 waves of 190 registers)
 #endif
@@ -1007,6 +1007,8 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             atomicAdd(&lh_rfa_hist[b_], 1ull);
             atomicMax(&lh_rfa_hist[32], dt_);
             atomicAdd(&lh_rfa_hist[33], dt_);
+            atomicAdd(&lh_rfa_hist[34], (unsigned long long)NC); atomicAdd(&lh_rfa_hist[35], (unsigned long long)NCf); atomicAdd(&lh_rfa_hist[36], (unsigned long long)M);
+            atomicAdd(&lh_rfa_hist[37], (unsigned long long)so); atomicAdd(&lh_rfa_hist[38], (unsigned long long)M * (unsigned long long)nR);
         }
 #endif
     }
