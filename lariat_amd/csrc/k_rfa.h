@@ -182,6 +182,9 @@ __device__ __forceinline__ int dev_mol_active(int alen, int nbest, int change) {
 static_assert(LH_RFA_LDS_BYTES >= 15 * 64 * (int)sizeof(double), "estimateMapQualities keeps a read's top-15 scores per lane in lds_raw (top[k * 64 + lane])");
 #define LH_RFA_NCONT_LDS 1024  // contig slots of a barcode kept in LDS while grouping (index with more contigs: slab copy)
 #define LH_RFA_SRC_CHUNK 256   // source-molecule alignments staged per pass of fastScore
+#ifndef LH_RFA_MOL_LDS_MIN
+#define LH_RFA_MOL_LDS_MIN 24   // entries of a raw molecule from which on markBest's first step scans the molecule from LDS (up to LH_RFA_LDS_BYTES / 24 entries)
+#endif
 
 // fastScore(source, sink) (lariat.go:1179-1307), evaluated by the whole wave: lane L scores sink `snk` (< 0: idle lane).
 // Everything that depends on the source alone (the read, whether its mate is active in the source and pairs with it,
@@ -603,6 +606,34 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             for (int k = 0; k < ncont; ++k) {
                 const int b0 = T.coff[k], n = T.coff[k + 1] - b0;
                 if (n < 2) continue;
+                if (n > LH_RFA_SORT_LDS && n <= LH_RFA_LDS_BYTES / 4) {
+                    // (r05) up to three times the buffer's usual length when the keys are taken relative to the contig's smallest position, 32 bits each, and the list itself
+                    // stays in memory (ranked into molraw, free until inferMolecules, and copied back): on configs[4]'s input the large contigs hold 800 - 1,500 of a
+                    // 100-pair barcode's 11,600 candidates, and their sorts in memory were a third of the kernel
+                    i64 mn = 0x7fffffffffffffffll, mx = -0x7fffffffffffffffll;
+                    for (int i = lane; i < n; i += 64) { const i64 x = R.pos[c_lo + pl[b0 + i]]; mn = mn < x ? mn : x; mx = mx > x ? mx : x; }
+                    mn = wave_min_i64(mn); mx = wave_max_i64(mx);
+                    if (mx - mn < 0xffffffffll) {
+                        uint32_t* const k32 = (uint32_t*)lds_raw;
+                        WAVE_SYNC();   // the previous contig's keys have been read
+                        for (int i = lane; i < n; i += 64) k32[i] = (uint32_t)(R.pos[c_lo + pl[b0 + i]] - mn);
+                        WAVE_SYNC();
+                        int tie = 0;
+                        for (int e = lane; e < n; e += 64) {
+                            const uint32_t key = k32[e];
+                            int rank = 0;
+                            for (int j = 0; j < n; ++j) { const uint32_t kj = k32[j]; rank += kj < key; tie |= (kj == key) & (j != e); }
+                            T.molraw[b0 + rank] = pl[b0 + e];
+                        }
+                        const int tied = __any(tie);
+                        WAVE_SYNC();
+                        if (!tied) {
+                            for (int e = lane; e < n; e += 64) pl[b0 + e] = T.molraw[b0 + e];
+                            WAVE_SYNC();
+                            continue;
+                        }
+                    }
+                }
                 if (n > LH_RFA_SORT_LDS) {
                     for (int i = lane; i < n; i += 64) kpg[b0 + i] = R.pos[c_lo + pl[b0 + i]];
                     WAVE_SYNC();
@@ -651,6 +682,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 int mi = Mraw + __popcll(mk & ((2ull << lane) - 1)) - 1;
                 if (i < NCf) {
                     T.molraw[i] = mi; T.molc[a] = mi; T.ppos[a] = i; T.rdl[i] = S.cand_read[c_lo + a] - r0;
+                    T.firstf[i] = -1;   // (not looked at yet: the large molecules' entries are, below, before the others)
                     if (st) T.mstart[mi] = i;
                 }
                 Mraw += __popcll(mk);
@@ -659,10 +691,72 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             WAVE_SYNC();
             // ---- markBestAlignmentForReadInMolecule, step 1: best pair score of every entry inside its molecule; the
             // entry's read is counted once per molecule (its first occurrence); molecules with an active alignment ----
+            // (r05) LARGE raw molecules first, from LDS.  On repeat families a read pair has a hundred alignments each within one 50-kb neighbourhood: one raw molecule of
+            // several hundred entries, in which every entry of the read is scored against every entry of its mate — n_a x n_m evaluations of ten scattered fields each,
+            // half of this kernel's time.  The molecule's entries (position, contig, strand, read, the four counts the score is made of: 24 B) are staged once and every
+            // lane scans them for ITS entry: the same set of mate entries, the same expression evaluated in the same order per pair (lariat.go:599-624 with lmp = 0: adding
+            // 0.0 to a sum that cannot be -0.0 is left out), the maximum of the same values; "first" = no earlier entry of the read in the molecule, as below.
+            {
+                struct MEnt { i64 pos; int32_t rid; uint32_t rd; int16_t mm, id, sc, scl; };
+                static_assert(sizeof(MEnt) == 24, "24 bytes per staged entry");
+                MEnt* const me = (MEnt*)lds_raw;
+                constexpr int ME_CAP = LH_RFA_LDS_BYTES / 24;
+                for (int mb = 0; mb < Mraw; mb += 64) {
+                    const int mr = mb + lane;
+                    int big = 0;
+                    if (mr < Mraw) { const int sz = T.mstart[mr + 1] - T.mstart[mr]; big = sz > LH_RFA_MOL_LDS_MIN && sz <= ME_CAP; }
+                    u64 bmk = __ballot(big);
+                    while (bmk) {
+                        const int mr2 = mb + __ffsll((unsigned long long)bmk) - 1;
+                        bmk &= bmk - 1;
+                        const int ms0 = T.mstart[mr2], msz = T.mstart[mr2 + 1] - ms0;
+                        WAVE_SYNC();   // the previous molecule's entries have been read
+                        for (int j = lane; j < msz; j += 64) {
+                            const i64 ca = c_lo + T.plist[ms0 + j];
+                            MEnt e;
+                            e.pos = R.pos[ca]; e.rid = R.rid[ca]; e.rd = (uint32_t)T.rdl[ms0 + j] | (uint32_t)(R.reversed[ca] != 0) << 31;
+                            e.mm = (int16_t)R.mismatches[ca]; e.id = (int16_t)R.indels[ca]; e.sc = (int16_t)R.soft_clipped[ca]; e.scl = (int16_t)R.soft_clipped_length[ca];
+                            me[j] = e;
+                        }
+                        WAVE_SYNC();
+                        for (int e0 = 0; e0 < msz; e0 += 64) {
+                            const int e = e0 + lane;
+                            if (e < msz) {
+                                const MEnt A = me[e];
+                                const int lr = (int)(A.rd & 0x7fffffffu), lrm = lr ^ 1, arev = (int)(A.rd >> 31);
+                                double best = -1.7976931348623157e308;
+                                int found = 0, first = 1;
+                                for (int j = 0; j < msz; ++j) {
+                                    const MEnt B = me[j];
+                                    const int lj = (int)(B.rd & 0x7fffffffu);
+                                    if (lj == lrm) {
+                                        found = 1;
+                                        double score = 0.0;
+                                        score += (double)(A.mm * -2 + A.id * -3);
+                                        if (A.sc > 0) { score -= 5.0 * (double)A.sc; score -= (double)A.scl * 0.5; }
+                                        score += (double)(B.mm * -2 + B.id * -3);
+                                        if (B.sc > 0) { score -= 5.0 * (double)B.sc; score -= (double)B.scl * 0.5; }
+                                        int pr = 0;
+                                        if (arev != (int)(B.rd >> 31) && A.rid == B.rid) { const i64 dist = arev ? A.pos - B.pos : B.pos - A.pos; pr = dist >= -35 && dist < 750; }
+                                        if (!pr) score += improper;
+                                        if (score > best) best = score;
+                                    } else if (lj == lr && j < e) first = 0;
+                                }
+                                const int i = ms0 + e;
+                                T.sval[i] = found ? best : R.lap[c_lo + T.plist[i]];
+                                T.firstf[i] = first;
+                            }
+                        }
+                    }
+                }
+                WAVE_SYNC();
+            }
             int nfirst = 0, nactive = 0;
             for (int base = 0; base < NCf; base += 64) {
                 int i = base + lane, first = 0, isact = 0;
-                if (i < NCf) {
+                const int pre = i < NCf ? T.firstf[i] : -1;
+                if (i < NCf && pre >= 0) { first = pre; isact = S.active[c_lo + T.plist[i]] != 0; }
+                else if (i < NCf) {
                     int a = T.plist[i], m = T.molraw[i];
                     int g = r0 + T.rdl[i], gm = g ^ 1;
                     double best = -1.7976931348623157e308;
@@ -683,14 +777,29 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                             } else if (lj == lr && j < i) first = 0;
                         }
                     } else {
-                        for (i64 b = R.cand_off[gm]; b < R.cand_off[gm + 1]; ++b) {
-                            if (T.molc[b - c_lo] != m) continue;
-                            found = 1;
-                            double s = dev_score_aln(R, S, improper, c_lo + a, b, 0.0);
-                            if (s > best) best = s;
+                        // (r05) four candidates' molecule numbers are fetched before any is looked at: the loop is a chain of dependent reads from the slab otherwise —
+                        // on repeat families 65 of them per entry and mate, a third of the kernel; the candidates are still taken in order (the maximum is the first of equals)
+                        const i64 mb0 = R.cand_off[gm], mb1 = R.cand_off[gm + 1];
+                        for (i64 b = mb0; b < mb1; b += 4) {
+                            int mm[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) mm[u] = b + u < mb1 ? T.molc[b + u - c_lo] : -2;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (mm[u] != m) continue;
+                                found = 1;
+                                double s = dev_score_aln(R, S, improper, c_lo + a, b + u, 0.0);
+                                if (s > best) best = s;
+                            }
                         }
-                        for (i64 b = R.cand_off[g]; b < R.cand_off[g + 1]; ++b)
-                            if (T.molc[b - c_lo] == m && T.ppos[b - c_lo] < i) first = 0;
+                        const i64 ob0 = R.cand_off[g], ob1 = R.cand_off[g + 1];
+                        for (i64 b = ob0; b < ob1; b += 4) {
+                            int mm[4], pp[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int ok = b + u < ob1; mm[u] = ok ? T.molc[b + u - c_lo] : -2; pp[u] = ok ? T.ppos[b + u - c_lo] : 0x7fffffff; }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (mm[u] == m && pp[u] < i) first = 0;
+                        }
                     }
                     T.sval[i] = found ? best : R.lap[c_lo + a];
                     T.firstf[i] = first;
