@@ -423,6 +423,7 @@ __device__ unsigned long long lh_rfa_prof[24];
 #ifndef LH_RFA_WAVES
 #ifdef LH_RA_HIST
 __device__ unsigned long long lh_rfa_hist[40];
+__device__ unsigned long long lh_rfa_hist2[8];   // position sort: contig lists, the longest, those beyond the LDS buffer's usual / 32-bit-key length, sum of squares, lists with a tie
 #endif
 #define LH_RFA_WAVES 4   // waves per SIMD the register budget is sized for (128 VGPRs + 64 spilled: the kernel waits on memory, 4 waves hide more of it than 2 waves of 190 registers)
 #endif
@@ -605,6 +606,9 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             int32_t* const pl = T.plist;
             for (int k = 0; k < ncont; ++k) {
                 const int b0 = T.coff[k], n = T.coff[k + 1] - b0;
+#ifdef LH_RA_HIST
+                if (lane == 0) { atomicAdd(&lh_rfa_hist2[0], 1ull); atomicMax(&lh_rfa_hist2[1], (unsigned long long)n); if (n > LH_RFA_SORT_LDS) atomicAdd(&lh_rfa_hist2[2], 1ull); if (n > LH_RFA_LDS_BYTES / 4) atomicAdd(&lh_rfa_hist2[3], 1ull); atomicAdd(&lh_rfa_hist2[4], (unsigned long long)n * n); }
+#endif
                 if (n < 2) continue;
                 if (n > LH_RFA_SORT_LDS && n <= LH_RFA_LDS_BYTES / 4) {
                     // (r05) up to three times the buffer's usual length when the keys are taken relative to the contig's smallest position, 32 bits each, and the list itself
@@ -626,6 +630,9 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                             T.molraw[b0 + rank] = pl[b0 + e];
                         }
                         const int tied = __any(tie);
+#ifdef LH_RA_HIST
+                        if (tied && lane == 0) atomicAdd(&lh_rfa_hist2[5], 1ull);
+#endif
                         WAVE_SYNC();
                         if (!tied) {
                             for (int e = lane; e < n; e += 64) pl[b0 + e] = T.molraw[b0 + e];
@@ -653,10 +660,16 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     pl[b0 + rank] = sidx[e];
                 }
                 if (__any(tie)) {
+                    // (r05: two reads drawn on one 300-bp family at the same offset have equal positions on EVERY copy — most of a repeat barcode's larger contigs have a tie.
+                    // Go's algorithm then, with the ranges of its quickSort spread over the lanes, on the keys in LDS; it was one lane's)
+#ifdef LH_RA_HIST
+                    if (lane == 0) atomicAdd(&lh_rfa_hist2[5], 1ull);
+#endif
                     WAVE_SYNC();
-                    if (lane == 0)
-                        dev_gosort(n, [&](int i, int j) { return spos[i] < spos[j]; },
-                                   [&](int i, int j) { i64 t = spos[i]; spos[i] = spos[j]; spos[j] = t; int u = sidx[i]; sidx[i] = sidx[j]; sidx[j] = u; }, T.gstk + lane, 64);
+                    if (lane == 0) { shi[6] = 0; shi[7] = n; }
+                    WAVE_SYNC();
+                    wave_gosort(1, shi + 6, [&](int i, int j) { return spos[i] < spos[j]; },
+                                [&](int i, int j) { i64 t = spos[i]; spos[i] = spos[j]; spos[j] = t; int u = sidx[i]; sidx[i] = sidx[j]; sidx[j] = u; }, T.molraw, T.rdl, T.firstf);
                     WAVE_SYNC();
                     for (int e = lane; e < n; e += 64) pl[b0 + e] = sidx[e];
                 }
@@ -700,51 +713,62 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 struct MEnt { i64 pos; int32_t rid; uint32_t rd; int16_t mm, id, sc, scl; };
                 static_assert(sizeof(MEnt) == 24, "24 bytes per staged entry");
                 MEnt* const me = (MEnt*)lds_raw;
+#ifdef LH_RFA_ME_CAP   // (test builds: tiles short enough for the suite's molecules to need several)
+                constexpr int ME_CAP = LH_RFA_ME_CAP < LH_RFA_LDS_BYTES / 24 ? LH_RFA_ME_CAP : LH_RFA_LDS_BYTES / 24;
+#else
                 constexpr int ME_CAP = LH_RFA_LDS_BYTES / 24;
+#endif
+                auto load_ent = [&](int i) {
+                    const i64 ca = c_lo + T.plist[i];
+                    MEnt e;
+                    e.pos = R.pos[ca]; e.rid = R.rid[ca]; e.rd = (uint32_t)T.rdl[i] | (uint32_t)(R.reversed[ca] != 0) << 31;
+                    e.mm = (int16_t)R.mismatches[ca]; e.id = (int16_t)R.indels[ca]; e.sc = (int16_t)R.soft_clipped[ca]; e.scl = (int16_t)R.soft_clipped_length[ca];
+                    return e;
+                };
                 for (int mb = 0; mb < Mraw; mb += 64) {
                     const int mr = mb + lane;
                     int big = 0;
-                    if (mr < Mraw) { const int sz = T.mstart[mr + 1] - T.mstart[mr]; big = sz > LH_RFA_MOL_LDS_MIN && sz <= ME_CAP; }
+                    if (mr < Mraw) big = T.mstart[mr + 1] - T.mstart[mr] > LH_RFA_MOL_LDS_MIN;
                     u64 bmk = __ballot(big);
                     while (bmk) {
                         const int mr2 = mb + __ffsll((unsigned long long)bmk) - 1;
                         bmk &= bmk - 1;
                         const int ms0 = T.mstart[mr2], msz = T.mstart[mr2 + 1] - ms0;
-                        WAVE_SYNC();   // the previous molecule's entries have been read
-                        for (int j = lane; j < msz; j += 64) {
-                            const i64 ca = c_lo + T.plist[ms0 + j];
-                            MEnt e;
-                            e.pos = R.pos[ca]; e.rid = R.rid[ca]; e.rd = (uint32_t)T.rdl[ms0 + j] | (uint32_t)(R.reversed[ca] != 0) << 31;
-                            e.mm = (int16_t)R.mismatches[ca]; e.id = (int16_t)R.indels[ca]; e.sc = (int16_t)R.soft_clipped[ca]; e.scl = (int16_t)R.soft_clipped_length[ca];
-                            me[j] = e;
-                        }
-                        WAVE_SYNC();
-                        for (int e0 = 0; e0 < msz; e0 += 64) {
-                            const int e = e0 + lane;
-                            if (e < msz) {
-                                const MEnt A = me[e];
-                                const int lr = (int)(A.rd & 0x7fffffffu), lrm = lr ^ 1, arev = (int)(A.rd >> 31);
-                                double best = -1.7976931348623157e308;
-                                int found = 0, first = 1;
-                                for (int j = 0; j < msz; ++j) {
-                                    const MEnt B = me[j];
-                                    const int lj = (int)(B.rd & 0x7fffffffu);
-                                    if (lj == lrm) {
-                                        found = 1;
-                                        double score = 0.0;
-                                        score += (double)(A.mm * -2 + A.id * -3);
-                                        if (A.sc > 0) { score -= 5.0 * (double)A.sc; score -= (double)A.scl * 0.5; }
-                                        score += (double)(B.mm * -2 + B.id * -3);
-                                        if (B.sc > 0) { score -= 5.0 * (double)B.sc; score -= (double)B.scl * 0.5; }
-                                        int pr = 0;
-                                        if (arev != (int)(B.rd >> 31) && A.rid == B.rid) { const i64 dist = arev ? A.pos - B.pos : B.pos - A.pos; pr = dist >= -35 && dist < 750; }
-                                        if (!pr) score += improper;
-                                        if (score > best) best = score;
-                                    } else if (lj == lr && j < e) first = 0;
+                        // a molecule longer than the buffer goes through it in tiles: every entry keeps its maximum so far in sval, "a mate's entry seen" in psum (free until
+                        // the counting below) and "first" in firstf
+                        for (int t0 = 0; t0 < msz; t0 += ME_CAP) {
+                            const int tn = msz - t0 < ME_CAP ? msz - t0 : ME_CAP;
+                            WAVE_SYNC();   // the previous tile's entries have been read
+                            for (int j = lane; j < tn; j += 64) me[j] = load_ent(ms0 + t0 + j);
+                            WAVE_SYNC();
+                            for (int e0 = 0; e0 < msz; e0 += 64) {
+                                const int e = e0 + lane;
+                                if (e < msz) {
+                                    const int i = ms0 + e;
+                                    const MEnt A = (e >= t0 && e < t0 + tn) ? me[e - t0] : load_ent(i);
+                                    const int lr = (int)(A.rd & 0x7fffffffu), lrm = lr ^ 1, arev = (int)(A.rd >> 31);
+                                    double best = -1.7976931348623157e308;
+                                    int found = 0, first = 1;
+                                    if (t0 > 0) { best = T.sval[i]; found = T.psum[i]; first = T.firstf[i]; }
+                                    for (int j = 0; j < tn; ++j) {
+                                        const MEnt B = me[j];
+                                        const int lj = (int)(B.rd & 0x7fffffffu);
+                                        if (lj == lrm) {
+                                            found = 1;
+                                            double score = 0.0;
+                                            score += (double)(A.mm * -2 + A.id * -3);
+                                            if (A.sc > 0) { score -= 5.0 * (double)A.sc; score -= (double)A.scl * 0.5; }
+                                            score += (double)(B.mm * -2 + B.id * -3);
+                                            if (B.sc > 0) { score -= 5.0 * (double)B.sc; score -= (double)B.scl * 0.5; }
+                                            int pr = 0;
+                                            if (arev != (int)(B.rd >> 31) && A.rid == B.rid) { const i64 dist = arev ? A.pos - B.pos : B.pos - A.pos; pr = dist >= -35 && dist < 750; }
+                                            if (!pr) score += improper;
+                                            if (score > best) best = score;
+                                        } else if (lj == lr && t0 + j < e) first = 0;
+                                    }
+                                    if (t0 + tn >= msz) { T.sval[i] = found ? best : R.lap[c_lo + T.plist[i]]; T.firstf[i] = first; }
+                                    else { T.sval[i] = best; T.psum[i] = found; T.firstf[i] = first; }
                                 }
-                                const int i = ms0 + e;
-                                T.sval[i] = found ? best : R.lap[c_lo + T.plist[i]];
-                                T.firstf[i] = first;
                             }
                         }
                     }
