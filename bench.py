@@ -723,6 +723,7 @@ def _c4_leg(lib, a, opts, steps, g, idx, n_bc, frac, t_setup, rank=0, dist=None,
         out = {"value": round(world * steps * n_pairs / dt, 1), "unit": "read-pairs/s", "n_gpus": world, "steps": steps, "pairs_per_step": n_pairs, "barcodes_per_step": n_bc,
                "repeat_pair_frac": frac, "ms_per_step": round(dt / steps * 1e3, 3),
                "kernel_ms": {k: round(sum(v) / len(v), 3) for k, v in kern.items()},
+               "kernel_ms_by_step": {k: [round(x, 1) for x in v] for k, v in kern.items() if max(v) >= 20.0},   # (the steps align different read sets)
                "candidates_per_read": {"mean": round(float(nc.mean()), 2), "median": int(np.median(nc)), "p99": int(np.percentile(nc, 99)), "max": int(nc.max())},
                "per_pair": {"rescue_attempts": round(cnt["n_rescue"] / n_pairs, 2), "rescue_cells": round(cnt["rescue_cells"] / n_pairs), "extension_cells": round(cnt["ext_cells"] / n_pairs),
                             "global_cells": round(cnt["glob_cells"] / n_pairs), "bwt_extend": round(cnt["n_ext"] / n_pairs)},

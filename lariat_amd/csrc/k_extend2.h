@@ -725,7 +725,9 @@ __global__ void __launch_bounds__(256) k_ext_flush(const int32_t* __restrict__ c
     for (int g = (int)(blockIdx.x * blockDim.x + threadIdx.x); g < n; g += (int)(gridDim.x * blockDim.x)) atomicOr(&A.rflag[A.u_read[list[g]]], 1);
 }
 // per read of the long list: the check of what its units assumed, then the regions moved together in chain order (or the read listed for k_extend)
-#define LH_EXT_MERGE_CAP 512
+#ifndef LH_EXT_MERGE_CAP
+#define LH_EXT_MERGE_CAP 512   // regions of a read copied to LDS for the check (the rest is read from the scratch records; tests build with 6)
+#endif
 struct ExtMReg { i64 rb, re; int32_t qb, qe, seedlen0, w; };
 __global__ void __launch_bounds__(64) k_ext_merge(DOpts o, const int32_t* __restrict__ long_list, const int32_t* __restrict__ long_count, ExtArgs A, DReg* __restrict__ tmp,
                                                    int32_t* __restrict__ defer_count, int32_t* __restrict__ defer_list, int32_t* __restrict__ why) {   // why[0..2] (diagnostics): reads handed on because a unit flagged them / too many regions / the check failed
@@ -751,13 +753,17 @@ __global__ void __launch_bounds__(64) k_ext_merge(DOpts o, const int32_t* __rest
                 const int incl = wave_scan_add_i32(m);
                 const int off = total + incl - m;
                 total += wave_readlane(incl, 63);
-                if (total > LH_EXT_MERGE_CAP) { bad = 1; reason = 1; break; }
+                // (r05) a read with more regions than the LDS copy holds — 1 or 2 reads of some 400 k-pair batches on repeat copies — used to be left to the wave-per-read
+                // kernel, ONE wave extending its 600 chains one after the other: 70 ms at the end of K4 in the batches that have such a read.  The test below reads the
+                // regions beyond the LDS copy from the scratch records instead
                 for (int j = 0; j < m; ++j) {
                     const DReg p = av[ss + j];
                     tv[off + j] = p;
-                    ExtMReg e;
-                    e.rb = p.rb; e.re = p.re; e.qb = p.qb; e.qe = p.qe; e.seedlen0 = p.seedlen0; e.w = p.w;
-                    P[off + j] = e;
+                    if (off + j < LH_EXT_MERGE_CAP) {
+                        ExtMReg e;
+                        e.rb = p.rb; e.re = p.re; e.qb = p.qb; e.qe = p.qe; e.seedlen0 = p.seedlen0; e.w = p.w;
+                        P[off + j] = e;
+                    }
                 }
             }
         }
@@ -779,7 +785,9 @@ __global__ void __launch_bounds__(64) k_ext_merge(DOpts o, const int32_t* __rest
                         if (!done[i]) continue;   // skipped inside its own chain: skipped by the sequential program as well
                         const DSeed s = sd[i];
                         for (int j = 0; j < off; ++j) {
-                            const ExtMReg p = P[j];
+                            ExtMReg p;
+                            if (j < LH_EXT_MERGE_CAP) p = P[j];
+                            else { const DReg& g = tv[j]; p.rb = g.rb; p.re = g.re; p.qb = g.qb; p.qe = g.qe; p.seedlen0 = g.seedlen0; p.w = g.w; }
                             if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;   // not fully contained
                             if (s.len - p.seedlen0 > .1 * l_query) continue;
                             int qd = s.qbeg - p.qb; i64 rd = s.rbeg - p.rb;

@@ -866,13 +866,28 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     int mr = T.molraw[i], g = r0 + T.rdl[i];
                     double best = -1.7976931348623157e308;
                     int bi = -1, bpos = 0x7fffffff, apos = -1;
-                    for (i64 b = R.cand_off[g]; b < R.cand_off[g + 1]; ++b) {
-                        int lb = (int)(b - c_lo);
-                        if (T.molc[lb] != mr) continue;
-                        int j = T.ppos[lb];
-                        double sv = T.sval[j];
-                        if (sv > best || (sv == best && j < bpos)) { best = sv; bi = lb; bpos = j; }
-                        if (S.active[b] && j > apos) { apos = j; act = lb; }
+                    // (four candidates' molecule numbers, places and flags are fetched before any is looked at, then the values of those that are in the molecule: the loop
+                    // was a chain of dependent reads per candidate; the candidates are still taken in order)
+                    const i64 cb0 = R.cand_off[g], cb1 = R.cand_off[g + 1];
+                    for (i64 b4 = cb0; b4 < cb1; b4 += 4) {
+                        int mm[4], pj[4], ac[4];
+                        double sv4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int ok = b4 + u < cb1;
+                            const int lb = (int)(b4 + u - c_lo);
+                            mm[u] = ok ? T.molc[lb] : -2; pj[u] = ok ? T.ppos[lb] : 0; ac[u] = ok ? (int)S.active[b4 + u] : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) sv4[u] = mm[u] == mr ? T.sval[pj[u]] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (mm[u] != mr) continue;
+                            const int lb = (int)(b4 + u - c_lo), j = pj[u];
+                            const double sv = sv4[u];
+                            if (sv > best || (sv == best && j < bpos)) { best = sv; bi = lb; bpos = j; }
+                            if (ac[u] && j > apos) { apos = j; act = lb; }
+                        }
                     }
                     T.bestT[(size_t)T.rdl[i] * M + m] = bi;
                 }
