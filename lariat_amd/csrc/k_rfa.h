@@ -423,7 +423,8 @@ __device__ unsigned long long lh_rfa_prof[24];
 #ifndef LH_RFA_WAVES
 #ifdef LH_RA_HIST
 __device__ unsigned long long lh_rfa_hist[40];
-__device__ unsigned long long lh_rfa_hist2[8];   // position sort: contig lists, the longest, those beyond the LDS buffer's usual / 32-bit-key length, sum of squares, lists with a tie
+__device__ unsigned long long lh_rfa_hist2[8];
+__device__ int lh_rfa_bcstat[4096][8];   // per barcode (index mod 4096): 10 ns ticks, candidates, filtered, raw molecules, largest raw molecule, contigs, molecules, largest contig list   // position sort: contig lists, the longest, those beyond the LDS buffer's usual / 32-bit-key length, sum of squares, lists with a tie
 #endif
 #define LH_RFA_WAVES 4   // waves per SIMD the register budget is sized for (128 VGPRs + 64 spilled: the kernel waits on memory, 4 waves hide more of it than 2 waves of 190 registers)
 #endif
@@ -702,6 +703,17 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             if (lane == 0) T.mstart[Mraw] = NCf;
             WAVE_SYNC();
+#ifdef LH_RA_HIST
+            {
+                int mxs = 0;
+                for (int q = lane; q < Mraw; q += 64) { const int z = T.mstart[q + 1] - T.mstart[q]; mxs = mxs > z ? mxs : z; }
+                mxs = wave_max_i32(mxs);
+                int mxc = 0;
+                for (int q = lane; q < ncont; q += 64) { const int z = T.coff[q + 1] - T.coff[q]; mxc = mxc > z ? mxc : z; }
+                mxc = wave_max_i32(mxc);
+                if (lane == 0) { lh_rfa_bcstat[bc & 4095][3] = Mraw; lh_rfa_bcstat[bc & 4095][4] = mxs; lh_rfa_bcstat[bc & 4095][7] = mxc; }
+            }
+#endif
             // ---- markBestAlignmentForReadInMolecule, step 1: best pair score of every entry inside its molecule; the
             // entry's read is counted once per molecule (its first occurrence); molecules with an active alignment ----
             // (r05) LARGE raw molecules first, from LDS.  On repeat families a read pair has a hundred alignments each within one 50-kb neighbourhood: one raw molecule of
@@ -1157,6 +1169,8 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             atomicAdd(&lh_rfa_hist[33], dt_);
             atomicAdd(&lh_rfa_hist[34], (unsigned long long)NC); atomicAdd(&lh_rfa_hist[35], (unsigned long long)NCf); atomicAdd(&lh_rfa_hist[36], (unsigned long long)M);
             atomicAdd(&lh_rfa_hist[37], (unsigned long long)so); atomicAdd(&lh_rfa_hist[38], (unsigned long long)M * (unsigned long long)nR);
+            int* st_ = lh_rfa_bcstat[bc & 4095];
+            st_[0] = (int)dt_; st_[1] = NC; st_[2] = NCf; st_[5] = ncont; st_[6] = M;
         }
 #endif
     }
