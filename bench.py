@@ -730,7 +730,7 @@ def _c4_leg(lib, a, opts, steps, g, idx, n_bc, frac, t_setup, rank=0, dist=None,
                "molecules_per_barcode": {"mean": round(float(mol.mean()), 1), "max": int(mol.max())},
                "n_rescue": cnt["n_rescue"], "rescue_cells": cnt["rescue_cells"], "rescue_cells_exec": cnt.get("rescue_cells_exec"),
                # rescue_cells = the cells ksw_align2 evaluates in the reference (equal to the oracle's count); the stage's rate in those cells, and the stage against the VALU
-               # issue rate of the ksw_u8 recurrence (9.25 packed-16 lane-instructions per cell, 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz) — for the WHOLE K6 bracket
+               # issue rate of the ksw_u8 recurrence (9.25 packed-16 lane-instructions per cell in the model; the SQ counters give 9.5 for the two Smith-Waterman kernels: profiles/r05_pmc_repeats.json; 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz) — for the WHOLE K6 bracket
                # (enumeration, Smith-Waterman launches, replay); the Smith-Waterman launches alone: profiles/r05_*_repeats_*.csv
                "rescue_GCUPS": round(cnt["rescue_cells"] / k6 / 1e9, 1),
                "rescue_stage_valu_frac": round(cnt["rescue_cells"] * 9.25 / k6 / (256 * 4 * 16 * 2.4e9), 3),

@@ -16,8 +16,10 @@
 // main loop (F_seg: restarted at every stripe) and reaches later stripes only through the lazy-F loop, which repairs H but not E
 // (k_rescue.h has the closed form: H_main = max(hnf, F_seg) feeds E and the row maximum, H' = max(hnf, F_full) is what the next row sees).
 // Here a job is a SYSTOLIC ARRAY of the same 16 stripes: 16 lanes, lane L works on row s - L at step s, its slen columns one after the
-// other in registers — F_seg and F_full are two running values, F_full and the diagonal H enter from lane L - 1 (one DPP row shift
-// each per step), nothing is scanned and nothing goes through LDS but the target base.  All cells are 16-bit halves of packed words
+// other in registers — F_seg is a running value, F_full is F_seg or the carry that entered from lane L - 1, decayed by e_ins per column (r05: saturating
+// subtraction distributes over max), the carry and the diagonal H enter by one DPP row shift each per step, nothing is scanned and nothing goes through LDS
+// but the row's reference base, stored as the byte selector with which one v_perm_b32 per column picks the match score from the query's profile.
+// (Measured and dropped, r05: the reverse passes bucketed by score class as well as by striping, so that a wave's eight jobs stop at about the same row: no change.)  All cells are 16-bit halves of packed words
 // (v_pk_max_u16, v_pk_sub_u16 clamp = the saturating arithmetic of the SSE code): a lane carries TWO jobs, a wave 8.
 // Rows before a job's first and after its last are fed a target base that matches nothing: every cell of such a row is at most the
 // value of an earlier cell, so neither "first row that beats the maximum" nor "first row that reaches endsc" can fire there.
