@@ -525,21 +525,24 @@ __global__ void __launch_bounds__(256) k_aln_flat(DIndex ix, DOpts o, i64 n_cand
 // same holds for each wider band of mem_reg2aln's retries, which therefore return Sn again and stop.  Measured: 83 % of the listed
 // candidates of the repeat-family input and 99.9 % of the headline's are settled here; the others (Sn <= U, a reference span beyond
 // LH_GRP_T, more than LH_GRP_CIG operations) are listed for k_aln, which starts them afresh.
-#define LH_GRP_W 7
+// (r05) GL = 16: four candidates per wave, band up to 7 (as r04).  GL = 32: two per wave, band up to 15 — for what the first kernel hands on: with five or more mismatches
+// Sn <= U(7) whatever the candidate looks like (U(wn) = lq - 2 (wn + 1) - 6 with the default scoring: 22 below the perfect score at wn = 7, 38 at wn = 15), a sixth of the
+// candidates on repeat families; they ran one per wave in k_aln, 43 columns of 64 lanes, as long as the other five sixths here.
 #define LH_GRP_T 176
-#define LH_GRP_Z (LH_GRP_T * (2 * LH_GRP_W + 1))
 #define LH_GRP_CIG 32
+template <int GL>
 __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
                                                  const DReg* __restrict__ regs, const int32_t* __restrict__ n_regs, DCand R, int32_t* __restrict__ status, DCounters* __restrict__ ctr,
                                                  const int32_t* __restrict__ slow_r, const int32_t* __restrict__ slow_ci, const int32_t* __restrict__ slow_count,
                                                  int32_t* __restrict__ wide_r, int32_t* __restrict__ wide_ci, int32_t* __restrict__ wide_count) {
-    __shared__ uint8_t q_[4][LH_MAXLEN + 6];
-    __shared__ uint8_t tref_[4][LH_GRP_T];
-    __shared__ uint32_t cg_[4][LH_GRP_CIG + 4];
-    __shared__ uint32_t cgo_[4][LH_GRP_CIG + 4];
-    __shared__ int32_t sh_[4][8];
-    __shared__ uint8_t z_[4][LH_GRP_Z];
-    const int lane = LANE(), g = lane >> 4, d = lane & 15;
+    constexpr int NG = 64 / GL, GRP_W = GL / 2 - 1, GRP_Z = LH_GRP_T * (2 * GRP_W + 1);
+    __shared__ uint8_t q_[NG][LH_MAXLEN + 6];
+    __shared__ uint8_t tref_[NG][LH_GRP_T];
+    __shared__ uint32_t cg_[NG][LH_GRP_CIG + 4];
+    __shared__ uint32_t cgo_[NG][LH_GRP_CIG + 4];
+    __shared__ int32_t sh_[NG][8];
+    __shared__ uint8_t z_[NG][GRP_Z];
+    const int lane = LANE(), g = lane / GL, d = lane & (GL - 1);
     uint8_t* const q = q_[g];
     uint8_t* const tref = tref_[g];
     uint32_t* const cg = cg_[g];
@@ -548,7 +551,7 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
     uint8_t* const z = z_[g];
     u64 cells = 0;   // (the group's first lane: the cells of the DPs mem_reg2aln asks for, whatever band was run)
     const int n_items = *slow_count;
-    for (int base = blockIdx.x * 4; base < n_items; base += gridDim.x * 4) {
+    for (int base = blockIdx.x * NG; base < n_items; base += gridDim.x * NG) {
         const int item = base + g;
         const int has = item < n_items;
         int r = 0, ci = 0, l_query = 0, n = 0;
@@ -564,10 +567,10 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
             c0 = R.cand_off[r];
         }
         WAVE_SYNC();
-        for (int i = d; i < l_query; i += 16) q[i] = seq[off + i];
+        for (int i = d; i < l_query; i += GL) q[i] = seq[off + i];
         int best = 0;
-        for (int i = d; i < n; i += 16) { int s = av[i].score; best = best > s ? best : s; }
-        best = grp_max_i32(best);
+        for (int i = d; i < n; i += GL) { int s = av[i].score; best = best > s ? best : s; }
+        best = grpN_max_i32<GL>(best);
         DReg ar;
         ar.rb = ar.re = 0; ar.qb = ar.qe = ar.rid = ar.score = ar.truesc = ar.w = 0;
         if (has) ar = av[ci];
@@ -583,7 +586,7 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
         const int valid = has && lq > 0 && rb < re && !(rb < ix.l_pac && re > ix.l_pac) && re - rb <= LH_GRP_T;
         int towide = has && !valid;
         if (valid)
-            for (int i = d; i < rlen; i += 16) tref[i] = (uint8_t)dev_ref_base(ix, t0 + (i64)tstep * i);
+            for (int i = d; i < rlen; i += GL) tref[i] = (uint8_t)dev_ref_base(ix, t0 + (i64)tstep * i);
         WAVE_SYNC();
         int tmp = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_del, o.e_del);
         int w2 = dev_infer_bw(lq, rlen, ar.truesc, o.a, o.o_ins, o.e_ins);
@@ -613,7 +616,7 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
                             if (end > beg) ccells += (u64)(end - beg);
                         }
                     if (!proved) {
-                        wn = w < LH_GRP_W ? w : LH_GRP_W;
+                        wn = w < GRP_W ? w : GRP_W;
                         if (wn < adq + 3) { towide = 1; act = 0; }   // (the narrow band would not reach the end cell with BWA's own margin)
                         else run = 1;
                     }
@@ -621,7 +624,7 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
             }
             const int tl_max = wave_max_i32(run ? rlen : 0);
             if (tl_max > 0) {
-                const int sc = grp_ksw_global2_band(o, q, qoff, qstep, lq, tref, rlen, wn, z, lane, run, tl_max);
+                const int sc = grp_ksw_global2_band<GL>(o, q, qoff, qstep, lq, tref, rlen, wn, z, lane, run, tl_max);
                 if (run) score = sc;
             }
             WAVE_SYNC();
@@ -672,14 +675,14 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
                 for (int k = 0; k < n_cigar; ++k) {
                     const int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
                     if (op == 0) {
-                        for (int t = d; t < len; t += 16) n_mm += q[qoff + qstep * (x + t)] != tref[y + t];
+                        for (int t = d; t < len; t += GL) n_mm += q[qoff + qstep * (x + t)] != tref[y + t];
                         x += len; y += len;
                     } else if (op == 2) {
                         if (k > 0 && k < n_cigar - 1) n_gap += len;
                         y += len;
                     } else if (op == 1) { x += len; n_gap += len; }
                 }
-            NM = grp_sum_i32(n_mm) + n_gap;
+            NM = grpN_sum_i32<GL>(n_mm) + n_gap;
         }
         int is_rev = 0;
         i64 posf = 0;
@@ -717,14 +720,14 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
             const int op = cv & 0xf, len = (int)(cv >> 4);
             const int mlen = op == 0 ? len : 0;
             const int lmax = wave_max_i32(mlen);
-            for (int t0 = 0; t0 < lmax; t0 += 16) {
+            for (int t0 = 0; t0 < lmax; t0 += GL) {
                 const int t = t0 + d, k = refSeqOffset + t;
                 int mm = 0;
                 if (t < mlen && k < refLen && readOffset + t < l_query) {
                     const int rbase = k < rlen ? tref[rev ? rlen - 1 - k : k] : 255;
                     mm = rbase != q[readOffset + t];
                 }
-                const uint32_t bm = (uint32_t)(__ballot(mm) >> (g * 16)) & 0xffffu;
+                const uint32_t bm = (uint32_t)(__ballot(mm) >> (g * GL)) & (GL == 32 ? 0xffffffffu : 0xffffu);
                 if (nmm + (int)__popc(bm) > LH_MAX_MM) towide = 1;   // (more loci than slots: k_aln knows the pool)
                 else if (mm) {
                     const int slot = nmm + (int)__popc(bm & ((1u << d) - 1u));
@@ -739,7 +742,7 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
         }
         if (fin && !towide) {
             cells += ccells;
-            for (int k = d; k < no; k += 16) R.cigar[(size_t)c * LH_MAX_CIGAR + k] = cgo[k];
+            for (int k = d; k < no; k += GL) R.cigar[(size_t)c * LH_MAX_CIGAR + k] = cgo[k];
             if (d == 0) {
                 const int rid = dev_pos2rid(ix, posf);
                 int mismatches = NM - indel_length;

@@ -190,12 +190,42 @@ __device__ __forceinline__ int grp_shl1_i32(int v, int fill) { return LH_DPP(fil
 __device__ __forceinline__ int grp_max_i32(int v) { for (int m = 8; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v > o ? v : o; } return v; }
 __device__ __forceinline__ int grp_sum_i32(int v) { for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m); return v; }
 
+// (r05) the same for groups of 32 lanes (two candidates per wave, bands up to 2 * 15 + 1 columns): a DPP row is 16 lanes, so the scan takes the row_bcast:15 step of the
+// wave-wide scan and the shifts are the wave's with the group's edge lanes filled
+#ifdef LH_EMU
+template <int GL> __device__ __forceinline__ int grpN_scan_max_i32(int v, int lane) {
+    for (int d = 1; d < GL; d <<= 1) { int o = __shfl_up(v, d); if ((lane & (GL - 1)) >= d) v = v > o ? v : o; }
+    return v;
+}
+template <int GL> __device__ __forceinline__ int grpN_shr1_i32(int v, int fill) { int o = __shfl_up(v, 1); return (LANE() & (GL - 1)) == 0 ? fill : o; }
+template <int GL> __device__ __forceinline__ int grpN_shl1_i32(int v, int fill) { int o = __shfl_down(v, 1); return (LANE() & (GL - 1)) == GL - 1 ? fill : o; }
+#else
+template <int GL> __device__ __forceinline__ int grpN_scan_max_i32(int v, int lane) {
+    v = grp_scan_max_i32(v, lane);
+    if (GL == 32) { const int t = LH_DPP((int)0x80000000, v, 0x142, 0xA); v = v > t ? v : t; }   // lane 15 of rows 0 and 2 to rows 1 and 3
+    return v;
+}
+template <int GL> __device__ __forceinline__ int grpN_shr1_i32(int v, int fill) {
+    if (GL == 16) return grp_shr1_i32(v, fill);
+    const int t = LH_DPP(fill, v, 0x138, 0xF);   // wave_shr:1
+    return (LANE() & 31) == 0 ? fill : t;
+}
+template <int GL> __device__ __forceinline__ int grpN_shl1_i32(int v, int fill) {
+    if (GL == 16) return grp_shl1_i32(v, fill);
+    const int t = LH_DPP(fill, v, 0x130, 0xF);   // wave_shl:1
+    return (LANE() & 31) == 31 ? fill : t;
+}
+#endif
+template <int GL> __device__ __forceinline__ int grpN_max_i32(int v) { for (int m = GL / 2; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = v > o ? v : o; } return v; }
+template <int GL> __device__ __forceinline__ int grpN_sum_i32(int v) { for (int m = GL / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m); return v; }
+
+template <int GL>
 __device__ __forceinline__ int grp_ksw_global2_band(const DOpts& o, const uint8_t* qarr, int qoff, int qstep, int qlen, const uint8_t* tg, int tlen, int w, uint8_t* z, int lane,
                                                     int run, int tl_max) {
     const int a_ = o.a, b_ = o.b, o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-    const int d = lane & 15;
+    const int d = lane & (GL - 1);
     int H, E = LH_MINUS_INF, lastv = LH_MINUS_INF;
     {
         const int j = d - w;
@@ -216,8 +246,8 @@ __device__ __forceinline__ int grp_ksw_global2_band(const DOpts& o, const uint8_
             tins = mm - oe_ins;
         }
         const int bj = in ? tins + (j + 1) * e_ins : -0x7fffffff;
-        const int incl = grp_scan_max_i32(bj, lane);
-        const int excl = grp_shr1_i32(incl, -0x7fffffff);
+        const int incl = grpN_scan_max_i32<GL>(bj, lane);
+        const int excl = grpN_shr1_i32<GL>(incl, -0x7fffffff);
         const int gc = LH_MINUS_INF + beg * e_ins;
         const int G = gc > excl ? gc : excl;
         const int f = G - j * e_ins;
@@ -238,10 +268,10 @@ __device__ __forceinline__ int grp_ksw_global2_band(const DOpts& o, const uint8_
             if (j == qlen - 1) lastv = h;
         }
         H = in ? h : LH_MINUS_INF;
-        E = grp_shl1_i32(in ? enew : LH_MINUS_INF, LH_MINUS_INF);
+        E = grpN_shl1_i32<GL>(in ? enew : LH_MINUS_INF, LH_MINUS_INF);
     }
     // eh[qlen].h after the last row = H(tlen - 1, qlen - 1): the band reaches that cell (callers: w >= |qlen - tlen| + 3), lane qlen - tlen + w held it
-    return grp_max_i32(run && d == qlen - tlen + w ? lastv : (int)0x80000000);
+    return grpN_max_i32<GL>(run && d == qlen - tlen + w ? lastv : (int)0x80000000);
 }
 
 // bwa_gen_cigar2 without traceback: global score of query[qb_..qe_) against the fwd||rev reference interval [rb,re).
