@@ -131,14 +131,19 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
     }
     }
     WAVE_SYNC();   // all lanes are done reading ia[]/av[] before lane 0 compacts and re-sorts them
+    // (r05) what the scan excluded leaves the order array — 64 entries at a time, the survivors' places from a ballot; it was one lane reading every record in turn, as was the
+    // pass over identical hits below: two or three dependent reads from memory per region, a third of K5 on repeat families
     int m = 0;
-    if (lane == 0) {
-        for (int i = 0; i < n; ++i)   // exclude identical hits
-            if (av[ia[i]].qe > av[ia[i]].qb) ia[m++] = ia[i];
-        ia[n] = m;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        int id = 0, alive = 0;
+        if (i < n) { id = ia[i]; alive = av[id].qe > av[id].qb; }
+        const u64 mk = __ballot(alive);
+        WAVE_SYNC();   // every lane holds its entry before any is moved (to a place at or before its own)
+        if (alive) ia[m + lanes_below(mk, lane)] = id;
+        m += (int)__popcll(mk);
     }
     WAVE_SYNC();
-    m = ia[n];
     int pk2 = packed;
     if (packed) {   // (score desc, rb, qb) as one ascending key: the bits of the list's largest score, 33 and 8 above the index; a region outside those ranges: the comparator on the records
         int smax = 0;
@@ -164,21 +169,35 @@ __device__ __forceinline__ int wave_sort_dedup_patch(const DIndex& ix, const DOp
         }
         WAVE_SYNC();
     }
-    if (lane == 0) {
-        if (!pk2) dev_introsort(m, ia, [&](int x, int y) {
+    if (!pk2) {
+        if (lane == 0) dev_introsort(m, ia, [&](int x, int y) {
             const DReg &A = av[x], &B = av[y];
             return A.score > B.score || (A.score == B.score && (A.rb < B.rb || (A.rb == B.rb && A.qb < B.qb)));
         }, o.wd);
-        for (int i = 1; i < m; ++i)   // mark identical hits
-            if (av[ia[i]].score == av[ia[i - 1]].score && av[ia[i]].rb == av[ia[i - 1]].rb && av[ia[i]].qb == av[ia[i - 1]].qb) av[ia[i]].qe = av[ia[i]].qb;
-        int m2 = m ? 1 : 0;
-        for (int i = 1; i < m; ++i)
-            if (av[ia[i]].qe > av[ia[i]].qb) ia[m2++] = ia[i];
+        WAVE_SYNC();
+    }
+    {   // identical hits: an entry with its predecessor's (score, rb, qb) is marked and left out (the first entry stays; the comparison reads fields no mark changes)
+        int m2 = 0, carry = 0;
+        for (int c0 = 0; c0 < m; c0 += 64) {
+            const int i = c0 + lane;
+            const int id = i < m ? ia[i] : 0;
+            const int pid = wave_shr1_i32(id, carry);   // the entry before: the previous chunk's last for lane 0 (its place may have been written by now)
+            carry = wave_readlane(id, 63);
+            int keep = 0;
+            if (i < m) {
+                int dup = 0;
+                if (i > 0) { const DReg &A = av[id], &B = av[pid]; dup = A.score == B.score && A.rb == B.rb && A.qb == B.qb; }
+                if (dup) av[id].qe = av[id].qb;
+                keep = !dup;
+            }
+            const u64 mk = __ballot(keep);
+            WAVE_SYNC();
+            if (keep) ia[m2 + lanes_below(mk, lane)] = id;
+            m2 += (int)__popcll(mk);
+        }
         m = m2;
-        ia[n] = m;   // broadcast slot
     }
     WAVE_SYNC();
-    m = ia[n];
     for (int i = lane; i < m; i += 64) tmp[i] = av[ia[i]];
     WAVE_SYNC();
     for (int i = lane; i < m; i += 64) av[i] = tmp[i];
