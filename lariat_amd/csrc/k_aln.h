@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
         int act = valid;   // mem_reg2aln's loop is still running for this candidate
         for (int it = 0; it < 3; ++it) {
             if (!__any(act)) break;
-            int w = 0, run = 0;
+            int w = 0, run = 0, ccw = -1;
             if (act) {
                 w2 = w2 < o.w << 2 ? w2 : o.w << 2;
                 if (lq == rlen && w2 == 0) { towide = 1; act = 0; }   // ("no gap; no need to do DP": never listed by the kernels above; k_aln has the branch)
@@ -610,17 +610,22 @@ __global__ void __launch_bounds__(64) k_aln_grp(DIndex ix, DOpts o, const uint8_
                     w = w < w2 ? w : w2;
                     const int min_w = adq + 3;
                     w = w > min_w ? w : min_w;
-                    if (d == 0)
-                        for (int i = 0; i < rlen; ++i) {   // the cells ksw_global2 evaluates with the band it was asked for
-                            const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
-                            if (end > beg) ccells += (u64)(end - beg);
-                        }
+                    ccw = w;   // (the cells ksw_global2 evaluates with the band it was asked for: counted below, by the group)
                     if (!proved) {
                         wn = w < GRP_W ? w : GRP_W;
                         if (wn < adq + 3) { towide = 1; act = 0; }   // (the narrow band would not reach the end cell with BWA's own margin)
                         else run = 1;
                     }
                 }
+            }
+            {   // (r05: the group's lanes share the rows of the count; it was the group's first lane walking all of them, a tenth of the kernel)
+                int part = 0;
+                if (ccw >= 0)
+                    for (int i = d; i < rlen; i += GL) {
+                        const int beg = i > ccw ? i - ccw : 0, end = i + ccw + 1 < lq ? i + ccw + 1 : lq;
+                        if (end > beg) part += end - beg;
+                    }
+                ccells += (u64)grpN_sum_i32<GL>(part);
             }
             const int tl_max = wave_max_i32(run ? rlen : 0);
             if (tl_max > 0) {
