@@ -327,6 +327,13 @@ int lh_get_seq(const lh_index* idx, int32_t rid, int64_t start, int64_t end, int
 int lh_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes);
 int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, int64_t n_access, double* gbps, double* ms);
 
+/* diagnostics: the rate at which the SIMDs issue vector-ALU instructions (csrc/k_valu_rate.h) — the ceiling of K6's Smith-Waterman
+ * (gobwa.go:286-325 -> mem_matesw -> ksw_align2 in packed 16-bit cells).  op: 0..22 one opcode in eight independent chains, 100 + op the same in
+ * one dependent chain, 50 the instruction mix of k_resc_sw's column, 51 v_pk_fma_f32, 52 s_nop.  waves_per_simd 1..8 over the whole chip.
+ * out[0..9]: ms, wave-instructions, G wave-instructions/s, median shader MHz, median cycles per instruction per WAVE, cycles per instruction per
+ * SIMD chip-wide, SIMDs seen, fewest / most waves on one SIMD, lowest MHz.  LH_E_NODEVICE without a GPU (and under the emulator). */
+int lh_diag_valu_rate(int device, int32_t op, int32_t waves_per_simd, int32_t iters, double* out, int32_t n_out);
+
 /* diagnostics: self-check of a resident index with a dense suffix array, on every stride-th row: adjacent suffixes are in
  * order (direct text comparison); the stored BWT symbol is the base before the suffix and the LF-mapping through the
  * occurrence table reaches that suffix's row.  A size-independent property for indexes the oracle cannot hold. */

@@ -1,0 +1,176 @@
+// k_valu_rate.h — diagnostic microbenchmark: the rate at which gfx950's SIMDs ISSUE vector-ALU instructions, one opcode at a time and in the
+// mix of K6's Smith-Waterman (k_rescue2.h: resc_sw_run), at 1 … 8 resident waves per SIMD on the whole chip, with the shader clock sampled.
+//
+// Why it exists: k_resc_sw — ksw_u8 (gobwa.go:286-325 -> mem_matesw -> ksw_align2) in packed 16-bit cells — issues one wave64 instruction per
+// 3.9 cycles per SIMD by the SQ counters.  Whether that is the chip's ceiling for THESE opcodes (v_pk_max_u16, v_pk_sub_u16 clamp, v_pk_add_u16,
+// v_perm_b32, DPP row_shr:1, v_lshl_or_b32) or half of it is a property of the hardware that has to be measured, not read off a data sheet:
+// tools/valu_rate.py prints the table, bench.py divides K6's instruction rate by the figure measured here.
+//
+// Method.  Every wave runs `iters` trips of a loop whose body is 64 instructions of one opcode in inline assembly — eight INDEPENDENT chains of
+// eight (chains = 8: throughput) or one dependent chain of 64 (chains = 1: issue-to-issue latency of a dependent instruction) — so the compiler
+// neither removes nor reorders anything; the loop's own scalar bookkeeping is 3 SALU instructions per 64.  Blocks are 256 threads (one wave per
+// SIMD of a CU), the grid is CUs x waves_per_simd blocks.  Lane 0 of every wave records s_memtime (shader cycles) and s_memrealtime (a constant
+// 100 MHz counter) around its loop and the SIMD it ran on (HW_ID, XCC_ID): the host reports the median clock, the median cycles per instruction
+// per wave, how many waves shared a SIMD, and the chip-wide rate from HIP events.
+#pragma once
+#include "lh_dev.h"
+
+#ifndef LH_EMU
+#define VR8(F) F("%0") F("%1") F("%2") F("%3") F("%4") F("%5") F("%6") F("%7")
+#define VR64(F) VR8(F) VR8(F) VR8(F) VR8(F) VR8(F) VR8(F) VR8(F) VR8(F)
+#define VR1x8(F) F("%0") F("%0") F("%0") F("%0") F("%0") F("%0") F("%0") F("%0")
+#define VR1x64(F) VR1x8(F) VR1x8(F) VR1x8(F) VR1x8(F) VR1x8(F) VR1x8(F) VR1x8(F) VR1x8(F)
+#define VR_OPS "v"(a), "v"(b), "s"(c)
+#define VR_REGS "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+#define VR_CASE(id, F)                                                                                     \
+    case id: for (int i = 0; i < iters; ++i) asm volatile(VR64(F) : VR_REGS : VR_OPS); break;            \
+    case 100 + id: for (int i = 0; i < iters; ++i) asm volatile(VR1x64(F) : VR_REGS : VR_OPS); break;
+
+#define VRI_NOP(R) "s_nop 0\n"
+#define VRI_ADD_U32(R) "v_add_u32 " R ", " R ", %8\n"
+#define VRI_FMA_F32(R) "v_fma_f32 " R ", " R ", %8, %9\n"
+#define VRI_PK_MAX_U16(R) "v_pk_max_u16 " R ", " R ", %8\n"
+#define VRI_PK_SUBS_U16(R) "v_pk_sub_u16 " R ", " R ", %8 clamp\n"
+#define VRI_PK_ADD_U16(R) "v_pk_add_u16 " R ", " R ", %8\n"
+#define VRI_PERM(R) "v_perm_b32 " R ", " R ", %8, %9\n"
+#define VRI_DPP_SHR1(R) "s_nop 1\nv_mov_b32_dpp " R ", " R " row_shr:1 row_mask:0xf bank_mask:0xf\n"   // (the nop: VALU write -> DPP read of the same register needs 2 wait states; counted out below)
+#define VRI_LSHL_OR(R) "v_lshl_or_b32 " R ", " R ", 8, %8\n"
+#define VRI_MAX_U32(R) "v_max_u32 " R ", " R ", %8\n"
+#define VRI_MAX3_U32(R) "v_max3_u32 " R ", " R ", %8, %9\n"
+#define VRI_AND_OR(R) "v_and_or_b32 " R ", " R ", %8, %9\n"
+#define VRI_PK_MIN_U16(R) "v_pk_min_u16 " R ", " R ", %8\n"
+#define VRI_MAX_U16(R) "v_max_u16 " R ", " R ", %8\n"
+#define VRI_PK_SUBS_SGPR(R) "v_pk_sub_u16 " R ", " R ", %10 clamp\n"
+#define VRI_ADD3_U32(R) "v_add3_u32 " R ", " R ", %8, %9\n"
+#define VRI_SAD_U8(R) "v_sad_u8 " R ", " R ", %8, %9\n"
+#define VRI_PK_ADD_F16(R) "v_pk_add_f16 " R ", " R ", %8\n"
+#define VRI_ADD_F32(R) "v_add_f32 " R ", " R ", %8\n"
+#define VRI_XOR(R) "v_xor_b32 " R ", " R ", %8\n"
+#define VRI_PK_MAX_I16(R) "v_pk_max_i16 " R ", " R ", %8\n"
+#define VRI_DPP_MAX(R) "s_nop 1\nv_max_u32_dpp " R ", " R ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define VRI_SUB_SAT_U32(R) "v_sub_u32 " R ", " R ", %8 clamp\n"
+#define VRI_PK_MAD_U16(R) "v_pk_mad_u16 " R ", " R ", %8, %9\n"
+#define VRI_MAX_F32(R) "v_max_f32 " R ", " R ", %8\n"
+#define VRI_MAX3_F32(R) "v_max3_f32 " R ", " R ", %8, %9\n"
+#define VRI_MIN_U32(R) "v_min_u32 " R ", " R ", %8\n"
+#define VRI_MAX_I32(R) "v_max_i32 " R ", " R ", %8\n"
+#define VRI_CNDMASK(R) "v_cndmask_b32 " R ", " R ", %8, vcc\n"
+#define VRI_MOV(R) "v_mov_b32 " R ", %8\n"
+#define VRI_AND(R) "v_and_b32 " R ", " R ", %8\n"
+#define VRI_OR(R) "v_or_b32 " R ", " R ", %8\n"
+#define VRI_LSHLREV(R) "v_lshlrev_b32 " R ", 1, " R "\n"
+#define VRI_ADD_U16(R) "v_add_u16 " R ", " R ", %8\n"
+#define VRI_SUB_U16_CL(R) "v_sub_u16 " R ", " R ", %8 clamp\n"
+#define VRI_MAX_I16(R) "v_max_i16 " R ", " R ", %8\n"
+#define VRI_MUL_U24(R) "v_mul_u32_u24 " R ", " R ", %8\n"
+#define VRI_MAD_U24(R) "v_mad_u32_u24 " R ", " R ", %8, %9\n"
+#define VRI_BFE(R) "v_bfe_u32 " R ", " R ", 1, 31\n"
+#define VRI_SUB_F32_CL(R) "v_sub_f32 " R ", " R ", %8 clamp\n"
+#define VRI_MED3_F32(R) "v_med3_f32 " R ", " R ", %8, %9\n"
+#define VRI_OR3(R) "v_or3_b32 " R ", " R ", %8, %9\n"
+#define VRI_MAX_U16_SDWA(R) "v_max_u16_sdwa " R ", " R ", %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n"
+#define VRI_MIN_I32(R) "v_min_i32 " R ", " R ", %8\n"
+#define VRI_CMP_EQ(R) "v_cmp_eq_u32 vcc, " R ", %8\n"
+#define VRI_BFI(R) "v_bfi_b32 " R ", " R ", %8, %9\n"
+#define VRI_MAD_U16(R) "v_mad_u16 " R ", " R ", %8, %9\n"
+#define VRI_LSHL_ADD(R) "v_lshl_add_u32 " R ", " R ", 1, %8\n"
+#define VRI_MIN3_U32(R) "v_min3_u32 " R ", " R ", %8, %9\n"
+#define VRI_MAX_F16(R) "v_max_f16 " R ", " R ", %8\n"
+#define VRI_SUB_U32(R) "v_sub_u32 " R ", " R ", %8\n"
+#define VRI_MAX_U16_E64(R) "v_max_u16_e64 " R ", " R ", %10\n"
+#define VRI_FMAC_F32(R) "v_fmac_f32 " R ", %8, %9\n"
+#define VRI_CVT_UBYTE(R) "v_cvt_f32_ubyte0 " R ", " R "\n"
+// one column of resc_sw_run for a lane's two jobs, in its instruction mix and order (16 instructions: 1 perm, 1 add, 6 saturating subs, 7 max, 1 shift-or),
+// on eight registers so that — as in the kernel, where a column's chain hnf -> hmain -> hfull / E / fseg is interleaved with its neighbours' by the
+// scheduler — no instruction reads the result of the one before it; x 4 = 64 per trip
+#define VRI_MIX16                                                                                                                  \
+    "v_perm_b32 %0, %1, %2, %8\n"  "v_pk_sub_u16 %3, %3, %10 clamp\n" "v_pk_add_u16 %4, %0, %9\n"    "v_pk_sub_u16 %5, %5, %10 clamp\n"   \
+    "v_pk_sub_u16 %4, %4, %8 clamp\n" "v_pk_max_u16 %6, %6, %3\n"    "v_pk_max_u16 %4, %4, %1\n"    "v_pk_sub_u16 %7, %7, %10 clamp\n"   \
+    "v_pk_max_u16 %0, %4, %5\n"    "v_lshl_or_b32 %2, %4, 8, %9\n"   "v_pk_max_u16 %3, %0, %7\n"    "v_pk_sub_u16 %1, %0, %10 clamp\n"   \
+    "v_pk_max_u16 %6, %6, %2\n"    "v_pk_sub_u16 %2, %4, %10 clamp\n" "v_pk_max_u16 %1, %1, %5\n"   "v_pk_max_u16 %5, %2, %7\n"
+#define VRI_MIX64 VRI_MIX16 VRI_MIX16 VRI_MIX16 VRI_MIX16
+
+__global__ void __launch_bounds__(256) k_diag_valu_rate(int op, int iters, uint32_t* __restrict__ sink, unsigned long long* __restrict__ rec) {
+    const uint32_t t = threadIdx.x;
+    uint32_t r0 = t * 2654435761u + 1, r1 = r0 ^ 0x9e3779b9u, r2 = r0 * 3 + 7, r3 = r1 * 5 + 11, r4 = r2 ^ r3, r5 = r4 + 0x01010101u, r6 = r5 * 9, r7 = r6 ^ r0;
+    const uint32_t a = 0x00010001u, b = t | 0x04050607u;
+    const uint32_t c = 0x00010001u;
+    unsigned long long t0, t1, w0, w1;
+    asm volatile("s_memtime %0\ns_memrealtime %1\ns_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(w0));
+    switch (op) {
+        VR_CASE(0, VRI_ADD_U32)
+        VR_CASE(1, VRI_FMA_F32)
+        VR_CASE(2, VRI_PK_MAX_U16)
+        VR_CASE(3, VRI_PK_SUBS_U16)
+        VR_CASE(4, VRI_PK_ADD_U16)
+        VR_CASE(5, VRI_PERM)
+        VR_CASE(6, VRI_DPP_SHR1)
+        VR_CASE(7, VRI_LSHL_OR)
+        VR_CASE(8, VRI_MAX_U32)
+        VR_CASE(9, VRI_MAX3_U32)
+        VR_CASE(10, VRI_AND_OR)
+        VR_CASE(11, VRI_PK_MIN_U16)
+        VR_CASE(12, VRI_MAX_U16)
+        VR_CASE(13, VRI_PK_SUBS_SGPR)
+        VR_CASE(14, VRI_ADD3_U32)
+        VR_CASE(15, VRI_SAD_U8)
+        VR_CASE(16, VRI_PK_ADD_F16)
+        VR_CASE(17, VRI_ADD_F32)
+        VR_CASE(18, VRI_XOR)
+        VR_CASE(19, VRI_PK_MAX_I16)
+        VR_CASE(20, VRI_DPP_MAX)
+        VR_CASE(21, VRI_SUB_SAT_U32)
+        VR_CASE(22, VRI_PK_MAD_U16)
+        VR_CASE(23, VRI_MAX_F32)
+        VR_CASE(24, VRI_MAX3_F32)
+        VR_CASE(25, VRI_MIN_U32)
+        VR_CASE(26, VRI_MAX_I32)
+        VR_CASE(27, VRI_CNDMASK)
+        VR_CASE(28, VRI_MOV)
+        VR_CASE(29, VRI_AND)
+        VR_CASE(30, VRI_OR)
+        VR_CASE(31, VRI_LSHLREV)
+        VR_CASE(32, VRI_ADD_U16)
+        VR_CASE(33, VRI_SUB_U16_CL)
+        VR_CASE(34, VRI_MAX_I16)
+        VR_CASE(35, VRI_MUL_U24)
+        VR_CASE(36, VRI_MAD_U24)
+        VR_CASE(37, VRI_BFE)
+        VR_CASE(38, VRI_SUB_F32_CL)
+        VR_CASE(39, VRI_MED3_F32)
+        VR_CASE(40, VRI_OR3)
+        VR_CASE(41, VRI_MAX_U16_SDWA)
+        VR_CASE(42, VRI_MIN_I32)
+        VR_CASE(44, VRI_BFI)
+        VR_CASE(45, VRI_MAD_U16)
+        VR_CASE(46, VRI_LSHL_ADD)
+        VR_CASE(47, VRI_MIN3_U32)
+        VR_CASE(48, VRI_MAX_F16)
+        VR_CASE(49, VRI_SUB_U32)
+        VR_CASE(53, VRI_MAX_U16_E64)
+        VR_CASE(54, VRI_FMAC_F32)
+        VR_CASE(55, VRI_CVT_UBYTE)
+        case 43: for (int i = 0; i < iters; ++i) asm volatile(VR64(VRI_CMP_EQ) : VR_REGS : VR_OPS : "vcc"); break;
+        case 50: for (int i = 0; i < iters; ++i) asm volatile(VRI_MIX64 : VR_REGS : VR_OPS); break;
+        case 51: {   // packed f32 FMA (the opcode behind the data sheet's vector FP32 peak): eight chains of register pairs
+            unsigned long long q0 = r0, q1 = r1, q2 = r2, q3 = r3, q4 = r4, q5 = r5, q6 = r6, q7 = r7, qa = a, qb = b;
+#define VRI_PK_FMA_F32(R) "v_pk_fma_f32 " R ", " R ", %8, %9\n"
+            for (int i = 0; i < iters; ++i)
+                asm volatile(VR64(VRI_PK_FMA_F32) : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "v"(qa), "v"(qb));
+            r0 ^= (uint32_t)(q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7);
+            break;
+        }
+        case 52: for (int i = 0; i < iters; ++i) asm volatile(VR64(VRI_NOP) : VR_REGS : VR_OPS); break;
+        default: break;
+    }
+    asm volatile("s_memtime %0\ns_memrealtime %1\ns_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(w1));
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\ns_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+    const uint32_t x = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+    if (x == 0x12345678u) sink[0] = x;   // keeps the chains alive
+    if ((t & 63) == 0) {
+        unsigned long long* o = rec + ((size_t)blockIdx.x * 4 + (t >> 6)) * 4;
+        o[0] = t1 - t0; o[1] = w1 - w0; o[2] = (unsigned long long)hw | (unsigned long long)xcc << 32; o[3] = t0;
+    }
+}
+#endif
