@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 4
+#define LH_ABI_VERSION 5
 
 /* status codes */
 #define LH_OK 0
@@ -77,6 +77,7 @@ typedef struct lh_opts {
 #define LH_F_EXT_WAVE 16u        /* K4 wave-per-read only */
 #define LH_F_EXT_SERIAL 32u      /* K4's rounds and wave-kernel launches one after the other on one stream (per-round timings) */
 #define LH_F_P2_TASKS 128u       /* K1 pass 2: a read's re-seeding calls shared by up to four lanes whatever the previous batch looked like (default: only after a repeat-rich batch) */
+#define LH_F_RESCUE_FULL 256u     /* K6: every mate-rescue Smith-Waterman runs all rows of its window (default: the rows k_resc_cert proves sufficient, k_rescue3.h) */
 #define LH_F_CHAIN_WAVE 64u      /* K3: the reads a lane does not chain all go to the wave-per-seed kernel (k_chain), none to the cluster kernel (k_chain_cl) */
 
 /* how an index is made resident (lh_index_load / lh_index_from_arrays / lh_index_build_device); NULL = defaults */
@@ -184,6 +185,8 @@ typedef struct lh_result {
     uint64_t n_ktree_p1, n_ktree_p2, n_ktree_p3;
     /* bwt_smem1a calls of pass 1 that K1 decided from the text at the read's known locus (two PLCP bytes + the comparison; their bwt_extend calls are in neither count) */
     uint64_t n_calls_by_text;
+    /* (ABI 5) the ksw_u8 cells K6 really executed: rescue_cells counts the cells the REFERENCE evaluates for the same attempts (tlen x striped width per pass) */
+    uint64_t rescue_cells_exec;
     void* arena_; /* private */
 } lh_result;
 
@@ -328,8 +331,8 @@ int lh_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes);
 int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, int64_t n_access, double* gbps, double* ms);
 
 /* diagnostics: the rate at which the SIMDs issue vector-ALU instructions (csrc/k_valu_rate.h) — the ceiling of K6's Smith-Waterman
- * (gobwa.go:286-325 -> mem_matesw -> ksw_align2 in packed 16-bit cells).  op: 0..22 one opcode in eight independent chains, 100 + op the same in
- * one dependent chain, 50 the instruction mix of k_resc_sw's column, 51 v_pk_fma_f32, 52 s_nop.  waves_per_simd 1..8 over the whole chip.
+ * (gobwa.go:286-325 -> mem_matesw -> ksw_align2 in packed 16-bit cells).  op: 0..49, 53..55 one opcode in eight independent chains, 100 + op the same in
+ * one dependent chain, 50 the instruction mix of k_resc_sw's column, 51 v_pk_fma_f32, 52 s_nop, 56 and 57 half- and full-rate opcodes interleaved.  waves_per_simd 1..8 over the whole chip.
  * out[0..9]: ms, wave-instructions, G wave-instructions/s, median shader MHz, median cycles per instruction per WAVE, cycles per instruction per
  * SIMD chip-wide, SIMDs seen, fewest / most waves on one SIMD, lowest MHz.  LH_E_NODEVICE without a GPU (and under the emulator). */
 int lh_diag_valu_rate(int device, int32_t op, int32_t waves_per_simd, int32_t iters, double* out, int32_t n_out);

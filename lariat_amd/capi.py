@@ -13,11 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LARIAT_HIP_LIB") or os.path.join(_HERE, "_build", "liblariat_hip.so")
 
 LH_OK = 0
-LH_ABI_VERSION = 4
+LH_ABI_VERSION = 5
 LH_E_ARG, LH_E_IO, LH_E_HIP, LH_E_CAPACITY, LH_E_NODEVICE, LH_E_LIMIT = 1, 2, 3, 4, 5, 6
 # lh_opts.flags
 LH_REC_DEBUG_TAGS = 1
-LH_F_NO_SWEEP_FILTER, LH_F_EXT_WAVE, LH_F_EXT_SERIAL, LH_F_CHAIN_WAVE, LH_F_P2_TASKS = 1, 16, 32, 64, 128
+LH_F_NO_SWEEP_FILTER, LH_F_EXT_WAVE, LH_F_EXT_SERIAL, LH_F_CHAIN_WAVE, LH_F_P2_TASKS, LH_F_RESCUE_FULL = 1, 16, 32, 64, 128, 256
 LH_MAX_READ_LEN = 250
 
 c_i32p = C.POINTER(C.c_int32)
@@ -83,7 +83,7 @@ _RESULT_READ_FIELDS = [
     ("as_score", c_f64p, np.float64), ("split_idx", c_i64p, np.int64), ("split_mapq", c_i32p, np.int32),
     ("split_second_best", c_f64p, np.float64), ("split_score", c_f64p, np.float64),
 ]
-_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3", "n_ktree_p1", "n_ktree_p2", "n_ktree_p3", "n_calls_by_text"]
+_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3", "n_ktree_p1", "n_ktree_p2", "n_ktree_p3", "n_calls_by_text", "rescue_cells_exec"]
 
 
 class LhResult(C.Structure):

@@ -76,7 +76,8 @@ struct RJob {
     int32_t pair;
     int16_t qlen, tlen, anchor;      // anchor: index of the anchoring region in the other mate's list
     int16_t score, te, qe, tb, qb;   // ksw_align2's result; tb = qb = -1: no start
-    int16_t rows2, pad_;             // rows the reverse pass executed (its cells: 16 * slen(qe + 1) * rows2)
+    int16_t rows2;                   // rows the reverse pass executed (its cells: 16 * slen(qe + 1) * rows2)
+    int16_t rlo, rn;                 // (r06, k_rescue3.h) the forward pass runs rows [rlo, rlo + rn) of the window: rn = tlen the whole of it, 0 none (no path reaches min_seed_len)
 };
 struct RMeta {   // per direction, on the device
     int32_t hist[LH_RJ_NB], bstart[LH_RJ_NB + 1], bcur[LH_RJ_NB];       // forward jobs by slen; bstart: bucket starts in the order array, each padded to 8
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(256) k_resc_enum(DIndex ix, DOpts o, int n_pai
                 RJob jb;
                 jb.t0 = rb; jb.q0 = (int32_t)(seq_off[w.r_ms] + w.l_ms - 1); jb.pair = p;
                 jb.qlen = (int16_t)w.l_ms; jb.tlen = (int16_t)(re - rb); jb.anchor = (int16_t)i;
-                jb.score = 0; jb.te = -1; jb.qe = -1; jb.tb = -1; jb.qb = -1; jb.rows2 = 0; jb.pad_ = 0;
+                jb.score = 0; jb.te = -1; jb.qe = -1; jb.tb = -1; jb.qb = -1; jb.rows2 = 0; jb.rlo = 0; jb.rn = jb.tlen;
                 jobs[jbase + nj] = jb;
                 order[obase + nj] = (int32_t)(jbase + nj);
             }
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(64) k_resc_enum_w(DIndex ix, DOpts o, int n_pa
                     RJob jb;
                     jb.t0 = rb; jb.q0 = (int32_t)(seq_off[w.r_ms] + w.l_ms - 1); jb.pair = p;
                     jb.qlen = (int16_t)w.l_ms; jb.tlen = (int16_t)(re - rb); jb.anchor = (int16_t)(i0 + u);
-                    jb.score = 0; jb.te = -1; jb.qe = -1; jb.tb = -1; jb.qb = -1; jb.rows2 = 0; jb.pad_ = 0;
+                    jb.score = 0; jb.te = -1; jb.qe = -1; jb.tb = -1; jb.qb = -1; jb.rows2 = 0; jb.rlo = 0; jb.rn = jb.tlen;
                     jobs[jbase + nj] = jb;
                     order[obase + nj] = (int32_t)(jbase + nj);
                 }
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(256) k_resc_bucket2(i64 n_jobs, const RJob* __
     const i64 per = (n_jobs + gridDim.x - 1) / gridDim.x, j0 = per * blockIdx.x, j1 = j0 + per < n_jobs ? j0 + per : n_jobs;
     for (i64 j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
         const RJob& jb = jobs[j];
-        if (jb.score < minsc || jb.te < 0 || jb.qe < 0) continue;
+        if (jb.score < minsc || jb.te < 0 || jb.qe < 0 || jb.rlo < 0) continue;   // (rlo < 0: k_resc_cert settled the job, start included)
         atomicAdd(&sh_n[(jb.qe + 1 + 15) / 16], 1);
     }
     __syncthreads();
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(256) k_resc_bucket2(i64 n_jobs, const RJob* __
     __syncthreads();
     for (i64 j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
         const RJob& jb = jobs[j];
-        if (jb.score < minsc || jb.te < 0 || jb.qe < 0) continue;
+        if (jb.score < minsc || jb.te < 0 || jb.qe < 0 || jb.rlo < 0) continue;   // (rlo < 0: k_resc_cert settled the job, start included)
         const int s2 = (jb.qe + 1 + 15) / 16;
         order2[sh_base[s2] + atomicAdd(&sh_n[s2], 1)] = (int32_t)j;
     }
@@ -372,8 +373,8 @@ __device__ __forceinline__ void resc_sw_run(const DIndex& ix, const DOpts& o, RJ
         const int ju = ord[u];
         if (ju < 0) continue;
         const RJob& J = jobs[ju];
-        const int tlen = REV ? J.te + 1 : J.tlen;
-        const i64 t0 = REV ? J.t0 + J.te : J.t0;
+        const int tlen = REV ? J.te + 1 : J.rn;              // (r06) forward: the rows k_resc_cert left (k_rescue3.h)
+        const i64 t0 = REV ? J.t0 + J.te : J.t0 + J.rlo;
         for (int i = lane; i < tlen; i += 64) tl[u * LH_RJ_TSLOT + 16 + i] = (uint8_t)((u & 1) * 4 + dev_ref_base(ix, REV ? t0 - i : t0 + i));
         max_t = max_t > tlen ? max_t : tlen;
     }
@@ -456,7 +457,7 @@ __device__ __forceinline__ void resc_sw_run(const DIndex& ix, const DOpts& o, RJ
             RJob& J = jobs[jj];
             const int qe = wl < 16 ? L * SLEN + (255 - kc) : -1;
             if (!REV) {
-                J.score = (int16_t)gmax; J.te = (int16_t)(wl < 16 ? te : -1); J.qe = (int16_t)qe;
+                J.score = (int16_t)gmax; J.te = (int16_t)(wl < 16 ? te + J.rlo : -1); J.qe = (int16_t)qe;
             } else {
                 const int tlen2 = J.te + 1;
                 J.rows2 = (int16_t)(wl < 16 ? te + 1 : tlen2);
@@ -929,7 +930,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
         i64 a_rb = 0;
         u64 amask = 0;
         int jp = 0;
-        u64 cells = 0;
+        u64 cells = 0, cells_x = 0;
         int n_sw = 0, num = 0;
         int w_sorted = 1;   // the list in LDS is in the call's final order (until a rescued region is appended)
         int mode = 0;   // 0: the list is in memory, no dedup call yet; 1: in LDS (W), clean; 2: in memory for good (too long); 3: in memory for this call; 4: in LDS with a tie that is not harmless (every call as written, resc_dedup_lds)
@@ -995,7 +996,9 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
                 if (J.score >= o.min_seed_len * o.a) cells += (u64)(16 * ((J.qe + 1 + 15) / 16)) * (u64)J.rows2;
             } else {   // no job: an attempt the enumeration saw as unnecessary (or left to this kernel): k_rescue.h's wave-wide kernel
                 RA_PROF(1)
+                const u64 cells_before = cells;
                 aln = wave_ksw_align2(ix, o, qm, l_ms - 1, -1, 1, l_ms, rb, 1, (int)(re - rb), o.min_seed_len * o.a, lane, &cells);
+                cells_x += cells - cells_before;   // (this kernel runs every cell it accounts for)
                 RA_PROF(17)
                 RA_COUNT(18)
             }
@@ -1132,7 +1135,7 @@ __global__ void __launch_bounds__(64) k_resc_apply(DIndex ix, DOpts o, int n_pai
 #endif
         if (lane == 0) {
             n_regs[r_ms] = n_ma;
-            if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); }
+            if (ctr && n_sw) { atomicAdd(&LH_CTR(ctr)->n_rescue, (u64)n_sw); atomicAdd(&LH_CTR(ctr)->rescue_cells, cells); if (cells_x) atomicAdd(&LH_CTR(ctr)->rescue_cells_exec, cells_x); }
         }
     }
 }

@@ -151,6 +151,25 @@ __global__ void __launch_bounds__(256) k_diag_valu_rate(int op, int iters, uint3
         VR_CASE(54, VRI_FMAC_F32)
         VR_CASE(55, VRI_CVT_UBYTE)
         case 43: for (int i = 0; i < iters; ++i) asm volatile(VR64(VRI_CMP_EQ) : VR_REGS : VR_OPS : "vcc"); break;
+        // do the two classes share an issue slot?  32 half-rate + 32 full-rate instructions, alternating (56), and 16 half-rate + 48 full-rate (57)
+#define VRI_ALT2(A, B, C, D) "v_pk_max_u16 " A ", " A ", %8\n" "v_max_u16 " B ", " B ", %8\n" "v_pk_max_u16 " C ", " C ", %8\n" "v_max_u16 " D ", " D ", %8\n"
+#define VRI_ALT8 VRI_ALT2("%0", "%1", "%2", "%3") VRI_ALT2("%4", "%5", "%6", "%7")
+#define VRI_ALT3(A, B, C, D) "v_pk_max_u16 " A ", " A ", %8\n" "v_max_u16 " B ", " B ", %8\n" "v_add_u32 " C ", " C ", %8\n" "v_max_u16 " D ", " D ", %8\n"
+#define VRI_ALT8B VRI_ALT3("%0", "%1", "%2", "%3") VRI_ALT3("%4", "%5", "%6", "%7")
+#define VRI_ALT4(A, B, C, D) "v_add_u32 " A ", " A ", %8\n" "v_xor_b32 " B ", " B ", %8\n" "v_sub_u32 " C ", " C ", %8\n" "v_and_b32 " D ", " D ", %9\n"
+#define VRI_ALT8C VRI_ALT4("%0", "%1", "%2", "%3") VRI_ALT4("%4", "%5", "%6", "%7")
+#define VRI_ALT5(A, B, C, D) "v_max_u16 " A ", " A ", %8\n" "v_sub_u16 " B ", " B ", %8 clamp\n" "v_add_u16 " C ", " C ", %8\n" "v_max_u16 " D ", " D ", %9\n"
+#define VRI_ALT8D VRI_ALT5("%0", "%1", "%2", "%3") VRI_ALT5("%4", "%5", "%6", "%7")
+#define VRI_ALT6(A, B, C, D) "v_max_u16 " A ", " A ", %8\n" "v_add_u32 " B ", " B ", %8\n" "v_max_u16 " C ", " C ", %8\n" "v_add_u32 " D ", " D ", %9\n"
+#define VRI_ALT8E VRI_ALT6("%0", "%1", "%2", "%3") VRI_ALT6("%4", "%5", "%6", "%7")
+#define VRI_ALT7(A, B, C, D) "v_pk_max_u16 " A ", " A ", %8\n" "v_pk_max_u16 " B ", " B ", %8\n" "v_add_u32 " C ", " C ", %8\n" "v_add_u32 " D ", " D ", %9\n"
+#define VRI_ALT8F VRI_ALT7("%0", "%1", "%2", "%3") VRI_ALT7("%4", "%5", "%6", "%7")
+        case 58: for (int i = 0; i < iters; ++i) asm volatile(VRI_ALT8C VRI_ALT8C VRI_ALT8C VRI_ALT8C VRI_ALT8C VRI_ALT8C VRI_ALT8C VRI_ALT8C : VR_REGS : VR_OPS); break;
+        case 59: for (int i = 0; i < iters; ++i) asm volatile(VRI_ALT8D VRI_ALT8D VRI_ALT8D VRI_ALT8D VRI_ALT8D VRI_ALT8D VRI_ALT8D VRI_ALT8D : VR_REGS : VR_OPS); break;
+        case 60: for (int i = 0; i < iters; ++i) asm volatile(VRI_ALT8E VRI_ALT8E VRI_ALT8E VRI_ALT8E VRI_ALT8E VRI_ALT8E VRI_ALT8E VRI_ALT8E : VR_REGS : VR_OPS); break;
+        case 61: for (int i = 0; i < iters; ++i) asm volatile(VRI_ALT8F VRI_ALT8F VRI_ALT8F VRI_ALT8F VRI_ALT8F VRI_ALT8F VRI_ALT8F VRI_ALT8F : VR_REGS : VR_OPS); break;
+        case 56: for (int i = 0; i < iters; ++i) asm volatile(VRI_ALT8 VRI_ALT8 VRI_ALT8 VRI_ALT8 VRI_ALT8 VRI_ALT8 VRI_ALT8 VRI_ALT8 : VR_REGS : VR_OPS); break;
+        case 57: for (int i = 0; i < iters; ++i) asm volatile(VRI_ALT8B VRI_ALT8B VRI_ALT8B VRI_ALT8B VRI_ALT8B VRI_ALT8B VRI_ALT8B VRI_ALT8B : VR_REGS : VR_OPS); break;
         case 50: for (int i = 0; i < iters; ++i) asm volatile(VRI_MIX64 : VR_REGS : VR_OPS); break;
         case 51: {   // packed f32 FMA (the opcode behind the data sheet's vector FP32 peak): eight chains of register pairs
             unsigned long long q0 = r0, q1 = r1, q2 = r2, q3 = r3, q4 = r4, q5 = r5, q6 = r6, q7 = r7, qa = a, qb = b;

@@ -1091,8 +1091,171 @@ static inline int mem_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* 
 // Any path's score is at most 7 + sum over its diagonals of V(d) when none of its pieces lies on d0, the result's diagonal.
 std::atomic<uint64_t> g_rescue_probe[64];
 int g_rescue_probe_on = 0;
+// (r06) the certificate of the row-restricted forward pass (k_rescue3.h; DESIGN section 3, "K6: a window the size of its hit"), counted on every attempt:
+//   K(d)      best ungapped segment of diagonal d;  d0 = the first diagonal with the largest K;  K0 = K(d0)
+//   V6(d)     the most that disjoint segments of d add to a path that pays a gap open (6) for each:  max sum of (segment - 6)+
+//   X8(d0)    the most that disjoint segments of d0 are worth to a path that leaves and returns between them (two gaps and two diagonals' worth of
+//             extension for every return: 8 of it charged to d0):  max over segment sets of sum - 8 (n - 1)
+//   any path with a cell more than w diagonals off d0 scores at most  max(6 + Vside, X8(d0) + Vside - (w + 1)),  Vside = sum of V6 over d != d0;
+//   with w = X8 - K0 + Vside that is below K0, a score the rows [d0 - w, d0 + qlen + w) reach themselves: the full window's result is theirs.
+static void rescue_probe_cert(const MemOpt& o, int qlen, const uint8_t* q, int tlen, const uint8_t* t, const Kswr& r) {
+    auto& P = g_rescue_probe;
+    const int nd = tlen + qlen - 1, go = o.o_del < o.o_ins ? o.o_del : o.o_ins;
+    int K0 = 0, d0 = 0;
+    long vall = 0;
+    std::vector<int> V6(nd, 0);
+    for (int di = 0; di < nd; ++di) {
+        const int d = di - (qlen - 1);
+        int k0 = d < 0 ? -d : 0, i0 = d < 0 ? 0 : d;
+        int h = 0, best = 0, open = -1000000, vbest = 0;
+        for (int k = k0, i = i0; k < qlen && i < tlen; ++k, ++i) {
+            const int sc = (q[k] > 3 || t[i] > 3) ? -1 : (q[k] == t[i] ? o.a : -o.b);
+            h = h + sc > 0 ? h + sc : 0;
+            if (h > best) best = h;
+            open = (open > vbest - go ? open : vbest - go) + sc;
+            if (open > vbest) vbest = open;
+        }
+        V6[di] = vbest; vall += vbest;
+        if (best > K0) { K0 = best; d0 = d; }
+    }
+    P[32]++;
+    P[33] += (uint64_t)tlen * (uint64_t)qlen;
+    if (go + vall < o.min_seed_len) {   // no path reaches min_seed_len: no region, no DP at all
+        P[34]++;
+        if (r.score >= o.min_seed_len) P[47]++;   // (must never happen)
+        return;
+    }
+    const long vside = vall - V6[d0 + qlen - 1];
+    int x8 = K0;
+    {
+        const int d = d0;
+        int k0 = d < 0 ? -d : 0, i0 = d < 0 ? 0 : d;
+        int open = -1000000, vbest = 0;
+        for (int k = k0, i = i0; k < qlen && i < tlen; ++k, ++i) {
+            const int sc = (q[k] > 3 || t[i] > 3) ? -1 : (q[k] == t[i] ? o.a : -o.b);
+            open = (open > vbest - (go + 2) ? open : vbest - (go + 2)) + sc;
+            if (open > vbest) vbest = open;
+        }
+        if (vbest + go + 2 > x8) x8 = vbest + go + 2;
+    }
+    if (go + vside >= K0) { P[35]++; P[36] += (uint64_t)tlen * (uint64_t)qlen; return; }   // another diagonal is too strong: the full window
+    long w = x8 - K0 + vside;
+    long r0 = d0 - w, r1 = d0 + qlen + w;
+    if (r0 < 0) r0 = 0;
+    if (r1 > tlen) r1 = tlen;
+    P[37]++;
+    P[36] += (uint64_t)(r1 - r0) * (uint64_t)qlen;
+    P[38] += (uint64_t)w; if ((uint64_t)w > P[39]) P[39] = (uint64_t)w;
+    if (x8 > K0) P[40]++;
+    // what the certificate promises, checked against the full DP's result
+    if (r.score >= o.min_seed_len) {
+        if (r.te < r0 || r.te >= r1) P[47]++;
+        if (r.score < K0) P[47]++;
+        if (std::abs((r.te - r.qe) - d0) > w) P[46]++;   // the result's end is off the strip (allowed only if an equal path inside ends there too: counted, looked at)
+    } else if (K0 >= o.min_seed_len) P[47]++;
+    if (w <= 8) P[41]++;
+    if (w <= 16) P[42]++;
+    if (w <= 32) P[43]++;
+}
+
+// the certificate as k_resc_cert computes it (k_rescue3.h): h(d) = exact 5-mer matches on diagonal d, V(d) = (h - 2)+, d0 = the diagonal with the most hits.
+// Class A (no DP at all): no path with a gap reaches K0 — 6 + Vside < K0 (paths off d0), Y2 < K0 (two or more pieces of d0: each return costs 8),
+// and for every distance D the V within D of d0 sums to less than D (a chain of pieces off d0 pays its farthest piece's distance) — so the result is d0's best
+// segment: first end of the maximum, the shortest segment that has it.  Class B: rows [d0 - w, d0 + qlen + w).  Class C: the whole window.  P[48..63].
+static void rescue_probe_cert2(const MemOpt& o, int qlen, const uint8_t* q, int tlen, const uint8_t* t, const Kswr& r) {
+    auto& P = g_rescue_probe;
+    const int nd = tlen + qlen - 1;
+    std::vector<int> H(nd, 0);
+    for (int di = 0; di < nd; ++di) {
+        const int d = di - (qlen - 1);
+        int k0 = d < 0 ? -d : 0, i0 = d < 0 ? 0 : d, run = 0, h = 0;
+        for (int k = k0, i = i0; k < qlen && i < tlen; ++k, ++i) {
+            if (q[k] < 4 && q[k] == t[i]) { if (++run >= 5) ++h; } else run = 0;
+        }
+        H[di] = h;
+    }
+    int di0 = 0; long vall = 0;
+    for (int di = 0; di < nd; ++di) { if (H[di] > H[di0]) di0 = di; vall += H[di] > 2 ? H[di] - 2 : 0; }
+    const int d0 = di0 - (qlen - 1), h0 = H[di0];
+    const uint64_t ref_fwd = (uint64_t)(16 * ((qlen + 15) / 16)) * (uint64_t)tlen;
+    uint64_t ref_rev = 0;
+    if (r.score >= o.min_seed_len && r.qe >= 0) ref_rev = (uint64_t)(16 * ((r.qe + 1 + 15) / 16)) * (uint64_t)(r.qb >= 0 ? r.te - r.tb + 1 : r.te + 1);
+    P[48]++; P[49] += ref_fwd + ref_rev;
+    if (6 + vall < o.min_seed_len) { P[50]++; if (r.score >= o.min_seed_len) P[63]++; return; }
+    const long vside = vall - (h0 > 2 ? h0 - 2 : 0);
+    // d0 exactly: K0 and where its first maximum ends, X8, Y2 (two or more segments)
+    const int k0 = d0 < 0 ? -d0 : 0, i0 = d0 < 0 ? 0 : d0;
+    int n = std::min(qlen - k0, tlen - i0);
+    int K0 = 0, e0 = -1;
+    {
+        int h = 0;
+        for (int c = 0; c < n; ++c) {
+            const int sc = q[k0 + c] > 3 ? -1 : (q[k0 + c] == t[i0 + c] ? o.a : -o.b);
+            h = h + sc > 0 ? h + sc : 0;
+            if (h > K0) { K0 = h; e0 = c; }
+        }
+    }
+    int open1 = -1000000, v1 = 0, open2 = -1000000, v2 = -1000000;   // v1: best sum of (seg - 8) over >= 1 segments so far (0: none yet allowed), v2: over >= 2 segments
+    {
+        // one-segment value without the charge: plain best segment so far = b1; sets of >= 2: second segment opens from b1 - 8
+        int hh = 0, b1 = 0;
+        for (int c = 0; c < n; ++c) {
+            const int sc = q[k0 + c] > 3 ? -1 : (q[k0 + c] == t[i0 + c] ? o.a : -o.b);
+            // segments after the first: open2 continues, or starts from the best value of the sets that end before c
+            const int start2 = std::max(b1, v2) - 8;
+            open2 = std::max(open2, start2) + sc;
+            if (open2 > v2) v2 = open2;
+            hh = hh + sc > 0 ? hh + sc : 0;   // (a first segment ending at c: Kadane)
+            // b1 must only hold segments that ended strictly before the cell the next one starts at: update after use
+            if (hh > b1) b1 = hh;
+            (void)open1; (void)v1;
+        }
+    }
+    const int Y2 = v2 < 0 ? 0 : v2;   // sum - 8 (n - 1), n >= 2 (b1 is uncharged, every later segment pays 8)
+    int X8 = std::max(K0, Y2);
+    bool A = 6 + vside < K0 && Y2 < K0 && K0 >= o.min_seed_len;
+    if (A) {
+        long cum = 0;
+        for (int D = 1; D < nd && A; ++D) {
+            const int a = di0 - D, b = di0 + D;
+            if (a >= 0) cum += H[a] > 2 ? H[a] - 2 : 0;
+            if (b < nd) cum += H[b] > 2 ? H[b] - 2 : 0;
+            if (cum >= D) A = false;
+            if (a < 0 && b >= nd) break;
+        }
+    }
+    if (A) {
+        int dmin = nd;
+        for (int di = 0; di < nd; ++di) if (di != di0 && H[di] > 2) dmin = std::min(dmin, std::abs(di - di0));
+        if (vside < dmin) P[56]++;   // the simpler sufficient condition: all of Vside is nearer than the nearest diagonal that has any
+    }
+    if (A) {
+        P[51]++;
+        // the predicted result
+        const int te = i0 + e0, qe = k0 + e0;
+        int rr = 0, cb = -1;
+        for (int c = e0; c >= 0; --c) {
+            const int sc = q[k0 + c] > 3 ? -1 : (q[k0 + c] == t[i0 + c] ? o.a : -o.b);
+            rr = rr + sc > 0 ? rr + sc : 0;
+            if (rr >= K0) { cb = c; break; }
+        }
+        if (r.score != K0 || r.te != te || r.qe != qe || cb < 0 || r.tb != i0 + cb || r.qb != k0 + cb) P[62]++;
+        return;
+    }
+    if (6 + vside >= K0) { P[52]++; P[53] += ref_fwd + ref_rev; return; }
+    long w = X8 - K0 + vside;
+    long r0 = std::max(0L, (long)d0 - w), r1 = std::min((long)tlen, (long)d0 + qlen + w);
+    P[54]++;
+    P[53] += (uint64_t)(16 * ((qlen + 15) / 16)) * (uint64_t)(r1 - r0) + ref_rev;
+    P[55] += (uint64_t)w;
+    if (r.score >= o.min_seed_len && (r.te < r0 || r.te >= r1 || r.score < K0)) P[63]++;
+    if (r.score < o.min_seed_len && K0 >= o.min_seed_len) P[63]++;
+}
+
 static void rescue_probe(const MemOpt& o, int qlen, const uint8_t* q, int tlen, const uint8_t* t, const Kswr& r) {
     auto& P = g_rescue_probe;
+    rescue_probe_cert(o, qlen, q, tlen, t, r);
+    rescue_probe_cert2(o, qlen, q, tlen, t, r);
     P[0]++;
     if (r.score < o.min_seed_len || r.qb < 0) { P[1]++; return; }   // no region comes of it
     P[2]++;

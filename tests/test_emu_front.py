@@ -415,6 +415,13 @@ def test_emu_repeat_families(emu, oracle, build):
         helpers.assert_same_result(res, ref, inference=True)
         for k in ("glob_cells", "n_rescue", "rescue_cells"):
             assert res.counters[k] == ref.counters[k], k
+        # (r06) the forward passes ran the rows k_resc_cert left them (k_rescue3.h): the same results from a fraction of the reference's cells; with
+        # LH_F_RESCUE_FULL every window is run whole, as before
+        assert 0 < res.counters["rescue_cells_exec"] < 0.6 * res.counters["rescue_cells"], (res.counters["rescue_cells_exec"], res.counters["rescue_cells"])
+        full = idx.context(rs.n_pairs).align_barcodes(b, lib.opts(flags=capi.LH_F_RESCUE_FULL))
+        helpers.assert_same_result(full, ref, inference=True)
+        assert full.counters["rescue_cells"] == ref.counters["rescue_cells"]
+        assert 0.9 * full.counters["rescue_cells"] < full.counters["rescue_cells_exec"] < 1.1 * full.counters["rescue_cells"]   # (jobs dropped by the replay ran; attempts without a job ran in place)
 
 
 def test_emu_k3_cluster_kernel_and_wave_kernel_agree(emu, oracle):

@@ -72,6 +72,21 @@ def main():
     for i, w in enumerate((0, 8, 16, 32)):
         print("    band |d - d0| <= %2d:  U < S %s   U < min_seed_len %s   no detour and V = 0 outside %s" % (w, pc(P[8 + i]), pc(P[12 + i]), pc(P[16 + i])))
     print("    start and end diagonals within 8 / 16 of each other %s / %s" % (pc(P[26]), pc(P[27])))
+    na = max(1, P[32])
+    print("  (r06) the row-restricted forward pass and its certificate, over ALL %d attempts (bwa_mem.cpp: rescue_probe_cert):" % P[32])
+    print("    no path reaches min_seed_len (no DP at all)     %6.2f %%" % (100.0 * P[34] / na))
+    print("    restricted to rows [d0 - w, d0 + qlen + w)      %6.2f %%   mean w %.1f, max w %d; w <= 8 / 16 / 32: %.1f / %.1f / %.1f %% of them; X8 > K0 in %.2f %%" % (
+        100.0 * P[37] / na, P[38] / max(1, P[37]), P[39], 100.0 * P[41] / max(1, P[37]), 100.0 * P[42] / max(1, P[37]), 100.0 * P[43] / max(1, P[37]), 100.0 * P[40] / max(1, P[37])))
+    print("    another diagonal too strong: the full window    %6.2f %%" % (100.0 * P[35] / na))
+    print("    forward cells executed / cells of the reference %6.2f %%   (%d of %d)" % (100.0 * P[36] / max(1, P[33]), P[36], P[33]))
+    print("    certificate violated (must be 0): %d; result's end diagonal off the strip: %d" % (P[47], P[46]))
+    nb = max(1, P[48])
+    print("  (r06) the certificate as k_resc_cert computes it, from 5-mer hits (rescue_probe_cert2), over %d attempts:" % P[48])
+    print("    no path reaches min_seed_len: no DP             %6.2f %%" % (100.0 * P[50] / nb))
+    print("    class A: the result is d0's best segment, no DP %6.2f %%   (prediction != the DP's result: %d — must be 0); with 'Vside < distance of the nearest diagonal that has any' for the distance condition: %.2f %%" % (100.0 * P[51] / nb, P[62], 100.0 * P[56] / nb))
+    print("    class B: rows [d0 - w, d0 + qlen + w)           %6.2f %%   mean w %.1f" % (100.0 * P[54] / nb, P[55] / max(1, P[54])))
+    print("    class C: the whole window                       %6.2f %%" % (100.0 * P[52] / nb))
+    print("    cells executed (both passes) / the reference's  %6.2f %%   certificate violated (must be 0): %d" % (100.0 * P[53] / max(1, P[49]), P[63]))
     print("    perfect score (forward pass may stop at te) %s, rows it would skip: %.1f %% of all rows" % (pc(P[22]), 100.0 * P[23] / max(1, P[24])))
 
 

@@ -19,7 +19,9 @@ OPS = [
     (25, "v_min_u32"), (26, "v_max_i32"), (42, "v_min_i32"), (47, "v_min3_u32"), (49, "v_sub_u32"), (27, "v_cndmask_b32 (vcc)"), (43, "v_cmp_eq_u32 -> vcc"), (28, "v_mov_b32"),
     (29, "v_and_b32"), (30, "v_or_b32"), (40, "v_or3_b32"), (44, "v_bfi_b32"), (31, "v_lshlrev_b32"), (46, "v_lshl_add_u32"), (37, "v_bfe_u32"), (35, "v_mul_u32_u24"), (36, "v_mad_u32_u24"),
     (32, "v_add_u16"), (33, "v_sub_u16 clamp"), (34, "v_max_i16"), (53, "v_max_u16 (e64, sgpr)"), (45, "v_mad_u16"), (41, "v_max_u16 sdwa WORD_1"),
-    (51, "v_pk_fma_f32"), (52, "s_nop 0"), (50, "k_resc_sw column mix (1 perm 1 add 6 subs 7 max 1 lshl_or)"),
+    (51, "v_pk_fma_f32"), (52, "s_nop 0"), (56, "alternating v_pk_max_u16 / v_max_u16 (32 + 32)"), (57, "v_pk_max_u16 + 3 full-rate (16 + 48)"),
+    (58, "v_add_u32 / v_xor_b32 / v_sub_u32 / v_and_b32 rotating (all full-rate, 32-bit)"), (59, "v_max_u16 / v_sub_u16 clamp / v_add_u16 rotating (all full-rate, 16-bit)"),
+    (60, "v_max_u16 / v_add_u32 alternating (full-rate, 16- and 32-bit)"), (61, "2 v_pk_max_u16 then 2 v_add_u32 (32 + 32)"), (50, "k_resc_sw column mix (1 perm 1 add 6 subs 7 max 1 lshl_or)"),
 ]
 
 
@@ -41,7 +43,7 @@ def main():
     print()
     print("%-58s %2s %9s %9s" % ("op (ONE dependent chain)", "W", "cyc/SIMD", "cyc/wave"))
     for op, name in OPS:
-        if op in (50, 51, 52, 43):
+        if op in (50, 51, 52, 43) or op >= 56:
             continue
         for w in (1, 4):
             r = lib.diag_valu_rate(100 + op, w, a.iters)
