@@ -337,6 +337,12 @@ int lh_diag_random_read(int device, int64_t table_bytes, int32_t granule_bytes, 
  * SIMD chip-wide, SIMDs seen, fewest / most waves on one SIMD, lowest MHz.  LH_E_NODEVICE without a GPU (and under the emulator). */
 int lh_diag_valu_rate(int device, int32_t op, int32_t waves_per_simd, int32_t iters, double* out, int32_t n_out);
 
+/* diagnostics: K6's Smith-Waterman as the pipeline runs it (k_resc_cert -> k_resc_sw forward -> reverse; csrc/k_rescue3.h) on caller-supplied cases: queries as
+ * ksw_align2 sees them and windows, nt4 bytes 0..3, q_off / t_off [n_cases + 1].  full != 0: every window whole (LH_F_RESCUE_FULL).  weaken: bits that switch terms
+ * of the certificate off (tests of the crafted cases each term guards against; 0 = the pipeline's).  out: 8 per case — score, te, qe, tb, qb (ksw_align2's, mem_matesw's
+ * call: gobwa.go:286-325; tb = qb = -1 below min_seed_len), then rlo (-1: settled without DP), rn (rows the forward pass ran), rows2 (rows of the reverse pass). */
+int lh_diag_rescue_sw(int device, int32_t n_cases, const int32_t* q_off, const uint8_t* q, const int32_t* t_off, const uint8_t* t, int32_t full, int32_t weaken, int32_t* out);
+
 /* diagnostics: self-check of a resident index with a dense suffix array, on every stride-th row: adjacent suffixes are in
  * order (direct text comparison); the stored BWT symbol is the base before the suffix and the LF-mapping through the
  * occurrence table reaches that suffix's row.  A size-independent property for indexes the oracle cannot hold. */

@@ -307,6 +307,7 @@ def _declare(L):
     L.lh_get_seq.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_char_p]
     L.lh_device_memory.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.lh_diag_random_read.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.lh_diag_rescue_sw.argtypes = [C.c_int, C.c_int32, c_i32p, c_u8p, c_i32p, c_u8p, C.c_int32, C.c_int32, c_i32p]
     L.lh_diag_valu_rate.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]
     return L
 
@@ -401,6 +402,17 @@ class Library:
         g, ms = C.c_double(), C.c_double()
         self.check(self.L.lh_diag_random_read(device, int(table_bytes), int(granule_bytes), int(n_access), C.byref(g), C.byref(ms)))
         return g.value, ms.value
+
+    def diag_rescue_sw(self, queries, windows, full=False, weaken=0, device=0):
+        """lh_diag_rescue_sw: per case (score, te, qe, tb, qb, rlo, rn, rows2) as an int32 array [n, 8]"""
+        n = len(queries)
+        q_off = np.zeros(n + 1, dtype=np.int32); t_off = np.zeros(n + 1, dtype=np.int32)
+        q_off[1:] = np.cumsum([len(x) for x in queries]); t_off[1:] = np.cumsum([len(x) for x in windows])
+        q = np.ascontiguousarray(np.concatenate(queries).astype(np.uint8)); t = np.ascontiguousarray(np.concatenate(windows).astype(np.uint8))
+        out = np.zeros((n, 8), dtype=np.int32)
+        self.check(self.L.lh_diag_rescue_sw(device, n, q_off.ctypes.data_as(c_i32p), q.ctypes.data_as(c_u8p), t_off.ctypes.data_as(c_i32p), t.ctypes.data_as(c_u8p), int(bool(full)), int(weaken),
+                                            out.ctypes.data_as(c_i32p)))
+        return out
 
     def diag_valu_rate(self, op, waves_per_simd, iters=2048, device=0):
         """lh_diag_valu_rate -> dict (k_valu_rate.h)"""
@@ -892,6 +904,6 @@ EXPORTED_SYMBOLS = [
     "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
     "lh_records_text", "lh_records_text_ex", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_set_flags", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
-    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_introsort", "lh_diag_random_read", "lh_diag_valu_rate", "lh_diag_go_rand", "lh_diag_rescue_dedup",
+    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_introsort", "lh_diag_random_read", "lh_diag_valu_rate", "lh_diag_rescue_sw", "lh_diag_go_rand", "lh_diag_rescue_dedup",
     "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_synth_write_fastq9", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt", "lh_bam_set_level", "lh_bam_timings", "lh_result_download_begin", "lh_result_download_end", "lh_batch_stage_slot", "lh_host_alloc", "lh_host_free",
 ]

@@ -81,7 +81,9 @@ __device__ __forceinline__ void resc_diag_scan(const u64* mw, int n, int b, int 
 }
 
 // one wave per job: J.rlo, J.rn (rn = 0: no forward pass — rlo = -1: the result is written here, rlo = 0: there is none; rn = tlen: the whole window)
-__global__ void __launch_bounds__(64) k_resc_cert(DIndex ix, DOpts o, i64 n_jobs, RJob* __restrict__ jobs, const uint8_t* __restrict__ seq, int32_t* __restrict__ wd) {
+// weaken (lh_diag_rescue_sw only; 0 in the pipeline): each bit switches one term of the certificate off, so that the tests can show that the crafted case
+// it guards against then comes out wrong — 1: the paths off d0 (6 + Vside < K0), 2: two or more pieces of d0 (Y2), 4: the distance condition, 8: the strip's width
+__global__ void __launch_bounds__(64) k_resc_cert(DIndex ix, DOpts o, i64 n_jobs, RJob* __restrict__ jobs, const uint8_t* __restrict__ seq, int weaken) {
     __shared__ RescCertLds S;
     const int lane = LANE();
     const int ok = resc_cert_ok(o);
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(64) k_resc_cert(DIndex ix, DOpts o, i64 n_jobs
         }
         int K0, e0, s0, Y2;
         resc_diag_scan(mw, n, o.b, 8, &K0, &e0, &s0, &Y2);
-        if (K0 >= minsc && 6 + vside < K0 && Y2 < K0 && !near_fail) {
+        if (K0 >= minsc && (6 + vside < K0 || (weaken & 1)) && (Y2 < K0 || (weaken & 2)) && (!near_fail || (weaken & 4))) {
             // class A: every path with a gap scores below K0 — the result is d0's best segment, no DP in either direction (rlo = -1: settled)
             if (lane == 0) {
                 J.score = (int16_t)K0; J.te = (int16_t)(i0 + e0); J.qe = (int16_t)(k0 + e0); J.tb = (int16_t)(i0 + s0); J.qb = (int16_t)(k0 + s0);
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(64) k_resc_cert(DIndex ix, DOpts o, i64 n_jobs
         const int X8 = K0 > Y2 ? K0 : Y2;
         int rlo = 0, rn = tlen;
         if (6 + vside < K0) {
-            const int w = X8 - K0 + vside;
+            const int w = (weaken & 8) ? 0 : X8 - K0 + vside;
             int r0 = d0 - w, r1 = d0 + qlen + w;
             r0 = r0 < 0 ? 0 : r0;
             r1 = r1 > tlen ? tlen : r1;
