@@ -44,7 +44,7 @@ def parse():
                                                           "are then execution times); 2 = every batch is cut at a barcode boundary and its halves are aligned side by side "
                                                           "inside ONE lh_align_resident call (+5 %: reported under two_lanes_pairs_per_s)")
     ap.add_argument("--repeats", action="store_true", help="only the configs[4] legs (repeats: every read on the copies of repeat families, tens to hundreds of candidates per read; mixed: 5 %% of every barcode's pairs on them); with --gpus N every rank runs them on its own batches")
-    ap.add_argument("--legs", default="repeats,mixed", help="with --repeats: which of the configs[4] legs to run")
+    ap.add_argument("--legs", default="repeats,mixed,mix_sweep", help="with --repeats: which of the configs[4] legs to run (mix_sweep: 1 %%, 20 %% and log-normal barcode sizes)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --steps batches in total, split over the ranks (default weak: --steps per rank)")
     ap.add_argument("--cpu-sample-barcodes", type=int, default=10000, help="barcodes of the first batch timed on the host cores (cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -637,7 +637,29 @@ def end_to_end(lib, idx, a, pac, l_pac, ctg, opts, local_rank):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def config4_legs(lib, a, local_rank, opts, steps=3, div=5, legs=("repeats", "mixed"), rank=0, dist=None, share=False):
+_VALU = {}
+
+
+def valu_ceiling():
+    """the measured VALU issue rate of K6's instruction mix on this chip (tools/valu_rate.py -> profiles/r06_valu_rate.log, committed): G wave64-instructions/s at 8 waves
+    per SIMD, and the same for a full-rate opcode (v_add_u32) — the guide's 2-cycle figure holds for add / sub / logic / mov / fma and e32 16-bit opcodes only"""
+    if not _VALU:
+        mix, add = None, None
+        try:
+            for line in open(os.path.join(ROOT, "profiles", "r06_valu_rate.log")):
+                f = line.split()
+                if line.startswith("k_resc_sw column mix") and f[-8] == "8":
+                    mix = float(f[-7])
+                if line.startswith("v_add_u32 ") and f[1] == "8":
+                    add = float(f[2])
+        except (OSError, ValueError, IndexError):
+            pass
+        _VALU.update({"source": "profiles/r06_valu_rate.log (lh_diag_valu_rate)" if mix else "not found: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles", "k_resc_sw_mix_G_wave_instr_per_s": mix or 614.4,
+                      "v_add_u32_G_wave_instr_per_s": add})
+    return dict(_VALU)
+
+
+def config4_legs(lib, a, local_rank, opts, steps=3, div=5, legs=("repeats", "mixed", "mix_sweep"), rank=0, dist=None, share=False):
     """BASELINE.json configs[4] on this GPU, in the default run: the hg38-scale genome of workload.config4_genome — 120 segmental-duplication
     families of 50-200 copies x 20 kb at 98-99.5 %, 40 LINE-like and 80 SINE-like families, 40 ALT contigs (is_alt) — its own index (the headline
     index has been freed by now), and two legs on it:
@@ -657,44 +679,71 @@ def config4_legs(lib, a, local_rank, opts, steps=3, div=5, legs=("repeats", "mix
         t_setup = time.time() - t0
         if "repeats" in legs:
             out["repeats"] = _c4_leg(lib, a, opts, steps, g, idx, max(1, a.barcodes // div), 1.0, t_setup, rank, dist, share)
-        if "mixed" in legs:
+
+        def extra_leg(name, **kw):   # (a newer leg must not cost the older ones; under the launcher a rank that fails must not leave the others in a collective: it exits)
             try:
-                out["mixed"] = _c4_leg(lib, a, opts, 2, g, idx, a.barcodes, 0.05, t_setup, rank, dist, share)
-            except Exception as e:   # (the newer leg must not cost the older one)
-                if "repeats" not in out:
+                out[name] = _c4_leg(lib, a, opts, 2, g, idx, max(1, a.barcodes // kw.pop("div", 1)), kw.pop("frac"), t_setup, rank, dist, share, **kw)
+            except Exception as e:
+                if "repeats" not in out or dist is not None:
                     raise
-                out["mixed"] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                out[name] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if "mixed" in legs:
+            extra_leg("mixed", frac=0.05, lanes2=(dist is None))
+        # (r06) the regime's shape: the same headline-sized batches at 1 % and 20 % repeat pairs, and at 5 % with log-normal barcode sizes (median 100 pairs, 20 .. 1,000)
+        if "mix_sweep" in legs:
+            extra_leg("mixed_1pct", frac=0.01, brief=True)
+            extra_leg("mixed_20pct", frac=0.20, div=4, brief=True)   # (a quarter of the headline batch: at 20 % a 2 M-pair batch holds 118 M seeds, whose workspace does not fit beside the index)
+            extra_leg("mixed_lognormal_barcodes", frac=0.05, sizes="lognormal", brief=True)
         return out
     finally:   # (whatever happens, the index and the context's pools leave HBM: the caller may try again with smaller batches)
         idx.close()
 
 
-def _c4_reads(lib, a, g, n_bc, frac, seed):
-    """one batch of the configs[4] legs: frac of every barcode's pairs on the repeat copies (g["windows"]), the rest on unique sequence (the primary contigs outside those windows)"""
+def _c4_reads(lib, a, g, n_bc, frac, seed, sizes=None):
+    """one batch of the configs[4] legs: frac of every barcode's pairs on the repeat copies (g["windows"]), the rest on unique sequence (the primary contigs outside those windows).
+    sizes = "lognormal": the same pairs as barcodes of log-normal size — 20-pair units (each with its own molecules and its share of repeat pairs) joined into
+    barcodes of 20 .. 1,000 pairs, median 100 (reader.go:176-260 cuts work units at barcode changes: sizes are whatever the library's partitions held)"""
+    import numpy as np
     from lariat_amd import workload
-    n_rep = int(round(a.pairs_per_barcode * frac))
-    if n_rep >= a.pairs_per_barcode:
-        return lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=seed, n_barcodes=n_bc, pairs_per_barcode=a.pairs_per_barcode)
-    if "unique" not in g:   # the primary contigs outside every window the repeat reads come from: nothing was planted there
-        g["unique"] = workload.outside_windows(g["contigs"], g["alt_flags"], g["windows"])
-    primary = g["unique"]
-    ra = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=seed, n_barcodes=n_bc, pairs_per_barcode=n_rep)
-    rb = lib.synth_reads(g["pac"], g["l_pac"], primary, seed=seed + 100000, n_barcodes=n_bc, pairs_per_barcode=a.pairs_per_barcode - n_rep)
-    return workload.interleave_reads(ra, rb)
+    ppb = a.pairs_per_barcode
+    if sizes == "lognormal":
+        ppb, n_bc = 20, n_bc * a.pairs_per_barcode // 20
+    n_rep = int(round(ppb * frac))
+    if n_rep >= ppb:
+        r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=seed, n_barcodes=n_bc, pairs_per_barcode=ppb)
+    else:
+        if "unique" not in g:   # the primary contigs outside every window the repeat reads come from: nothing was planted there
+            g["unique"] = workload.outside_windows(g["contigs"], g["alt_flags"], g["windows"])
+        primary = g["unique"]
+        ra = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=seed, n_barcodes=n_bc, pairs_per_barcode=n_rep)
+        rb = lib.synth_reads(g["pac"], g["l_pac"], primary, seed=seed + 100000, n_barcodes=n_bc, pairs_per_barcode=ppb - n_rep)
+        r = workload.interleave_reads(ra, rb)
+    if sizes == "lognormal":
+        rng = np.random.default_rng(seed)
+        units = np.clip(np.round(rng.lognormal(np.log(100.0), 0.8, size=n_bc) / 20.0), 1, 50).astype(np.int64)
+        ends = np.cumsum(units)
+        ends = ends[: int(np.searchsorted(ends, n_bc, side="left"))]
+        cuts = np.concatenate([[0], ends, [n_bc]]) if (len(ends) == 0 or ends[-1] < n_bc) else np.concatenate([[0], ends])
+        r = dict(r)
+        r["bc_pair_off"] = np.asarray(r["bc_pair_off"])[np.unique(cuts)].astype(np.int32)
+    return r
 
 
-def _c4_leg(lib, a, opts, steps, g, idx, n_bc, frac, t_setup, rank=0, dist=None, share=False):
+def _c4_leg(lib, a, opts, steps, g, idx, n_bc, frac, t_setup, rank=0, dist=None, share=False, sizes=None, lanes2=False, brief=False):
     import numpy as np
     import torch
     from lariat_amd import capi, workload
     n_pairs = n_bc * a.pairs_per_barcode
     world = dist.get_world_size() if dist is not None else 1
     ctx = idx.context(n_pairs)
+    batches = []
     try:
         t0 = time.time()
         for slot in range(steps):
-            r = _c4_reads(lib, a, g, n_bc, frac, workload.READS_SEED + (400 if frac >= 1.0 else 700) + slot + 1000 * rank)
-            ctx.upload_slot(slot, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
+            r = _c4_reads(lib, a, g, n_bc, frac, workload.READS_SEED + (400 if frac >= 1.0 else 700) + slot + 1000 * rank, sizes)
+            batches.append(capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
+            bc_sizes = np.diff(r["bc_pair_off"])
+            ctx.upload_slot(slot, batches[-1])
         t_reads = time.time() - t0
         ctx.select(0)
         ctx.align_resident(opts)   # warm-up: pools grow to this workload's seed, region and job counts
@@ -717,7 +766,7 @@ def _c4_leg(lib, a, opts, steps, g, idx, n_bc, frac, t_setup, rank=0, dist=None,
             dt = max(per_rank)
         res = ctx.download()
         nc = np.diff(res.cand_off)
-        mol = np.maximum.reduceat(res.molecule_id, res.cand_off[:-1][::2 * a.pairs_per_barcode]) + 1   # molecules that survive scrapMolecules, per barcode
+        mol = np.maximum.reduceat(res.molecule_id, res.cand_off[:-1][2 * np.asarray(r["bc_pair_off"][:-1], dtype=np.int64)]) + 1   # molecules that survive scrapMolecules, per barcode
         cnt = res.counters
         k6 = sum(kern["k_rescue"]) / len(kern["k_rescue"]) * 1e-3
         out = {"value": round(world * steps * n_pairs / dt, 1), "unit": "read-pairs/s", "n_gpus": world, "steps": steps, "pairs_per_step": n_pairs, "barcodes_per_step": n_bc,
@@ -729,11 +778,15 @@ def _c4_leg(lib, a, opts, steps, g, idx, n_bc, frac, t_setup, rank=0, dist=None,
                             "global_cells": round(cnt["glob_cells"] / n_pairs), "bwt_extend": round(cnt["n_ext"] / n_pairs)},
                "molecules_per_barcode": {"mean": round(float(mol.mean()), 1), "max": int(mol.max())},
                "n_rescue": cnt["n_rescue"], "rescue_cells": cnt["rescue_cells"], "rescue_cells_exec": cnt.get("rescue_cells_exec"),
-               # rescue_cells = the cells ksw_align2 evaluates in the reference (equal to the oracle's count); the stage's rate in those cells, and the stage against the VALU
-               # issue rate of the ksw_u8 recurrence (9.25 packed-16 lane-instructions per cell in the model; the SQ counters give 9.5 for the two Smith-Waterman kernels: profiles/r05_pmc_repeats.json; 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz) — for the WHOLE K6 bracket
-               # (enumeration, Smith-Waterman launches, replay); the Smith-Waterman launches alone: profiles/r05_*_repeats_*.csv
+               # rescue_cells = the cells ksw_align2 evaluates in the reference (equal to the oracle's count), rescue_cells_exec = the cells K6 ran (r06: a certificate per job
+               # settles most of them without DP, k_rescue3.h); rescue_GCUPS = the stage's rate in the REFERENCE's cells; rescue_stage_valu_frac = the executed cells' packed-16
+               # instructions (9.25 lane-instructions per cell) against the MEASURED issue rate of that instruction mix (lh_diag_valu_rate, profiles/r06_valu_rate.log: packed-16,
+               # min / max, three-operand and permute opcodes issue every ~4.2 cycles per SIMD on gfx950, not every 2) — for the WHOLE K6 bracket (enumeration, certificate,
+               # Smith-Waterman launches, replay), so it is small now that the Smith-Waterman is a quarter of the bracket
                "rescue_GCUPS": round(cnt["rescue_cells"] / k6 / 1e9, 1),
-               "rescue_stage_valu_frac": round(cnt["rescue_cells"] * 9.25 / k6 / (256 * 4 * 16 * 2.4e9), 3),
+               "rescue_cells_exec_frac": round(cnt["rescue_cells_exec"] / max(1, cnt["rescue_cells"]), 4),
+               "rescue_stage_valu_frac": round(cnt["rescue_cells_exec"] * 9.25 / 64.0 / k6 / valu_ceiling()["k_resc_sw_mix_G_wave_instr_per_s"] / 1e9, 3),
+               "valu_ceiling": valu_ceiling(),
                "setup_s": {"genome+index": round(t_setup, 1), "reads": round(t_reads, 1)},
                "workload": "BASELINE.json configs[4] on one GPU: %d Mb genome with 120 segmental-duplication families (50-200 copies x 20 kb, 98-99.5 %%), 40 x 6-kb and 80 x 300-bp "
                            "repeat families, 40 ALT contigs (is_alt); %s; %d steps x %d pairs"
@@ -742,9 +795,32 @@ def _c4_leg(lib, a, opts, steps, g, idx, n_bc, frac, t_setup, rank=0, dist=None,
                               steps, n_pairs)}
         if per_rank:
             out["per_rank_timed_s"] = per_rank
+        out["barcode_pairs"] = {"min": int(bc_sizes.min()), "median": int(np.median(bc_sizes)), "max": int(bc_sizes.max())}
+        if lanes2:   # (r06) the same batches through two lanes: a VALU-bound k_resc_sw of one half beside the latency-bound K1 / K3 / K8 of the other
+            ctx.close()
+            ctx = None
+            try:
+                c2 = idx.context(n_pairs, lanes=2)
+                try:
+                    for slot in range(steps):
+                        c2.upload_slot(slot, batches[slot])
+                    c2.select(0)
+                    c2.align_resident(opts)
+                    t0 = time.perf_counter()
+                    for sl in range(steps):
+                        c2.select(sl)
+                        c2.align_resident(opts)
+                    out["two_lanes_ms_per_step"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+                finally:
+                    c2.close()
+            except Exception as e:
+                out["two_lanes_ms_per_step"] = "failed: %s" % str(e)[:200]
+        if brief:
+            out = {k: out[k] for k in ("value", "unit", "ms_per_step", "pairs_per_step", "barcodes_per_step", "repeat_pair_frac", "barcode_pairs", "kernel_ms", "candidates_per_read", "rescue_cells_exec_frac")}
         return out
     finally:
-        ctx.close()
+        if ctx is not None:
+            ctx.close()
 
 
 def extras(lib, idx, batch, n_pairs, opts, step_s):

@@ -105,6 +105,10 @@ typedef struct lh_context_opts {
                            * that one part's kernels fill the idle tails of the others'; results are merged.  No stage dumps then. */
     int32_t big_slots;    /* K1: slots of the slab for reads with more than 64 SMEM intervals (max_pairs / 128, at least 64); the slab grows when a
                            * batch needs more, tests force that with a small value */
+    int32_t rfa_tier_kb[2];   /* (ABI 5) K8: slab sizes in KiB of the two tiers between the regular slabs and the few large ones (16384, 131072); -1 = no such tier.
+                               * The slabs are allocated when a batch first lists a barcode for the tier, as many as the list is long (at most rfa_tier_grid;
+                               * together at most 32 KiB per read of the context's capacity); tests force the tiers with small values */
+    int32_t rfa_tier_grid[2]; /* at most this many slabs (= waves) per tier (1024, 64) */
     int32_t reserved;
 } lh_context_opts;
 void lh_context_opts_init(lh_context_opts* co);

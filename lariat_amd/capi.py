@@ -54,7 +54,7 @@ class LhIndexOpts(C.Structure):
 
 class LhContextOpts(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("smem_grid", C.c_int32), ("aln_grid", C.c_int32), ("rfa_grid", C.c_int32), ("rfa_slab_kb", C.c_int32),
-                ("lanes", C.c_int32), ("big_slots", C.c_int32), ("reserved", C.c_int32)]
+                ("lanes", C.c_int32), ("big_slots", C.c_int32), ("rfa_tier_kb", C.c_int32 * 2), ("rfa_tier_grid", C.c_int32 * 2), ("reserved", C.c_int32)]
 
 
 class LhBatch(C.Structure):
@@ -476,7 +476,12 @@ class Library:
         for k, v in kw.items():
             if not hasattr(co, k):
                 raise AttributeError(k)
-            setattr(co, k, v)
+            if isinstance(v, (tuple, list)):
+                arr = getattr(co, k)
+                for i, x in enumerate(v):
+                    arr[i] = int(x)
+            else:
+                setattr(co, k, v)
         return co
 
     def index_load(self, prefix, device=0, **index_opts):

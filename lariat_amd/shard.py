@@ -40,11 +40,12 @@ def slice_batch(seq, seq_off, bc_pair_off, name_seed, b0, b1):
     return (seq[s0:s1], seq_off[2 * p0:2 * p1 + 1] - s0, (np.asarray(bc_pair_off[b0:b1 + 1]) - p0).astype(np.int32), name_seed[p0:p1])
 
 
-def align_rank_shard(lib, idx, seq, seq_off, bc_pair_off, name_seed, rank, world, opts=None, max_pairs_per_batch=1 << 20):
+def align_rank_shard(lib, idx, seq, seq_off, bc_pair_off, name_seed, rank, world, opts=None, max_pairs_per_batch=1 << 20, weights=None):
     """what ONE rank of a `world`-GPU job does: its barcode range of the sorted input through lh_align_barcodes, batch by batch
-    (whole barcodes per batch).  Returns ((b0, b1), [Result ...]); nothing is exchanged with other ranks."""
+    (whole barcodes per batch).  `weights`: a cost per barcode for barcode_ranges (default: its pairs) — every rank must pass the same.
+    Returns ((b0, b1), [Result ...]); nothing is exchanged with other ranks."""
     from . import capi
-    b0, b1 = barcode_ranges(bc_pair_off, world)[rank]
+    b0, b1 = barcode_ranges(bc_pair_off, world, weights=weights)[rank]
     out = []
     if b1 <= b0:
         return (b0, b1), out

@@ -73,10 +73,11 @@ def test_emu_inference_slab_overflow_pass(emu, oracle):
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
 
 
-def test_emu_inference_slab_tiers(emu, oracle, monkeypatch):
+def test_emu_inference_slab_tiers(emu, oracle):
     """(r05) between the regular slabs and the few large ones there are two tiers; a barcode that outgrows one is listed for the next.  With tiers of 48 and 256 KiB
-    (LH_RFA_MID_KB, a test aid) and 4-KiB regular slabs the suite's barcodes go through all of them: some finish in the second tier, the largest in the last launch"""
-    monkeypatch.setenv("LH_RFA_MID_KB", "48,256")
+    (lh_context_opts.rfa_tier_kb) and 4-KiB regular slabs the suite's barcodes go through all of them: some finish in the second tier, the largest in the last launch.
+    (r06) The tiers' slabs are allocated when a batch first needs them, as many as it lists barcodes (here: at most 2 and 1, so that the lists are longer than the tiers
+    have waves), and grown by a later batch that lists more."""
     names, contigs = helpers.small_genome()
     oidx = oracle.index_build_naive(names, contigs)
     idx = emu.index_from_arrays(oidx.arrays())
@@ -84,11 +85,20 @@ def test_emu_inference_slab_tiers(emu, oracle, monkeypatch):
     rs = synth.make_reads(contigs, names, n_barcodes=5, pairs_per_barcode=30, seed=77, junk_frac=0.05)
     big = synth.make_reads(contigs, names, n_barcodes=1, pairs_per_barcode=400, seed=78, junk_frac=0.05)
     b = helpers.batch_of(rs)
-    res = idx.context(rs.n_pairs, rfa_slab_kb=4).align_barcodes(b)
+    res = idx.context(rs.n_pairs, rfa_slab_kb=4, rfa_tier_kb=(48, 256)).align_barcodes(b)
     helpers.assert_same_result(res, oidx.align_barcodes(b), inference=True)
     b2 = helpers.batch_of(big)
-    res2 = idx.context(big.n_pairs, rfa_slab_kb=4).align_barcodes(b2)
+    res2 = idx.context(big.n_pairs, rfa_slab_kb=4, rfa_tier_kb=(48, 256)).align_barcodes(b2)
     helpers.assert_same_result(res2, oidx.align_barcodes(b2), inference=True)
+    # one context through a batch that needs no tier, one that needs them, and a larger one (the tiers grow); few waves per tier; one tier switched off
+    both = synth.make_reads(contigs, names, n_barcodes=9, pairs_per_barcode=40, seed=79, junk_frac=0.05)
+    ctx = idx.context(both.n_pairs, rfa_slab_kb=4, rfa_tier_kb=(48, 256), rfa_tier_grid=(2, 1))
+    for batch in (rs, both, rs):
+        bb = helpers.batch_of(batch)
+        helpers.assert_same_result(ctx.align_barcodes(bb), oidx.align_barcodes(bb), inference=True)
+    ctx.close()
+    bb = helpers.batch_of(both)
+    helpers.assert_same_result(idx.context(both.n_pairs, rfa_slab_kb=4, rfa_tier_kb=(-1, 256)).align_barcodes(bb), oidx.align_barcodes(bb), inference=True)
 
 
 def test_emu_long_noisy_reads(emu, oracle):

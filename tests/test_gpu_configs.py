@@ -280,7 +280,28 @@ def test_config4_repeat_families_at_its_multiplicity(lib, oracle):
     print("oracle: %.1f s on %d threads" % (time.time() - t0, THREADS))
     helpers.assert_same_result(res, ref, inference=True)
     assert cnt["n_rescue"] == ref.counters["n_rescue"] and cnt["rescue_cells"] == ref.counters["rescue_cells"]
+    # (r06) the same batch with every rescue window run whole (LH_F_RESCUE_FULL): the same result from five to ten times the Smith-Waterman cells
+    full = ctx.align_barcodes(b, lib.opts(flags=capi.LH_F_RESCUE_FULL))
+    helpers.assert_same_result(full, ref, inference=True)
+    print("rescue cells: the reference's %.3g, executed %.3g with the certificate, %.3g without" % (cnt["rescue_cells"], cnt["rescue_cells_exec"], full.counters["rescue_cells_exec"]))
+    assert 0 < cnt["rescue_cells_exec"] < 0.25 * full.counters["rescue_cells_exec"]
     ctx.close()
+    # (r06) barcodes of 200 and 400 pairs on the copies: their molecule x read tables outgrow the regular 2 MiB slabs, so they pass through K8's slab tiers at
+    # their real sizes (16 MiB, 128 MiB; allocated when the batch lists them), 40 barcodes of each against the oracle, every field
+    parts = [lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 44 + k, n_barcodes=40, pairs_per_barcode=ppb) for k, ppb in enumerate((200, 400))]
+    seq2 = np.concatenate([p["seq"] for p in parts])
+    so2 = np.concatenate([parts[0]["seq_off"], parts[1]["seq_off"][1:] + parts[0]["seq_off"][-1]])
+    bco2 = np.concatenate([parts[0]["bc_pair_off"], parts[1]["bc_pair_off"][1:] + parts[0]["bc_pair_off"][-1]]).astype(np.int32)
+    b2 = capi.Batch.from_arrays(seq2, so2, bco2, np.concatenate([p["name_seed"] for p in parts]))
+    c2 = idx.context(int(bco2[-1]))
+    try:
+        free0 = lib.device_memory()[0]
+        res2 = c2.align_barcodes(b2)
+        tier_bytes = free0 - lib.device_memory()[0]
+    finally:
+        c2.close()
+    print("200- and 400-pair barcodes: %d pairs, %.1f candidates per read; HBM taken during the batch (tier slabs among it): %.2f GiB" % (int(bco2[-1]), np.diff(res2.cand_off).mean(), tier_bytes / 2**30))
+    helpers.assert_same_result(res2, oidx.align_barcodes(b2, threads=THREADS), inference=True)
     # the MIXED workload of bench.py's `mixed` leg on the same index: 5 of every barcode's 100 pairs drawn on the repeat copies, 95 on unique sequence (the primary
     # contigs outside the copies' windows), interleaved per barcode (workload.interleave_reads) — repeat-regime reads and unique reads side by side in every kernel's waves and in every
     # barcode's inference: 200 barcodes against the oracle, every field
@@ -291,10 +312,15 @@ def test_config4_repeat_families_at_its_multiplicity(lib, oracle):
     m = workload.interleave_reads(ra, rb)
     assert m["n_pairs"] == 20000 and int(m["from_first"].sum()) == 1000 and (np.diff(m["bc_pair_off"]) == 100).all()
     bm = capi.Batch.from_arrays(m["seq"], m["seq_off"], m["bc_pair_off"], m["name_seed"])
-    got = idx.context(m["n_pairs"]).align_barcodes(bm)
+    cm = idx.context(m["n_pairs"])
+    try:
+        got = cm.align_barcodes(bm)
+    finally:
+        cm.close()   # (its pools leave HBM before the oracle's pass: the module runs beside an hg38-scale index)
     ncm = np.diff(got.cand_off).reshape(-1, 2).sum(axis=1)
     print("mixed: %.1f candidates per pair on the copies, %.1f elsewhere" % (ncm[m["from_first"]].mean(), ncm[~m["from_first"]].mean()))
     assert ncm[m["from_first"]].mean() > 10 * ncm[~m["from_first"]].mean() and np.median(ncm[~m["from_first"]]) <= 4
     refm = oidx.align_barcodes(bm, threads=THREADS)
     helpers.assert_same_result(got, refm, inference=True)
     assert got.counters["n_rescue"] == refm.counters["n_rescue"] and got.counters["rescue_cells"] == refm.counters["rescue_cells"]
+    assert 0 < got.counters["rescue_cells_exec"] < 0.5 * got.counters["rescue_cells"]   # (r06) K6 ran a fraction of the reference's Smith-Waterman cells (k_rescue3.h)
