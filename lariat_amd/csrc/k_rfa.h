@@ -413,6 +413,30 @@ __global__ void __launch_bounds__(64) k_rfa_tag_w(DOpts o, const u64* __restrict
 // A barcode whose tables do not fit the wave's slab (the reader caps a work unit at 30,000 pairs, fastqreader/reader.go:205,
 // far above the common few hundred) is appended to ovf_list and processed by a second launch whose few waves own much
 // larger slabs (work_list = that list); only there an overflow is final (LH_ST_POOL_OVERFLOW).
+// (r06) the order in which the barcode programs take their barcodes: most candidates first.  A barcode's time grows faster than its candidate count (the position sorts,
+// the molecule x read tables), a wave takes one barcode at a time, and the launch lasts until its last barcode is done: in index order the largest barcode of a batch
+// could start last (kernel_ms_by_step of the repeats leg: 119 / 93 / 90 ms on three read sets).  A counting sort by size class (a quarter of an octave of the
+// candidate count), one block; order[n_bc] = n_bc, the list's length as k_rfa's work_count wants it.
+__global__ void __launch_bounds__(256) k_rfa_order(int n_bc, const int32_t* __restrict__ bc_pair_off, DCand R, int32_t* __restrict__ order) {
+    __shared__ int32_t cnt[128], start[128];
+    const int t = threadIdx.x;
+    if (t < 128) cnt[t] = 0;
+    __syncthreads();
+    auto cls_of = [&](int bc) {
+        const i64 nc = R.cand_off[2 * (i64)bc_pair_off[bc + 1]] - R.cand_off[2 * (i64)bc_pair_off[bc]];
+        const u64 x = (u64)(nc > 0 ? nc : 0) + 1;
+        const int lg = 63 - __clzll((long long)x);                       // floor(log2(x)), x >= 1
+        const int frac = lg >= 2 ? (int)((x >> (lg - 2)) & 3) : 0;
+        const int c = 4 * lg + frac;
+        return 127 - (c < 127 ? c : 127);                                // large classes first
+    };
+    for (int bc = t; bc < n_bc; bc += 256) atomicAdd(&cnt[cls_of(bc)], 1);
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int c = 0; c < 128; ++c) { start[c] = acc; acc += cnt[c]; } order[n_bc] = n_bc; }
+    __syncthreads();
+    for (int bc = t; bc < n_bc; bc += 256) order[atomicAdd(&start[cls_of(bc)], 1)] = bc;
+}
+
 // development aid (tools/prof_rfa.sh builds a library with -DLH_RFA_PROF): shader-clock time per phase of the barcode program, summed over the waves
 #ifdef LH_RFA_PROF
 __device__ unsigned long long lh_rfa_prof[24];
@@ -611,35 +635,47 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 if (lane == 0) { atomicAdd(&lh_rfa_hist2[0], 1ull); atomicMax(&lh_rfa_hist2[1], (unsigned long long)n); if (n > LH_RFA_SORT_LDS) atomicAdd(&lh_rfa_hist2[2], 1ull); if (n > LH_RFA_LDS_BYTES / 4) atomicAdd(&lh_rfa_hist2[3], 1ull); atomicAdd(&lh_rfa_hist2[4], (unsigned long long)n * n); }
 #endif
                 if (n < 2) continue;
-                if (n > LH_RFA_SORT_LDS && n <= LH_RFA_LDS_BYTES / 4) {
-                    // (r05) up to three times the buffer's usual length when the keys are taken relative to the contig's smallest position, 32 bits each, and the list itself
-                    // stays in memory (ranked into molraw, free until inferMolecules, and copied back): on configs[4]'s input the large contigs hold 800 - 1,500 of a
-                    // 100-pair barcode's 11,600 candidates, and their sorts in memory were a third of the kernel
-                    i64 mn = 0x7fffffffffffffffll, mx = -0x7fffffffffffffffll;
-                    for (int i = lane; i < n; i += 64) { const i64 x = R.pos[c_lo + pl[b0 + i]]; mn = mn < x ? mn : x; mx = mx > x ? mx : x; }
-                    mn = wave_min_i64(mn); mx = wave_max_i64(mx);
-                    if (mx - mn < 0xffffffffll) {
-                        uint32_t* const k32 = (uint32_t*)lds_raw;
-                        WAVE_SYNC();   // the previous contig's keys have been read
-                        for (int i = lane; i < n; i += 64) k32[i] = (uint32_t)(R.pos[c_lo + pl[b0 + i]] - mn);
-                        WAVE_SYNC();
-                        int tie = 0;
-                        for (int e = lane; e < n; e += 64) {
-                            const uint32_t key = k32[e];
-                            int rank = 0;
-                            for (int j = 0; j < n; ++j) { const uint32_t kj = k32[j]; rank += kj < key; tie |= (kj == key) & (j != e); }
-                            T.molraw[b0 + rank] = pl[b0 + e];
-                        }
-                        const int tied = __any(tie);
+                if (n > 64 && n < (1 << 20)) {
+                    // (r06) a list of more than a wave's worth is put in order by a sorting NETWORK on packed words ((position - smallest) << 20 | place in the list) — up to
+                    // 1,024 of them in LDS, longer lists in the slab (sval, free until the molecules are scored) — instead of by ranking (every lane counting the smaller keys
+                    // of its elements: n^2 / 64 steps; 2,000 entries of one contig, common for a 1,000-pair barcode with a twentieth of its pairs on repeat families, were
+                    // 62,000 steps a list and the position sorts a third of the kernel).  With all keys different there is only one sorted order, whatever the algorithm;
+                    // two equal positions (adjacent after the sort): Go's algorithm on the list as it was, below.
+                    i64 mn = 0x7fffffffffffffffll;
+                    for (int i = lane; i < n; i += 64) { const i64 x = R.pos[c_lo + pl[b0 + i]]; mn = mn < x ? mn : x; }
+                    mn = wave_min_i64(mn);
+                    u64* const bk = n <= LH_RFA_LDS_BYTES / 8 ? (u64*)lds_raw : (u64*)kpg + b0;
+                    WAVE_SYNC();   // the previous contig's keys have been read
+                    for (int i = lane; i < n; i += 64) bk[i] = (u64)(R.pos[c_lo + pl[b0 + i]] - mn) << 20 | (u64)i;
+                    WAVE_SYNC();
+                    wave_bitonic_u64(bk, n, lane);
+                    int tie = 0;
+                    for (int e = lane; e < n; e += 64) {
+                        const u64 w = bk[e];
+                        if (e + 1 < n) tie |= (bk[e + 1] >> 20) == (w >> 20);
+                        T.molraw[b0 + e] = pl[b0 + (int)(w & 0xfffffu)];
+                    }
+                    const int tied = __any(tie);
 #ifdef LH_RA_HIST
-                        if (tied && lane == 0) atomicAdd(&lh_rfa_hist2[5], 1ull);
+                    if (tied && lane == 0) atomicAdd(&lh_rfa_hist2[5], 1ull);
 #endif
+                    WAVE_SYNC();
+                    if (!tied) {
+                        for (int e = lane; e < n; e += 64) pl[b0 + e] = T.molraw[b0 + e];
                         WAVE_SYNC();
-                        if (!tied) {
-                            for (int e = lane; e < n; e += 64) pl[b0 + e] = T.molraw[b0 + e];
-                            WAVE_SYNC();
-                            continue;
-                        }
+                        continue;
+                    }
+                    if (n <= LH_RFA_SORT_LDS) {   // Go's algorithm on the keys in LDS, its ranges spread over the lanes
+                        for (int i = lane; i < n; i += 64) { const int a = pl[b0 + i]; sidx[i] = a; spos[i] = R.pos[c_lo + a]; }
+                        WAVE_SYNC();
+                        if (lane == 0) { shi[6] = 0; shi[7] = n; }
+                        WAVE_SYNC();
+                        wave_gosort(1, shi + 6, [&](int i, int j) { return spos[i] < spos[j]; },
+                                    [&](int i, int j) { i64 t = spos[i]; spos[i] = spos[j]; spos[j] = t; int u = sidx[i]; sidx[i] = sidx[j]; sidx[j] = u; }, T.molraw, T.rdl, T.firstf);
+                        WAVE_SYNC();
+                        for (int e = lane; e < n; e += 64) pl[b0 + e] = sidx[e];
+                        WAVE_SYNC();
+                        continue;
                     }
                 }
                 if (n > LH_RFA_SORT_LDS) {
@@ -737,17 +773,28 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     e.mm = (int16_t)R.mismatches[ca]; e.id = (int16_t)R.indels[ca]; e.sc = (int16_t)R.soft_clipped[ca]; e.scl = (int16_t)R.soft_clipped_length[ca];
                     return e;
                 };
-                for (int mb = 0; mb < Mraw; mb += 64) {
-                    const int mr = mb + lane;
-                    int big = 0;
-                    if (mr < Mraw) big = T.mstart[mr + 1] - T.mstart[mr] > LH_RFA_MOL_LDS_MIN;
-                    u64 bmk = __ballot(big);
-                    while (bmk) {
-                        const int mr2 = mb + __ffsll((unsigned long long)bmk) - 1;
-                        bmk &= bmk - 1;
-                        const int ms0 = T.mstart[mr2], msz = T.mstart[mr2 + 1] - ms0;
+                // (r06) EVERY molecule's entries go through LDS, not only the large ones: the entries of a barcode are cut into tiles of whole molecules (they are contiguous
+                // in position order), a tile is staged once and every lane scans ITS entry's molecule inside it — a handful to a few dozen LDS records where it was as many
+                // dependent reads of ten scattered fields from memory per entry (46 % of the kernel on repeat families, 37 % on 1,000-pair barcodes with a twentieth of their
+                // pairs on them).  A molecule longer than a tile goes through tiles of its own, as in r05.
+                auto score_pair = [&](const MEnt& A, int arev, const MEnt& B) {
+                    double score = 0.0;
+                    score += (double)(A.mm * -2 + A.id * -3);
+                    if (A.sc > 0) { score -= 5.0 * (double)A.sc; score -= (double)A.scl * 0.5; }
+                    score += (double)(B.mm * -2 + B.id * -3);
+                    if (B.sc > 0) { score -= 5.0 * (double)B.sc; score -= (double)B.scl * 0.5; }
+                    int pr = 0;
+                    if (arev != (int)(B.rd >> 31) && A.rid == B.rid) { const i64 dist = arev ? A.pos - B.pos : B.pos - A.pos; pr = dist >= -35 && dist < 750; }
+                    if (!pr) score += improper;
+                    return score;
+                };
+                for (int i0 = 0; i0 < NCf;) {
+                    const int m0 = T.molraw[i0];
+                    const int msz = T.mstart[m0 + 1] - i0;   // (i0 is the first entry of molecule m0)
+                    if (msz > ME_CAP) {
                         // a molecule longer than the buffer goes through it in tiles: every entry keeps its maximum so far in sval, "a mate's entry seen" in psum (free until
                         // the counting below) and "first" in firstf
+                        const int ms0 = i0;
                         for (int t0 = 0; t0 < msz; t0 += ME_CAP) {
                             const int tn = msz - t0 < ME_CAP ? msz - t0 : ME_CAP;
                             WAVE_SYNC();   // the previous tile's entries have been read
@@ -767,14 +814,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                                         const int lj = (int)(B.rd & 0x7fffffffu);
                                         if (lj == lrm) {
                                             found = 1;
-                                            double score = 0.0;
-                                            score += (double)(A.mm * -2 + A.id * -3);
-                                            if (A.sc > 0) { score -= 5.0 * (double)A.sc; score -= (double)A.scl * 0.5; }
-                                            score += (double)(B.mm * -2 + B.id * -3);
-                                            if (B.sc > 0) { score -= 5.0 * (double)B.sc; score -= (double)B.scl * 0.5; }
-                                            int pr = 0;
-                                            if (arev != (int)(B.rd >> 31) && A.rid == B.rid) { const i64 dist = arev ? A.pos - B.pos : B.pos - A.pos; pr = dist >= -35 && dist < 750; }
-                                            if (!pr) score += improper;
+                                            const double score = score_pair(A, arev, B);
                                             if (score > best) best = score;
                                         } else if (lj == lr && t0 + j < e) first = 0;
                                     }
@@ -783,7 +823,39 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                                 }
                             }
                         }
+                        i0 += msz;
+                        continue;
                     }
+                    // whole molecules from i0 on: up to the start of the molecule that holds entry i0 + ME_CAP
+                    int i1 = NCf;
+                    if (i0 + ME_CAP < NCf) i1 = T.mstart[T.molraw[i0 + ME_CAP]];
+                    const int tn = i1 - i0;
+                    WAVE_SYNC();   // the previous tile's entries have been read
+                    for (int j = lane; j < tn; j += 64) me[j] = load_ent(i0 + j);
+                    WAVE_SYNC();
+                    for (int e0 = 0; e0 < tn; e0 += 64) {
+                        const int e = e0 + lane;
+                        if (e < tn) {
+                            const int i = i0 + e, m = T.molraw[i];
+                            const int j0 = T.mstart[m] - i0, j1 = T.mstart[m + 1] - i0;
+                            const MEnt A = me[e];
+                            const int lr = (int)(A.rd & 0x7fffffffu), lrm = lr ^ 1, arev = (int)(A.rd >> 31);
+                            double best = -1.7976931348623157e308;
+                            int found = 0, first = 1;
+                            for (int j = j0; j < j1; ++j) {
+                                const MEnt B = me[j];
+                                const int lj = (int)(B.rd & 0x7fffffffu);
+                                if (lj == lrm) {
+                                    found = 1;
+                                    const double score = score_pair(A, arev, B);
+                                    if (score > best) best = score;
+                                } else if (lj == lr && j < e) first = 0;
+                            }
+                            T.sval[i] = found ? best : R.lap[c_lo + T.plist[i]];
+                            T.firstf[i] = first;
+                        }
+                    }
+                    i0 = i1;
                 }
                 WAVE_SYNC();
             }
@@ -792,55 +864,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 int i = base + lane, first = 0, isact = 0;
                 const int pre = i < NCf ? T.firstf[i] : -1;
                 if (i < NCf && pre >= 0) { first = pre; isact = S.active[c_lo + T.plist[i]] != 0; }
-                else if (i < NCf) {
-                    int a = T.plist[i], m = T.molraw[i];
-                    int g = r0 + T.rdl[i], gm = g ^ 1;
-                    double best = -1.7976931348623157e308;
-                    int found = 0;
-                    first = 1;
-                    const int ms0 = T.mstart[m], ms1 = T.mstart[m + 1];
-                    if (ms1 - ms0 <= (int)(R.cand_off[g + 1] - R.cand_off[g]) + (int)(R.cand_off[gm + 1] - R.cand_off[gm])) {
-                        // (r05) the mate's alignments inside molecule m, and this read's own before entry i, are among the MOLECULE's entries — a handful on
-                        // repeat families, where a read has a hundred alignments spread over as many raw molecules (walking those to find the few of this
-                        // molecule was half of the kernel there).  The same set, the same maximum.
-                        const int lr = T.rdl[i], lrm = lr ^ 1;
-                        for (int j = ms0; j < ms1; ++j) {
-                            const int lj = T.rdl[j];
-                            if (lj == lrm) {
-                                found = 1;
-                                double s = dev_score_aln(R, S, improper, c_lo + a, c_lo + T.plist[j], 0.0);
-                                if (s > best) best = s;
-                            } else if (lj == lr && j < i) first = 0;
-                        }
-                    } else {
-                        // (r05) four candidates' molecule numbers are fetched before any is looked at: the loop is a chain of dependent reads from the slab otherwise —
-                        // on repeat families 65 of them per entry and mate, a third of the kernel; the candidates are still taken in order (the maximum is the first of equals)
-                        const i64 mb0 = R.cand_off[gm], mb1 = R.cand_off[gm + 1];
-                        for (i64 b = mb0; b < mb1; b += 4) {
-                            int mm[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) mm[u] = b + u < mb1 ? T.molc[b + u - c_lo] : -2;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if (mm[u] != m) continue;
-                                found = 1;
-                                double s = dev_score_aln(R, S, improper, c_lo + a, b + u, 0.0);
-                                if (s > best) best = s;
-                            }
-                        }
-                        const i64 ob0 = R.cand_off[g], ob1 = R.cand_off[g + 1];
-                        for (i64 b = ob0; b < ob1; b += 4) {
-                            int mm[4], pp[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) { const int ok = b + u < ob1; mm[u] = ok ? T.molc[b + u - c_lo] : -2; pp[u] = ok ? T.ppos[b + u - c_lo] : 0x7fffffff; }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) if (mm[u] == m && pp[u] < i) first = 0;
-                        }
-                    }
-                    T.sval[i] = found ? best : R.lap[c_lo + a];
-                    T.firstf[i] = first;
-                    isact = S.active[c_lo + a] != 0;
-                }
                 u64 mf = __ballot(first), ma = __ballot(isact);
                 if (i < NCf) { T.psum[i] = nfirst + lanes_below(mf, lane); T.actc[i] = nactive + lanes_below(ma, lane); }
                 nfirst += __popcll(mf); nactive += __popcll(ma);

@@ -367,3 +367,27 @@ template <class L, class S> __device__ inline void wave_gosort(int nsort, const 
         WAVE_SYNC();
     }
 }
+
+// ---- (r06) a sorting network by the whole wave, for lists whose keys are all different (then there is only one sorted order and no contract about equal keys):
+// the bitonic merge sort with every comparator pointing the same way (the first step of a merge mirrors the second half), so that the list needs no padding —
+// places from n on stand for +infinity and a comparator that reaches one does nothing.  a[0 .. n) in LDS or in memory, ascending; n log^2 n / 128 steps per lane.
+__device__ inline void wave_bitonic_u64(u64* a, int n, int lane) {
+    int np = 64;
+    while (np < n) np <<= 1;
+    for (int k = 2; k <= np; k <<= 1) {
+        const int half = k >> 1;
+        for (int c = lane; c < (np >> 1); c += 64) {   // the flip: place p of the first half of a block of k against place k - 1 - p of the block
+            const int blk = c / half, p = c - blk * half;
+            const int lo = blk * k + p, hi = blk * k + k - 1 - p;
+            if (hi < n) { const u64 x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
+        }
+        WAVE_SYNC();
+        for (int j = half >> 1; j >= 1; j >>= 1) {
+            for (int c = lane; c < (np >> 1); c += 64) {
+                const int lo = (c / j) * 2 * j + (c % j), hi = lo + j;
+                if (hi < n) { const u64 x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
+            }
+            WAVE_SYNC();
+        }
+    }
+}
