@@ -680,6 +680,9 @@ def config4_legs(lib, a, local_rank, opts, steps=3, div=5, legs=("repeats", "mix
         if "repeats" in legs:
             out["repeats"] = _c4_leg(lib, a, opts, steps, g, idx, max(1, a.barcodes // div), 1.0, t_setup, rank, dist, share)
 
+        if "repeats" in out:
+            print("[bench] repeats: %.1f ms per step" % out["repeats"]["ms_per_step"], file=sys.stderr, flush=True)
+
         def extra_leg(name, **kw):   # (a newer leg must not cost the older ones; under the launcher a rank that fails must not leave the others in a collective: it exits)
             try:
                 out[name] = _c4_leg(lib, a, opts, 2, g, idx, max(1, a.barcodes // kw.pop("div", 1)), kw.pop("frac"), t_setup, rank, dist, share, **kw)
@@ -687,6 +690,7 @@ def config4_legs(lib, a, local_rank, opts, steps=3, div=5, legs=("repeats", "mix
                 if "repeats" not in out or dist is not None:
                     raise
                 out[name] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            print("[bench] %s: %s" % (name, out[name].get("ms_per_step", out[name].get("failed"))), file=sys.stderr, flush=True)
         if "mixed" in legs:
             extra_leg("mixed", frac=0.05, lanes2=(dist is None))
         # (r06) the regime's shape: the same headline-sized batches at 1 % and 20 % repeat pairs, and at 5 % with log-normal barcode sizes (median 100 pairs, 20 .. 1,000)

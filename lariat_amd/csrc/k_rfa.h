@@ -179,6 +179,7 @@ __device__ __forceinline__ int dev_mol_active(int alen, int nbest, int change) {
 #define LH_RFA_SORT_LDS 768   // filtered candidates of a barcode whose position sort is staged in LDS (9 KB: 16 single-wave blocks per CU)
 #endif
 #define LH_RFA_LDS_BYTES (LH_RFA_SORT_LDS * 12)
+
 static_assert(LH_RFA_LDS_BYTES >= 15 * 64 * (int)sizeof(double), "estimateMapQualities keeps a read's top-15 scores per lane in lds_raw (top[k * 64 + lane])");
 #define LH_RFA_NCONT_LDS 1024  // contig slots of a barcode kept in LDS while grouping (index with more contigs: slab copy)
 #define LH_RFA_SRC_CHUNK 256   // source-molecule alignments staged per pass of fastScore
@@ -636,15 +637,15 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
 #endif
                 if (n < 2) continue;
                 if (n > 64 && n < (1 << 20)) {
-                    // (r06) a list of more than a wave's worth is put in order by a sorting NETWORK on packed words ((position - smallest) << 20 | place in the list) — up to
-                    // 1,024 of them in LDS, longer lists in the slab (sval, free until the molecules are scored) — instead of by ranking (every lane counting the smaller keys
+                    // (r06) a list of more than a wave's worth is put in order by a sorting NETWORK on packed words ((position - smallest) << 20 | place in the list), in the
+                    // slab (sval, free until the molecules are scored) — instead of by ranking (every lane counting the smaller keys
                     // of its elements: n^2 / 64 steps; 2,000 entries of one contig, common for a 1,000-pair barcode with a twentieth of its pairs on repeat families, were
                     // 62,000 steps a list and the position sorts a third of the kernel).  With all keys different there is only one sorted order, whatever the algorithm;
                     // two equal positions (adjacent after the sort): Go's algorithm on the list as it was, below.
                     i64 mn = 0x7fffffffffffffffll;
                     for (int i = lane; i < n; i += 64) { const i64 x = R.pos[c_lo + pl[b0 + i]]; mn = mn < x ? mn : x; }
                     mn = wave_min_i64(mn);
-                    u64* const bk = n <= LH_RFA_LDS_BYTES / 8 ? (u64*)lds_raw : (u64*)kpg + b0;
+                    u64* const bk = (u64*)kpg + b0;   // (always in the slab: a pointer that is LDS for short lists and memory for long ones is a flat one — that form faulted on the device, and this one measured faster)
                     WAVE_SYNC();   // the previous contig's keys have been read
                     for (int i = lane; i < n; i += 64) bk[i] = (u64)(R.pos[c_lo + pl[b0 + i]] - mn) << 20 | (u64)i;
                     WAVE_SYNC();
@@ -665,15 +666,32 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                         WAVE_SYNC();
                         continue;
                     }
-                    if (n <= LH_RFA_SORT_LDS) {   // Go's algorithm on the keys in LDS, its ranges spread over the lanes
-                        for (int i = lane; i < n; i += 64) { const int a = pl[b0 + i]; sidx[i] = a; spos[i] = R.pos[c_lo + a]; }
+                    if (n <= LH_RFA_LDS_BYTES / 4 && n <= 4096) {
+                        // Two equal positions: Go's algorithm (its ranges spread over the lanes) on the list AS IT WAS — but on one word per entry in LDS: Less only asks which of two
+                        // positions is smaller, so a position's dense RANK (from the network's order: equal positions share one) answers for it, and (rank << 12 | place) is a
+                        // 32-bit word that a Swap moves whole.  Up to 2,304 entries instead of 768 (12 bytes each: position and place), and lists of 800 - 2,300 entries — two reads
+                        // at the same offset of a 300-bp family tie on EVERY copy — were sorted in memory, two dependent reads per comparison.
+                        int carry = 0;
+                        for (int e0 = 0; e0 < n; e0 += 64) {
+                            const int e = e0 + lane;
+                            int fl = 0;
+                            u64 w = 0;
+                            if (e < n) { w = bk[e]; fl = e > 0 && (bk[e - 1] >> 20) != (w >> 20); }
+                            const int rk = carry + wave_scan_add_i32(fl);
+                            if (e < n) T.rdl[b0 + (int)(w & 0xfffffu)] = rk;   // (rdl: free until inferMolecules)
+                            carry = wave_readlane(rk, 63);
+                        }
                         WAVE_SYNC();
+                        uint32_t* const g32 = (uint32_t*)lds_raw;
+                        for (int i = lane; i < n; i += 64) g32[i] = (uint32_t)T.rdl[b0 + i] << 12 | (uint32_t)i;
                         if (lane == 0) { shi[6] = 0; shi[7] = n; }
                         WAVE_SYNC();
-                        wave_gosort(1, shi + 6, [&](int i, int j) { return spos[i] < spos[j]; },
-                                    [&](int i, int j) { i64 t = spos[i]; spos[i] = spos[j]; spos[j] = t; int u = sidx[i]; sidx[i] = sidx[j]; sidx[j] = u; }, T.molraw, T.rdl, T.firstf);
+                        wave_gosort(1, shi + 6, [&](int i, int j) { return (g32[i] >> 12) < (g32[j] >> 12); },
+                                    [&](int i, int j) { const uint32_t t = g32[i]; g32[i] = g32[j]; g32[j] = t; }, T.molraw, T.rdl, T.firstf);
                         WAVE_SYNC();
-                        for (int e = lane; e < n; e += 64) pl[b0 + e] = sidx[e];
+                        for (int e = lane; e < n; e += 64) T.molc[b0 + e] = pl[b0 + (int)(g32[e] & 0xfffu)];   // (molc: set after the sorts)
+                        WAVE_SYNC();
+                        for (int e = lane; e < n; e += 64) pl[b0 + e] = T.molc[b0 + e];
                         WAVE_SYNC();
                         continue;
                     }

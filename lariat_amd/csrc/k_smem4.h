@@ -28,7 +28,11 @@
 //    registers (and is never written to the slab: most backward rows have a single survivor) and the following one is prefetched
 //    while the current extension is in flight
 #pragma once
+#ifndef LH_K1_SLAB_CHUNK
+#define LH_K1_SLAB_CHUNK 4   // entries of a lane's interval list that share a 64-B line of the slab (1: the r02-r05 layout); must divide LH_MAXLEN + 2
+#endif
 #include "lh_dev.h"
+static_assert((LH_MAXLEN + 2) % LH_K1_SLAB_CHUNK == 0, "a lane's list of LH_MAXLEN + 2 entries is a whole number of chunks");
 
 struct __attribute__((aligned(16))) PEnt { u64 lo, hi; };   // x0:40 | x2[0..23]  /  x1:40 | x2[24..32] | info:15
 #define LH_M40 0xffffffffffull
@@ -273,8 +277,11 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
 #ifdef LH_K1_TRACE
     uint32_t trace_k = 0;
 #endif
-    PEnt* const LA = slab + t;                                    // entry e of list A at LA[e * T]
-    PEnt* const LB = slab + (size_t)(LH_MAXLEN + 2) * T + t;
+    // (r06) entry e of list A at LA[K1_SLAB_IX(e)]: LH_K1_SLAB_CHUNK consecutive entries of a lane share a 64-B line (the lane's next push and the sweep's next read hit the
+    // line the last one touched), chunks interleaved by thread.  It was one entry per thread and row (LA[e * T]): with 17 of 64 lanes active, each on its own row, every
+    // access was a line of its own — 28 % of pass 1's requests (profiles/r05_k1_request_floor.json)
+    PEnt* const LA = slab + (size_t)LH_K1_SLAB_CHUNK * t;
+    PEnt* const LB = slab + (size_t)(LH_MAXLEN + 2) * T + (size_t)LH_K1_SLAB_CHUNK * t;
     const int split_len = (int)(o.min_seed_len * o.split_factor + .499);
     int chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of reads
     int st = S4_FETCH;
@@ -354,7 +361,8 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
 #define T16_B() (tw_sh ? (tw1 >> tw_sh) | (tw2 << (32 - tw_sh)) : tw1)
 #define CURR ((rflags & RF_CURA) ? LA : LB)
 #define PREV ((rflags & RF_CURA) ? LB : LA)
-#define PREV_AT(e_) PREV[(uint32_t)(e_) * T]
+#define K1_SLAB_IX(e_) (((uint32_t)(e_) / LH_K1_SLAB_CHUNK) * (LH_K1_SLAB_CHUNK * T) + ((uint32_t)(e_) % LH_K1_SLAB_CHUNK))
+#define PREV_AT(e_) PREV[K1_SLAB_IX(e_)]
     // forward extension: the next base decides between another bwt_extend and the end of the forward list
 #define FWD_ADVANCE()                                                                                        \
     {                                                                                                        \
@@ -935,7 +943,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             if (ok.x2 != c2) {
                 ce = pe_pack(c0, c1, c2, cinfo);
                 if (ok.x2 < (u64)min_intv) { st = S4_BWD_INIT; ncurr++; }   // the interval is too small to be extended further: ce is the list's last entry
-                else if (FWD_PUSH_OK()) { if (!ncurr) emin = cinfo; CURR[(uint32_t)ncurr * T] = ce; K1_REQ(K1T_SLAB_W, &CURR[(uint32_t)ncurr * T], 16) ncurr++; }
+                else if (FWD_PUSH_OK()) { if (!ncurr) emin = cinfo; CURR[K1_SLAB_IX(ncurr)] = ce; K1_REQ(K1T_SLAB_W, &CURR[K1_SLAB_IX(ncurr)], 16) ncurr++; }
             }
             if (st == S4_REQ_FWD) {
                 c0 = ok.x0; c1 = ok.x1; c2 = ok.x2; cinfo = i + 1; ++i;
@@ -949,7 +957,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
             } else if (ncurr == 0 || ok.x2 != last_size) {
                 PEnt e = pe_pack(ok.x0, ok.x1, ok.x2, cinfo);
                 if (ncurr == 0) ce = e;   // a row's first entry is only ever read through ce
-                else { CURR[(uint32_t)ncurr * T] = e; K1_REQ(K1T_SLAB_W, &CURR[(uint32_t)ncurr * T], 16) }
+                else { CURR[K1_SLAB_IX(ncurr)] = e; K1_REQ(K1T_SLAB_W, &CURR[K1_SLAB_IX(ncurr)], 16) }
                 ncurr++;
                 last_size = ok.x2;
             }
@@ -1015,6 +1023,7 @@ __global__ void __launch_bounds__(64, PASS == 3 ? 8 : LH_SMEM4_WAVES) k_smem_pas
 #undef CURR
 #undef PREV
 #undef PREV_AT
+#undef K1_SLAB_IX
 #undef P3_NOTEXT
 #undef US0
 #undef UE0

@@ -22,8 +22,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--oracle", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--rfa-slab-kb", type=int, default=0)
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--big", type=int, default=0, help="one more barcode of this many pairs (1,200 molecules)")
     a = ap.parse_args()
-    lib = capi.load_library()
+    lib = capi.load_library(a.lib)
     t0 = time.time()
     g = workload.config4_genome(lib, a.genome_mb * 1e6, scale=a.scale, quiet=False)
     print("genome %.1f s" % (time.time() - t0)); t0 = time.time()
@@ -31,11 +34,15 @@ def main():
     idx.set_alt(g["alt_flags"])
     print("index %.1f s" % (time.time() - t0)); t0 = time.time()
     n_pairs = a.barcodes * 100
-    ctx = idx.context(n_pairs)
+    ctx = idx.context(n_pairs + a.big, **({"rfa_slab_kb": a.rfa_slab_kb} if a.rfa_slab_kb else {}))
     opts = lib.opts(flags=a.flags)
     rs = []
     for s in range(a.steps):
         r = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 400 + s, n_barcodes=a.barcodes, pairs_per_barcode=100)
+        if a.big:
+            big = lib.synth_reads(g["pac"], g["l_pac"], g["windows"], seed=workload.READS_SEED + 41, n_barcodes=1, pairs_per_barcode=a.big, mol_min=1200, mol_max=1200)
+            r = dict(seq=np.concatenate([r["seq"], big["seq"]]), seq_off=np.concatenate([r["seq_off"], big["seq_off"][1:] + r["seq_off"][-1]]),
+                     bc_pair_off=np.concatenate([r["bc_pair_off"], big["bc_pair_off"][1:] + r["bc_pair_off"][-1]]).astype(np.int32), name_seed=np.concatenate([r["name_seed"], big["name_seed"]]))
         rs.append(r)
         ctx.upload_slot(s, capi.Batch.from_arrays(r["seq"], r["seq_off"], r["bc_pair_off"], r["name_seed"]))
     print("reads %.1f s" % (time.time() - t0))
