@@ -89,71 +89,106 @@ __global__ void __launch_bounds__(64) k_resc_cert(DIndex ix, DOpts o, i64 n_jobs
     const int ok = resc_cert_ok(o);
     for (int i = lane; i < 1024; i += 64) S.head[i] = 0;
     WAVE_SYNC();
-    for (i64 j = blockIdx.x; j < n_jobs; j += gridDim.x) {
+    // a wave takes a contiguous share of the jobs: the jobs of a pair follow each other and share their mate, whose 5-mer table is then built once
+    const i64 per = (n_jobs + gridDim.x - 1) / gridDim.x, j_lo = per * blockIdx.x, j_hi = j_lo + per < n_jobs ? j_lo + per : n_jobs;
+    i64 tab_q0 = -1;
+    int tab_qlen = 0;
+    auto qcode = [&](int k) { return (uint32_t)S.q[k] | (uint32_t)S.q[k + 1] << 2 | (uint32_t)S.q[k + 2] << 4 | (uint32_t)S.q[k + 3] << 6 | (uint32_t)S.q[k + 4] << 8; };
+    for (i64 j = j_lo; j < j_hi; ++j) {
         RJob& J = jobs[j];
         const int qlen = J.qlen, tlen = J.tlen;
         if (!ok || qlen < 5 || tlen < 5) { if (lane == 0) { J.rlo = 0; J.rn = (int16_t)tlen; } continue; }
         const i64 t0 = J.t0, q0 = J.q0;
         WAVE_SYNC();   // the previous job's arrays are no longer in use
-        for (int k = lane; k < qlen; k += 64) S.q[k] = (uint8_t)(3 - seq[q0 - k]);   // (jobs are only made for mates without an ambiguous base)
-        for (int i = lane; i < tlen; i += 64) S.tgt[i] = (uint8_t)dev_ref_base(ix, t0 + i);
+        const int same_q = q0 == tab_q0 && qlen == tab_qlen;
+        if (!same_q) {
+            for (int k = lane; k + 5 <= tab_qlen; k += 64) S.head[qcode(k)] = 0;   // (the table back to empty: only the entries the previous mate set)
+            WAVE_SYNC();
+            for (int k = lane; k < qlen; k += 64) S.q[k] = (uint8_t)(3 - seq[q0 - k]);   // (jobs are only made for mates without an ambiguous base)
+        }
+        {   // the window's bases, four per byte of the 2-bit reference (on the reverse strand: the complement of the forward bases, read backwards)
+            const int fwd = t0 < ix.l_pac;
+            const i64 f0 = fwd ? t0 : (ix.l_pac << 1) - t0 - tlen;   // the forward positions [f0, f0 + tlen) hold the window
+            const i64 b_lo = f0 >> 2, b_hi = (f0 + tlen - 1) >> 2;
+            for (i64 b = b_lo + lane; b <= b_hi; b += 64) {
+                const uint32_t byte = ix.pac[b];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const i64 fp = 4 * b + u;
+                    const int base = (int)(byte >> ((3 - u) << 1)) & 3;
+                    const i64 i = fwd ? fp - f0 : f0 + tlen - 1 - fp;
+                    if (fp >= f0 && fp < f0 + tlen) S.tgt[i] = (uint8_t)(fwd ? base : 3 - base);
+                }
+            }
+        }
         const int nd = tlen + qlen - 1, nw = (nd + 3) / 4;
         for (int w = lane; w < nw; w += 64) S.hist[w] = 0;
         WAVE_SYNC();
-        // the mate's 5-mers, chained per code
-        for (int k = lane; k + 5 <= qlen; k += 64) {
-            const uint32_t code = (uint32_t)S.q[k] | (uint32_t)S.q[k + 1] << 2 | (uint32_t)S.q[k + 2] << 4 | (uint32_t)S.q[k + 3] << 6 | (uint32_t)S.q[k + 4] << 8;
-            S.nxt[k] = (uint8_t)atomicExch(&S.head[code], (uint32_t)(k + 1));
+        if (!same_q) {   // the mate's 5-mers, chained per code
+            for (int k = lane; k + 5 <= qlen; k += 64) S.nxt[k] = (uint8_t)atomicExch(&S.head[qcode(k)], (uint32_t)(k + 1));
+            tab_q0 = q0; tab_qlen = qlen;
+            WAVE_SYNC();
         }
-        WAVE_SYNC();
-        // every 5-mer of the window against them: one count per (row, column) pair of equal 5-mers, on the pair's diagonal
+        // every 5-mer of the window against them: one count per (row, column) pair of equal 5-mers, on the pair's diagonal.  A lane takes a run of consecutive rows
+        // and rolls their code (one base read per row)
         int over = 0;
-        for (int i = lane; i + 5 <= tlen; i += 64) {
-            const uint32_t code = (uint32_t)S.tgt[i] | (uint32_t)S.tgt[i + 1] << 2 | (uint32_t)S.tgt[i + 2] << 4 | (uint32_t)S.tgt[i + 3] << 6 | (uint32_t)S.tgt[i + 4] << 8;
-            int hd = (int)S.head[code], steps = 0;
-            while (hd) {
-                const int k = hd - 1, di = i - k + (qlen - 1);
-                atomicAdd(&S.hist[di >> 2], 1u << (8 * (di & 3)));
-                hd = S.nxt[k];
-                if (++steps > 48) { over = 1; break; }   // a low-complexity mate: the whole window
+        {
+            const int n5 = tlen - 4, per_lane = (n5 + 63) / 64;
+            const int i_lo = lane * per_lane, i_hi = i_lo + per_lane < n5 ? i_lo + per_lane : n5;
+            uint32_t code = 0;
+            if (i_lo < i_hi) code = (uint32_t)S.tgt[i_lo] << 2 | (uint32_t)S.tgt[i_lo + 1] << 4 | (uint32_t)S.tgt[i_lo + 2] << 6 | (uint32_t)S.tgt[i_lo + 3] << 8;
+            for (int i = i_lo; i < i_hi; ++i) {
+                code = code >> 2 | (uint32_t)S.tgt[i + 4] << 8;
+                int hd = (int)S.head[code], steps = 0;
+                while (hd) {
+                    const int k = hd - 1, di = i - k + (qlen - 1);
+                    atomicAdd(&S.hist[di >> 2], 1u << (8 * (di & 3)));
+                    hd = S.nxt[k];
+                    if (++steps > 48) { over = 1; break; }   // a low-complexity mate: the whole window
+                }
             }
         }
         over = __any(over);
         WAVE_SYNC();
-        for (int k = lane; k + 5 <= qlen; k += 64) {   // (the table back to empty: only the entries this job set)
-            const uint32_t code = (uint32_t)S.q[k] | (uint32_t)S.q[k + 1] << 2 | (uint32_t)S.q[k + 2] << 4 | (uint32_t)S.q[k + 3] << 6 | (uint32_t)S.q[k + 4] << 8;
-            S.head[code] = 0;
-        }
         if (over) { if (lane == 0) { J.rlo = 0; J.rn = (int16_t)tlen; } continue; }
-        // the diagonal with the most hits (the smallest such diagonal)
-        int bestkey = 0;
+        // the diagonal with the most hits (the smallest such diagonal), and V summed over all diagonals
+        int bestkey = 0, vsum = 0;
         for (int w = lane; w < nw; w += 64) {
             const uint32_t hw = S.hist[w];
+            if (hw == 0) continue;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int key = (int)((hw >> (8 * u)) & 0xffu) << 12 | (4095 - (4 * w + u));
+                const int hcount = (int)((hw >> (8 * u)) & 0xffu);
+                const int key = hcount << 12 | (4095 - (4 * w + u));
                 bestkey = bestkey > key ? bestkey : key;
+                vsum += hcount > 2 ? hcount - 2 : 0;
             }
         }
         bestkey = wave_max_i32(bestkey);
-        const int h0 = bestkey >> 12, di0 = 4095 - (bestkey & 4095), d0 = di0 - (qlen - 1);
-        // V(d) = (hits - 2)+ by distance from d0: Vside, and whether the V within every distance D sums to less than D (a chain of pieces off d0 pays
-        // at least its farthest piece's distance in gap extension)
+        const int h0 = bestkey >> 12, di0 = bestkey ? 4095 - (bestkey & 4095) : 0, d0 = di0 - (qlen - 1);
+        const int vside = wave_readlane(wave_scan_add_i32(vsum), 63) - (h0 > 2 ? h0 - 2 : 0);
+        // V(d) = (hits - 2)+ by distance from d0: whether the V within every distance D sums to less than D (a chain of pieces off d0 pays at least its farthest
+        // piece's distance in gap extension).  The sum within D never exceeds Vside, so only distances up to Vside can fail; and from Vside >= 250 on no window
+        // passes the first condition (6 + Vside < K0 <= 250), whatever this one says
         const uint8_t* hb = (const uint8_t*)S.hist;
         const int maxD = di0 > nd - 1 - di0 ? di0 : nd - 1 - di0;
-        int vside = 0, near_fail = 0;
-        for (int base = 1; base <= maxD; base += 64) {
-            const int D = base + lane;
-            int v = 0;
-            if (D <= maxD) {
-                if (di0 - D >= 0) { const int x = hb[di0 - D]; v += x > 2 ? x - 2 : 0; }
-                if (di0 + D < nd) { const int x = hb[di0 + D]; v += x > 2 ? x - 2 : 0; }
+        const int scanD = vside < maxD ? vside : maxD;
+        int near_fail = 0;
+        if (vside < 250) {
+            int cum = 0;
+            for (int base = 1; base <= scanD; base += 64) {
+                const int D = base + lane;
+                int v = 0;
+                if (D <= scanD) {
+                    if (di0 - D >= 0) { const int x = hb[di0 - D]; v += x > 2 ? x - 2 : 0; }
+                    if (di0 + D < nd) { const int x = hb[di0 + D]; v += x > 2 ? x - 2 : 0; }
+                }
+                const int incl = wave_scan_add_i32(v) + cum;
+                if (D <= scanD && incl >= D) near_fail = 1;
+                cum = wave_readlane(incl, 63);
             }
-            const int incl = wave_scan_add_i32(v) + vside;
-            if (D <= maxD && incl >= D) near_fail = 1;
-            vside = wave_readlane(incl, 63);
+            near_fail = __any(near_fail);
         }
-        near_fail = __any(near_fail);
         const int vall = vside + (h0 > 2 ? h0 - 2 : 0);
         const int minsc = o.min_seed_len * o.a;
         if (6 + vall < minsc) { if (lane == 0) { J.rlo = 0; J.rn = 0; } continue; }   // no path reaches min_seed_len
