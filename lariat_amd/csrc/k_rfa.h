@@ -160,6 +160,7 @@ struct RfaTab {   // carved from the wave's slab
     u64 *dk0, *dk1, *dk2, *dk3;   // [R] markDuplicates keys
     int32_t* htab;       // [<= 4R] open-addressing table over the keys
     int32_t* gstk;       // [3 * LH_GOSORT_STK * 64] the lanes' stacks of dev_gosort
+    i64* spl;            // (k_rfa_post) [LH_SPLIT_MAX * 64] a read's split candidates, entry i of lane l at spl[i * 64 + l] (a private array of 64 was 512 B of scratch per lane)
     int32_t* bestT;      // [R*M] best_alignment_for_read of molecule m for local read r at [r*M + m]; bit 30: it pairs with
                          // the molecule's best alignment of the mate read (static after markBest); -1: nil
 };
@@ -523,10 +524,68 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         // (measured, r05: guessing from NC and nR that the molecule x read table will not fit — to spare a barcode three phases in a tier it outgrows — sends on too many that do fit:
         // one candidate in four to sixteen starts a molecule, and a barcode sent on waits for one of fewer waves; 4,000 x 100 pairs 108 -> 155 ms, 1,000 x 400 pairs 0.44 -> 1.1 s)
         // ---- positions: filtered candidates grouped by contig in first-seen order, candidate order inside a contig ----
+        int ncont = 0, NCf = 0;
+        if (ncmax <= LH_RFA_NCONT_LDS && NC > 256) {
+            // (r06) a large barcode, a contig table that fits LDS: the contigs' first-seen order from one atomic minimum per candidate (the smallest candidate index
+            // that names the contig), slot sizes from one atomic add, and the stable placement from the lanes that share a slot — found with one ballot per bit of
+            // the slot number, not one loop turn per slot present in the chunk (a read on repeat families names thirty contigs: the three passes were a sixth of the
+            // kernel for a barcode of 10,000 candidates, most of it loop turns and a 36-deep search per candidate).
+            int32_t* const fs = (int32_t*)lds_raw;                          // [ncmax] by contig + 1: its first candidate, then its slot
+            int32_t* const scnt2 = (int32_t*)lds_raw + LH_RFA_NCONT_LDS;    // [ncont] slot sizes, then running write positions
+            for (int x = lane; x < ncmax; x += 64) fs[x] = 0x7fffffff;
+            WAVE_SYNC();
+            for (int a = lane; a < NC; a += 64) if (R.in_filtered[c_lo + a]) atomicMin(&fs[R.rid[c_lo + a] + 1], a);   // (+ 1: a read without a region has a placeholder on contig -1, a group of its own)
+            WAVE_SYNC();
+            // the contigs present, in the order of their first candidates: rank by counting (a few dozen of them)
+            for (int base = 0; base < ncmax; base += 64) {
+                const int x = base + lane;
+                const int f = x < ncmax ? fs[x] : 0x7fffffff;
+                int rank = -1;
+                if (f != 0x7fffffff) { rank = 0; for (int y = 0; y < ncmax; ++y) rank += fs[y] < f; }
+                const u64 pm = __ballot(rank >= 0);
+                if (rank >= 0) { T.seen_rid[rank] = x; T.ccnt[x] = rank; }
+                ncont += __popcll(pm);
+            }
+            WAVE_SYNC();
+            for (int x = lane; x < ncmax; x += 64) fs[x] = fs[x] != 0x7fffffff ? T.ccnt[x] : -1;   // contig -> slot
+            for (int k = lane; k < ncont; k += 64) scnt2[k] = 0;
+            WAVE_SYNC();
+            for (int a = lane; a < NC; a += 64) {
+                const int k = R.in_filtered[c_lo + a] ? fs[R.rid[c_lo + a] + 1] : -1;
+                T.kidx[a] = k;
+                if (k >= 0) atomicAdd(&scnt2[k], 1);
+            }
+            WAVE_SYNC();
+            for (int base = 0; base < ncont; base += 64) {   // slot offsets; scnt2 becomes the running write position
+                const int k = base + lane;
+                const int c = k < ncont ? scnt2[k] : 0;
+                const int inc = wave_scan_add_i32(c);
+                EMU_SYNC();
+                if (k < ncont) { T.coff[k] = NCf + inc - c; scnt2[k] = NCf + inc - c; }
+                NCf += wave_readlane(inc, 63);
+            }
+            if (lane == 0) T.coff[ncont] = NCf;
+            WAVE_SYNC();
+            int kbits = 1;
+            while ((1 << kbits) < ncont) ++kbits;
+            for (int base = 0; base < NC; base += 64) {   // stable placement: candidate order inside a slot
+                const int a = base + lane;
+                const int k = a < NC ? T.kidx[a] : -1;
+                const int valid = k >= 0;
+                u64 peers = __ballot(valid);
+                for (int b = 0; b < kbits; ++b) { const u64 bb = __ballot(valid && ((k >> b) & 1)); peers &= ((k >> b) & 1) ? bb : ~bb; }
+                const int at = valid ? scnt2[k] : 0;
+                EMU_SYNC();
+                if (valid) {
+                    T.plist[at + lanes_below(peers, lane)] = a;
+                    if (lanes_below(peers, lane) == 0) scnt2[k] = at + __popcll(peers);
+                }
+                WAVE_SYNC();
+            }
+        } else {
         // pass A: contig slot of every candidate (first-seen numbering) and the slot sizes
         int32_t* const seen = ncmax <= LH_RFA_NCONT_LDS ? (int32_t*)lds_raw : T.seen_rid;
         int32_t* const scnt = ncmax <= LH_RFA_NCONT_LDS ? (int32_t*)lds_raw + LH_RFA_NCONT_LDS : T.ccnt;
-        int ncont = 0;
         for (int base = 0; base < NC; base += 64) {
             int a = base + lane;
             int valid = a < NC && R.in_filtered[c_lo + a];
@@ -553,7 +612,6 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             WAVE_SYNC();
         }
-        int NCf = 0;
         for (int base = 0; base < ncont; base += 64) {   // slot offsets; scnt becomes the running write position
             int k = base + lane;
             int c = k < ncont ? scnt[k] : 0;
@@ -582,6 +640,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
         }
         WAVE_SYNC();
+        }
         RFA_PROF(3)
         // sort.Sort(ByPosition) per contig (lariat.go:1545-1547), one lane per contig; keys staged in LDS when they fit
         if (NCf <= LH_RFA_SORT_LDS && ncont <= 8) {
@@ -1388,7 +1447,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa_post(DIndex ix, DOpts 
         RfaTab T;
 #define CARVE(ptr, type, count) { so = (so + 7) & ~(size_t)7; T.ptr = (type*)(slab + so); so += sizeof(type) * (size_t)(count); }
         CARVE(dk0, u64, nR) CARVE(dk1, u64, nR) CARVE(dk2, u64, nR) CARVE(dk3, u64, nR) CARVE(htab, int32_t, (size_t)1 << hbits)
-        CARVE(gstk, int32_t, 3 * LH_GOSORT_STK * 64)
+        CARVE(gstk, int32_t, 3 * LH_GOSORT_STK * 64) CARVE(spl, i64, LH_SPLIT_MAX * 64)
 #undef CARVE
         if (so > (size_t)slab_bytes) RFA_OVERFLOW()   // barcode too large for the slab
         // ---- markDuplicates: first-seen wins on (read1?, reversed, contig, pos, mate contig, mate pos) in read order ----
@@ -1438,7 +1497,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa_post(DIndex ix, DOpts 
             int Ps = R.qb[P], Pe = R.qe[P];
             if (Ps > Pe) { int t = Ps; Ps = Pe; Pe = t; }
             if ((Pe - Ps) > R.read_len[P] - 15) continue;
-            i64 cidx[LH_SPLIT_MAX];
+            i64* const cidx = T.spl + lane;   // entry i at cidx[i * 64]
             int ncand = 0, ovf = 0;
             for (i64 sc = R.cand_off[gr]; sc < R.cand_off[gr + 1]; ++sc) {
                 if (S.active[sc] || R.pos[sc] == -1) continue;
@@ -1450,16 +1509,16 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa_post(DIndex ix, DOpts 
                 if (overlap < (Se - Ss) / 2) {
                     int prop = dev_is_pair(R, sc, S.mate[P]);
                     S.is_proper[sc] = (uint8_t)prop;
-                    if (R.score[sc] >= 36 || prop) { if (ncand < LH_SPLIT_MAX) cidx[ncand++] = sc; else ovf = 1; }
+                    if (R.score[sc] >= 36 || prop) { if (ncand < LH_SPLIT_MAX) cidx[64 * ncand++] = sc; else ovf = 1; }
                 }
             }
             if (ovf) status[gr] |= LH_ST_POOL_OVERFLOW;
             if (ncand == 0) continue;
-            dev_gosort(ncand, [&](int i, int j) { return R.score[cidx[i]] > R.score[cidx[j]]; }, [&](int i, int j) { i64 t = cidx[i]; cidx[i] = cidx[j]; cidx[j] = t; }, T.gstk + lane, 64);
+            dev_gosort(ncand, [&](int i, int j) { return R.score[cidx[64 * i]] > R.score[cidx[64 * j]]; }, [&](int i, int j) { i64 t = cidx[64 * i]; cidx[64 * i] = cidx[64 * j]; cidx[64 * j] = t; }, T.gstk + lane, 64);
             i64 c = cidx[0];
             double mapq;
             double second_best = dev_score_aln(R, S, improper, P, -1, 0.0) + dev_pseudo_score(R, c, 0.0);
-            if (ncand > 1) { mapq = (double)(R.score[cidx[0]] - R.score[cidx[1]]); second_best = dev_score_aln(R, S, improper, P, cidx[1], 0.0); }
+            if (ncand > 1) { mapq = (double)(R.score[cidx[0]] - R.score[cidx[64]]); second_best = dev_score_aln(R, S, improper, P, cidx[64], 0.0); }
             else mapq = (double)R.score[cidx[0]];
             i64 cs = -1, ce = -1;
             if (R.rid[c] >= 0 && cen_start[R.rid[c]] >= 0) { cs = cen_start[R.rid[c]]; ce = cen_end[R.rid[c]]; }
