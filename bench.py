@@ -27,8 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")   # HBM-side counters of this workload (tools/pmc_summary.py), per kernel
-K1_FLOOR_FILE = os.path.join(ROOT, "profiles", "r05_k1_request_floor.json")   # pass 1's request stream recorded and replayed without bookkeeping (tools/k1_trace.py)
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_bench.json")   # HBM-side counters of this workload (tools/pmc_summary.py), per kernel
+K1_FLOOR_FILE = os.path.join(ROOT, "profiles", "r06_k1_request_floor.json")   # pass 1's request stream recorded and replayed without bookkeeping (tools/k1_trace.py)
 HBM_PEAK_GBPS = 8000.0
 
 

@@ -75,7 +75,7 @@ def run_case(lib, oracle, seed):
     b = capi.Batch.from_arrays(rs.seq, rs.seq_off, rs.bc_pair_off, rs.name_seed, bc_do_rfa=rfa)
     kw = {}
     if rng.random() < 0.2:
-        kw["flags"] = int(rng.choice([capi.LH_F_NO_SWEEP_FILTER, capi.LH_F_EXT_SERIAL, capi.LH_F_EXT_WAVE, capi.LH_F_CHAIN_WAVE, capi.LH_F_P2_TASKS, capi.LH_F_P2_TASKS | capi.LH_F_NO_SWEEP_FILTER, 0]))
+        kw["flags"] = int(rng.choice([capi.LH_F_NO_SWEEP_FILTER, capi.LH_F_EXT_SERIAL, capi.LH_F_EXT_WAVE, capi.LH_F_CHAIN_WAVE, capi.LH_F_P2_TASKS, capi.LH_F_P2_TASKS | capi.LH_F_NO_SWEEP_FILTER, capi.LH_F_RESCUE_FULL, 0, 0]))
     if rng.random() < 0.3:
         kw = dict(b=int(rng.integers(2, 7)), o_del=int(rng.integers(3, 9)), o_ins=int(rng.integers(3, 9)), e_del=int(rng.integers(1, 3)), e_ins=int(rng.integers(1, 3)),
                   w=int(rng.choice([20, 100])), zdrop=int(rng.choice([50, 100])), min_seed_len=int(rng.choice([15, 19, 25])))

@@ -1,8 +1,9 @@
 #!/bin/bash
-# kernel-trace statistics and the three PMC passes of bench.py on the GPU box (usage: bash tools/profile_all.sh <commit>); writes gpurun_out/prof_r05/
+# kernel-trace statistics and the three PMC passes of bench.py on the GPU box (usage: bash tools/profile_all.sh <commit>); writes gpurun_out/prof_r06/
+ulimit -c 0
 set -x
 REPO=$PWD
-OUT=$REPO/gpurun_out/prof_r05
+OUT=$REPO/gpurun_out/prof_r06
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
@@ -26,9 +27,9 @@ python3 tools/rocpd_stats.py $DB 0.05 > $OUT/kernel_stats_repeats.csv
 grep "^{" $OUT/kt_repeats.log | tail -n 1 > $OUT/kt_repeats.json
 rm -rf $OUT/kt4
 # one step of each configs[4] leg launch by launch, and the SQ counters of the repeats leg
-bash tools/prof_timeline.sh prof_r05_tl k_pack_reads --repeats --legs repeats
-cp $REPO/gpurun_out/prof_r05_tl/timeline.csv $OUT/timeline_repeats.csv
-bash tools/pmc_repeats.sh prof_r05_pmc4 $1
-cp $REPO/gpurun_out/prof_r05_pmc4/pmc_repeats.json $OUT/pmc_repeats.json
+bash tools/prof_timeline.sh prof_r06_tl k_pack_reads --repeats --legs repeats
+cp $REPO/gpurun_out/prof_r06_tl/timeline.csv $OUT/timeline_repeats.csv
+bash tools/pmc_repeats.sh prof_r06_pmc4 $1
+cp $REPO/gpurun_out/prof_r06_pmc4/pmc_repeats.json $OUT/pmc_repeats.json
 # K1's request stream (needs the -DLH_K1_TRACE build: bash tools/prof_rfa.sh beforehand, here, where hipcc is)
 if [ -f lariat_amd/_build/liblariat_hip_prof.so ]; then python3 tools/k1_trace.py --commit $1 --kernel-stats $OUT/kernel_stats.csv > $OUT/k1_request_floor.json 2> $OUT/k1_trace.err; fi
