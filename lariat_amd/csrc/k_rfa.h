@@ -706,9 +706,20 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     mn = wave_min_i64(mn);
                     u64* const bk = (u64*)kpg + b0;   // (always in the slab: a pointer that is LDS for short lists and memory for long ones is a flat one — that form faulted on the device, and this one measured faster)
                     WAVE_SYNC();   // the previous contig's keys have been read
-                    for (int i = lane; i < n; i += 64) bk[i] = (u64)(R.pos[c_lo + pl[b0 + i]] - mn) << 20 | (u64)i;
-                    WAVE_SYNC();
-                    wave_bitonic_u64(bk, n, lane);
+                    if (n <= LH_RFA_LDS_BYTES / 8) {
+                        // up to 1,152 keys: the network runs in LDS (a pass is a round trip to LDS, not to the slab: thirty lists a barcode, 36 - 55 passes each) and its result is
+                        // copied to the slab, where everything that follows reads it — through its own pointer, never one that is LDS for some lists and memory for others
+                        u64* const lk = (u64*)lds_raw;
+                        for (int i = lane; i < n; i += 64) lk[i] = (u64)(R.pos[c_lo + pl[b0 + i]] - mn) << 20 | (u64)i;
+                        WAVE_SYNC();
+                        wave_bitonic_u64(lk, n, lane);
+                        for (int i = lane; i < n; i += 64) bk[i] = lk[i];
+                        WAVE_SYNC();
+                    } else {
+                        for (int i = lane; i < n; i += 64) bk[i] = (u64)(R.pos[c_lo + pl[b0 + i]] - mn) << 20 | (u64)i;
+                        WAVE_SYNC();
+                        wave_bitonic_u64(bk, n, lane);
+                    }
                     int tie = 0;
                     for (int e = lane; e < n; e += 64) {
                         const u64 w = bk[e];

@@ -371,7 +371,7 @@ template <class L, class S> __device__ inline void wave_gosort(int nsort, const 
 // ---- (r06) a sorting network by the whole wave, for lists whose keys are all different (then there is only one sorted order and no contract about equal keys):
 // the bitonic merge sort with every comparator pointing the same way (the first step of a merge mirrors the second half), so that the list needs no padding —
 // places from n on stand for +infinity and a comparator that reaches one does nothing.  a[0 .. n) in LDS or in memory, ascending; n log^2 n / 128 steps per lane.
-__device__ inline void wave_bitonic_u64(u64* a, int n, int lane) {
+__device__ __forceinline__ void wave_bitonic_u64(u64* a, int n, int lane) {
     int np = 64;
     while (np < n) np <<= 1;
     for (int k = 2; k <= np; k <<= 1) {
