@@ -99,7 +99,7 @@ typedef struct lh_context_opts {
     int32_t smem_grid;    /* K1 persistent waves (6144) */
     int32_t aln_grid;     /* K7 waves (10240) */
     int32_t rfa_grid;     /* K8 waves (4096) */
-    int32_t rfa_slab_kb;  /* K8 first-pass slab per wave in KiB (4096); tests force the second pass with a small value */
+    int32_t rfa_slab_kb;  /* K8 first-pass slab per wave in KiB (3072); tests force the second pass with a small value */
     int32_t lanes;        /* 1 (default) .. 4: with L > 1 the context owns L - 1 further, smaller pipelines; every batch is cut at barcode
                            * boundaries and the L parts (barcodes are independent) are aligned side by side from L host threads, so
                            * that one part's kernels fill the idle tails of the others'; results are merged.  No stage dumps then. */

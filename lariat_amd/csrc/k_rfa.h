@@ -415,28 +415,69 @@ __global__ void __launch_bounds__(64) k_rfa_tag_w(DOpts o, const u64* __restrict
 // A barcode whose tables do not fit the wave's slab (the reader caps a work unit at 30,000 pairs, fastqreader/reader.go:205,
 // far above the common few hundred) is appended to ovf_list and processed by a second launch whose few waves own much
 // larger slabs (work_list = that list); only there an overflow is final (LH_ST_POOL_OVERFLOW).
+// the barcode program's tables, carved from the wave's slab in this order (sizes follow the barcode's candidates NC, reads nR, the index's contigs and the hash bits): one list
+// for the carve itself (k_rfa) and for its size (k_rfa_order routes a barcode that cannot fit the regular slab to a larger one BEFORE any wave has looked at it)
+#define LH_RFA_CARVE_LIST(X)                                                                                                                                             \
+        X(plist, int32_t, NC) X(molraw, int32_t, NC) X(mstart, int32_t, NC + 1) X(newid, int32_t, NC) X(nreads, int32_t, NC)                                              \
+        X(sval, double, NC) X(seen_rid, int32_t, ncmax) X(ccnt, int32_t, ncmax) X(coff, int32_t, ncmax + 1)                                                               \
+        X(kidx, int32_t, NC) X(molc, int32_t, NC) X(ppos, int32_t, NC) X(rdl, int32_t, NC) X(firstf, int32_t, NC)                                                         \
+        X(actc, int32_t, NC + 1) X(psum, int32_t, NC + 1)                                                                                                                 \
+        X(seg0, int32_t, NC) X(seg1, int32_t, NC) X(nbest, int32_t, NC) X(aoff, int32_t, NC) X(alen, int32_t, NC)                                                         \
+        X(act_store, int32_t, NC) X(act_cand, int32_t, nR) X(act_slot, int32_t, nR) X(tdel, int32_t, nR) X(tset, int32_t, nR)                                             \
+        X(mflag, int32_t, NC) X(P, double, NC)                                                                                                                            \
+        X(dk0, u64, nR) X(dk1, u64, nR) X(dk2, u64, nR) X(dk3, u64, nR) X(htab, int32_t, (size_t)1 << hbits)                                                              \
+        X(gstk, int32_t, 3 * LH_GOSORT_STK * 64)
+__device__ __forceinline__ size_t rfa_carve_bytes(int NC, int nR, int ncmax) {
+    int hbits = 6;
+    while ((1 << hbits) < 2 * nR) ++hbits;
+    size_t so = 0;
+#define LH_RFA_SZ(ptr, type, count) { so = (so + 7) & ~(size_t)7; so += sizeof(type) * (size_t)(count); }
+    LH_RFA_CARVE_LIST(LH_RFA_SZ)
+#undef LH_RFA_SZ
+    return (so + 7) & ~(size_t)7;
+}
+
 // (r06) the order in which the barcode programs take their barcodes: most candidates first.  A barcode's time grows faster than its candidate count (the position sorts,
 // the molecule x read tables), a wave takes one barcode at a time, and the launch lasts until its last barcode is done: in index order the largest barcode of a batch
 // could start last (kernel_ms_by_step of the repeats leg: 119 / 93 / 90 ms on three read sets).  A counting sort by size class (a quarter of an octave of the
 // candidate count), one block; order[n_bc] = n_bc, the list's length as k_rfa's work_count wants it.
-__global__ void __launch_bounds__(256) k_rfa_order(int n_bc, const int32_t* __restrict__ bc_pair_off, DCand R, int32_t* __restrict__ order) {
-    __shared__ int32_t cnt[128], start[128];
+// all[0 .. n_bc): every barcode, largest first (k_rfa_post's list); big[]: those whose tables cannot fit a regular slab (slab_bytes), largest first — they go straight to the
+// first tier's slabs, beside the others, instead of being turned away by the first launch and started when it has ended (a batch with log-normal barcode sizes: 61 ms, then 77 ms
+// for the turned-away ones) —; rest[]: the others.  counts = {n_bc, n_big, n_bc - n_big}.
+__global__ void __launch_bounds__(256) k_rfa_order(int n_bc, const int32_t* __restrict__ bc_pair_off, DCand R, int32_t* __restrict__ all, int32_t* __restrict__ big, int32_t* __restrict__ rest,
+                                                    int32_t* __restrict__ counts, i64 slab_bytes, int ncmax) {
+    __shared__ int32_t cnt[256], start[256];
     const int t = threadIdx.x;
-    if (t < 128) cnt[t] = 0;
+    cnt[t] = 0;
     __syncthreads();
     auto cls_of = [&](int bc) {
-        const i64 nc = R.cand_off[2 * (i64)bc_pair_off[bc + 1]] - R.cand_off[2 * (i64)bc_pair_off[bc]];
+        const int p0 = bc_pair_off[bc], p1 = bc_pair_off[bc + 1];
+        const i64 nc = R.cand_off[2 * (i64)p1] - R.cand_off[2 * (i64)p0];
         const u64 x = (u64)(nc > 0 ? nc : 0) + 1;
         const int lg = 63 - __clzll((long long)x);                       // floor(log2(x)), x >= 1
         const int frac = lg >= 2 ? (int)((x >> (lg - 2)) & 3) : 0;
         const int c = 4 * lg + frac;
-        return 127 - (c < 127 ? c : 127);                                // large classes first
+        // "cannot fit": the fixed tables, plus the molecule x read table at one molecule per four reads (M x nR words, M unknown until the molecules are made: nR^2 bytes
+        // is M = nR / 4; a library's barcodes hold a molecule per three to ten read pairs) — a barcode routed without need only takes one of the larger slabs, one turned
+        // away late starts again when the first launch has ended
+        const size_t nr_ = (size_t)(2 * (p1 - p0));
+        const int is_big = nc < 0x7fffffff && rfa_carve_bytes((int)nc, 2 * (p1 - p0), ncmax) + nr_ * nr_ > (size_t)slab_bytes;
+        return (is_big ? 0 : 128) + 127 - (c < 127 ? c : 127);           // the big ones first, large classes first
     };
     for (int bc = t; bc < n_bc; bc += 256) atomicAdd(&cnt[cls_of(bc)], 1);
     __syncthreads();
-    if (t == 0) { int acc = 0; for (int c = 0; c < 128; ++c) { start[c] = acc; acc += cnt[c]; } order[n_bc] = n_bc; }
+    if (t == 0) {
+        int acc = 0, nb = 0;
+        for (int c = 0; c < 256; ++c) { start[c] = acc; acc += cnt[c]; if (c == 127) nb = acc; }
+        counts[0] = n_bc; counts[1] = nb; counts[2] = n_bc - nb;
+    }
     __syncthreads();
-    for (int bc = t; bc < n_bc; bc += 256) order[atomicAdd(&start[cls_of(bc)], 1)] = bc;
+    const int n_big = start[128];
+    for (int bc = t; bc < n_bc; bc += 256) {
+        const int c = cls_of(bc), at = atomicAdd(&start[c], 1);
+        all[at] = bc;
+        if (c < 128) big[at] = bc; else rest[at - n_big] = bc;
+    }
 }
 
 // development aid (tools/prof_rfa.sh builds a library with -DLH_RFA_PROF): shader-clock time per phase of the barcode program, summed over the waves
@@ -507,15 +548,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
         int ncmax = ix.n_contigs + 2;
         int hbits = 6;
         while ((1 << hbits) < 2 * nR) ++hbits;
-        CARVE(plist, int32_t, NC) CARVE(molraw, int32_t, NC) CARVE(mstart, int32_t, NC + 1) CARVE(newid, int32_t, NC) CARVE(nreads, int32_t, NC)
-        CARVE(sval, double, NC) CARVE(seen_rid, int32_t, ncmax) CARVE(ccnt, int32_t, ncmax) CARVE(coff, int32_t, ncmax + 1)
-        CARVE(kidx, int32_t, NC) CARVE(molc, int32_t, NC) CARVE(ppos, int32_t, NC) CARVE(rdl, int32_t, NC) CARVE(firstf, int32_t, NC)
-        CARVE(actc, int32_t, NC + 1) CARVE(psum, int32_t, NC + 1)
-        CARVE(seg0, int32_t, NC) CARVE(seg1, int32_t, NC) CARVE(nbest, int32_t, NC) CARVE(aoff, int32_t, NC) CARVE(alen, int32_t, NC)
-        CARVE(act_store, int32_t, NC) CARVE(act_cand, int32_t, nR) CARVE(act_slot, int32_t, nR) CARVE(tdel, int32_t, nR) CARVE(tset, int32_t, nR)
-        CARVE(mflag, int32_t, NC) CARVE(P, double, NC)
-        CARVE(dk0, u64, nR) CARVE(dk1, u64, nR) CARVE(dk2, u64, nR) CARVE(dk3, u64, nR) CARVE(htab, int32_t, (size_t)1 << hbits)
-        CARVE(gstk, int32_t, 3 * LH_GOSORT_STK * 64)
+        LH_RFA_CARVE_LIST(CARVE)
         so = (so + 7) & ~(size_t)7;
         T.bestT = (int32_t*)(slab + so);
         size_t best_cap = ((size_t)slab_bytes > so) ? ((size_t)slab_bytes - so) / 4 : 0;
