@@ -191,6 +191,10 @@ typedef struct lh_result {
     uint64_t n_calls_by_text;
     /* (ABI 5) the ksw_u8 cells K6 really executed: rescue_cells counts the cells the REFERENCE evaluates for the same attempts (tlen x striped width per pass) */
     uint64_t rescue_cells_exec;
+    /* (ABI 5) K7, region -> CIGAR: the candidates whose alignment is not settled by bounds on the first look (k_aln_flat: equal spans, no DP needed by BWA's own rule
+     * or at most four mismatches and no shifted diagonal in reach), and those still unsettled after the second (k_aln_flat2: five or six mismatches) — the ones a
+     * banded global DP ran for.  The reference runs ksw_global2 for every candidate but bwa_gen_cigar2's "no gap" case: the oracle reports that count in both */
+    uint64_t n_glob_listed, n_glob_exec;
     void* arena_; /* private */
 } lh_result;
 

@@ -83,7 +83,7 @@ _RESULT_READ_FIELDS = [
     ("as_score", c_f64p, np.float64), ("split_idx", c_i64p, np.int64), ("split_mapq", c_i32p, np.int32),
     ("split_second_best", c_f64p, np.float64), ("split_score", c_f64p, np.float64),
 ]
-_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3", "n_ktree_p1", "n_ktree_p2", "n_ktree_p3", "n_calls_by_text", "rescue_cells_exec"]
+_COUNTERS = ["n_ext", "n_lf", "n_sa", "win_bases", "n_chain_ext", "ext_cells", "glob_cells", "n_rescue", "rescue_cells", "n_ext_exec_p1", "n_ext_exec_p2", "n_ext_exec_p3", "n_ktree_p1", "n_ktree_p2", "n_ktree_p3", "n_calls_by_text", "rescue_cells_exec", "n_glob_listed", "n_glob_exec"]
 
 
 class LhResult(C.Structure):

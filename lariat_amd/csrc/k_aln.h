@@ -268,8 +268,81 @@ __global__ void __launch_bounds__(64) k_aln(DIndex ix, DOpts o, int n_reads, con
     if (lane == 0 && ctr && cells) atomicAdd(&LH_CTR(ctr)->glob_cells, cells);
 }
 
+// ---- (r06) the second look at a candidate with equal spans and FIVE OR SIX mismatches (a third of what k_aln_flat lists on repeat families).  As in aln_fast_cand the diagonal wins when no path with gaps reaches it at any diagonal
+// cell (ties go to the diagonal).  Such a path is the diagonal with EXCURSIONS, each leaving the diagonal and coming back to it; the excursions lie in disjoint
+// column ranges, so their gains add, and it is enough that no single excursion gains.  An excursion over the columns [x, y) with R gap runs, I inserted and I
+// deleted bases has  gain = (a+b) (M - own) - I (a + e_ins + e_del) - opens(R),  M = the diagonal's mismatches in [x, y), own = its own mismatches.
+//   R = 2, g >= g0:   gain <= loss - g a - c(g) <= 0 by the choice of g0 (as before; g0 is 5 / 6 for 5 / 6 mismatches with the usual penalties).
+//   R = 2, g <  g0:   the exact running maximum over both orders of the two gaps (C1; shifts 1 .. g0-1 instead of 1 .. 2).
+//   R >= 3:           split the columns [x, y) by their TEXT base: deleted (I columns, H <= min(I, m) of them mismatches of the diagonal) or aligned in one of the
+//                     R - 1 pieces between two runs.  A piece at shift s, |s| < g0, saves (mismatches of the diagonal over its text columns) - (its own) <= B,
+//                     the largest such saving of any stretch of any of those shifted diagonals — a second running maximum in the same sweep.  So
+//                     M - own <= min(m, (R-1) B + H), I >= max(H, ceil(R/2), 2), opens(R) >= o_ins + o_del + (R-2) min(o_ins, o_del): a few dozen (R, H) pairs
+//                     to look at (C2).  A piece at a shift of g0 or more needs I >= g0: gain <= (a+b) m - g0 (a + e_ins + e_del) - opens(3), checked as well.
+// With the usual penalties C2 holds for m = 5, 6 when B <= 1 (m = 7 would need B = 0: not looked at); low-complexity sequence, whose shifted diagonals match, fails C1 or C2
+// and takes the DP as before.  LH_K7_WEAK (test builds only, tests/hipemu `weak1` / `weak2`) leaves out one of the two checks: the crafted cases of
+// tests/test_emu_front.py must then come out wrong.
+#ifndef LH_K7_WEAK
+#define LH_K7_WEAK 0
+#endif
+__device__ __forceinline__ int aln_deep_check(const DIndex& ix, const DOpts& o, const uint32_t* q4, i64 qp0, i64 rb, int lq, int loss, int m, int t_first, int t_last, int eligible) {
+    if (!eligible || m > 6 || o.o_ins < 1 || o.o_del < 1) return 0;   // (seven would need B = 0 with the usual penalties: some shifted diagonal always matches somewhere)
+    int g0 = 1;
+    while (o.o_ins + o.o_del + g0 * (o.e_ins + o.e_del + o.a) < loss) { if (++g0 > 8) return 0; }
+    const int ab = o.a + o.b, per = o.a + o.e_ins + o.e_del, omin = o.o_ins < o.o_del ? o.o_ins : o.o_del;
+    if (ab * m - g0 * per - (o.o_ins + o.o_del + omin) > 0) return 0;   // (an excursion of three or more runs with a piece g0 or more columns out)
+    int K[14], KT[7], B = 0;   // K[2 (g-1) + v]: running maxima of C1 (v = 0: insertion first, 1: deletion first); KT[g-1]: the text-indexed one of the deletion-first diagonal
+#pragma unroll
+    for (int i = 0; i < 14; ++i) K[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) KT[i] = 0;
+    const int e_beg = (t_first - g0 > 0 ? t_first - g0 : 0) & ~7;
+    for (int e8 = e_beg; e8 <= t_last + 1; e8 += 8) {
+        const u64 qq = (u64)dev_nib8(q4, qp0 + e8) | (u64)dev_nib8(q4, qp0 + e8 + 8) << 32;
+        const u64 tt = (u64)dev_nib8(ix.tn, rb + e8) | (u64)dev_nib8(ix.tn, rb + e8 + 8) << 32;
+        const u64 xm = qq ^ tt;
+        uint32_t mmask = 0;   // bit j: the diagonal's pair e8 + j is a mismatch (pairs beyond the last one are not)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mmask |= (uint32_t)(((xm >> (4 * j)) & 0xf) != 0 && e8 + j <= t_last) << j;
+#pragma unroll
+        for (int g = 1; g <= 7; ++g) {
+            if (g >= g0) continue;
+            if (LH_K7_WEAK == 1 && g > 2) continue;
+            const int lim = g * o.a + o.o_ins + o.o_del + g * (o.e_ins + o.e_del);   // g a + c(g)
+            const u64 xi = (qq >> (4 * g)) ^ tt, xd = qq ^ (tt >> (4 * g));       // q[k + g] against t[k]; q[k] against t[k + g]
+            int ki = K[2 * g - 2], kd = K[2 * g - 1], kt = KT[g - 1];
+            for (int u = 0; u < 8; ++u) {
+                const int e = e8 + u;
+                if (e > t_last + 1 || e + g > lq) break;
+                const int tail = __popc(mmask >> u & ((1u << g) - 1u));
+                if (ab * ((ki > kd ? ki : kd) + tail) > lim) return 0;
+                if (e + g < lq) {
+                    const int m0 = mmask >> u & 1, mg = mmask >> (u + g) & 1;
+                    const int bi = ((xi >> (4 * u)) & 0xf) != 0, bd = ((xd >> (4 * u)) & 0xf) != 0;
+                    ki += m0 - bi; ki = ki > 0 ? ki : 0;
+                    kd += m0 - bd; kd = kd > 0 ? kd : 0;
+                    kt += mg - bd; kt = kt > 0 ? kt : 0;
+                    B = B > ki ? B : ki; B = B > kt ? B : kt;
+                }
+            }
+            K[2 * g - 2] = ki; K[2 * g - 1] = kd; KT[g - 1] = kt;
+        }
+    }
+    if (LH_K7_WEAK == 2) B = 0;
+    for (int R = 3; o.o_ins + o.o_del + (R - 2) * omin < ab * m; ++R)
+        for (int h = 0; h <= m; ++h) {
+            int I = (R + 1) >> 1;
+            I = I > h ? I : h; I = I > 2 ? I : 2;
+            int av = (R - 1) * B + h;
+            av = av < m ? av : m;
+            if (ab * av - I * per - (o.o_ins + o.o_del + (R - 2) * omin) > 0) return 0;
+        }
+    return 1;
+}
+
 // one candidate of a read without DP, by ONE lane: everything k_aln would write for it, or 1 = it needs the DP (nothing final written).
 // q = the read's bytes, off = its offset in the batch's 4-bit stream q4, best = the read's best region score
+template <int DEEP>
 __device__ __forceinline__ int aln_fast_cand(const DIndex& ix, const DOpts& o, const DCand& R, const uint8_t* q, const uint32_t* q4, i64 off, int l_query, const DReg& ar, i64 c,
                                              int best, int32_t* status_r, unsigned* proven_cells) {
         const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
@@ -340,6 +413,7 @@ __device__ __forceinline__ int aln_fast_cand(const DIndex& ix, const DOpts& o, c
                     xw &= ~(0xfu << (4 * u));
                     if (nmm < LH_MAX_MM) { mref[nmm] = is_rev ? (int)refEnd - t : t + (int)refStart; mread[nmm] = qb + t; }
                     else {   // (rare: the pool, see DCand)
+                        if (DEEP) return 1;   // (far beyond what the second look can settle: leave the pool to the DP kernels)
                         if (xo == -2) {
                             xo = atomicAdd(R.mm_xctr, l_query - LH_MAX_MM);
                             if (xo + l_query - LH_MAX_MM > R.mm_xcap) xo = -1;
@@ -373,38 +447,40 @@ __device__ __forceinline__ int aln_fast_cand(const DIndex& ix, const DOpts& o, c
                 const int loss = lq * o.a - S0;
                 const int c3a = 2 * o.o_ins + 2 * o.e_ins + o.o_del + 2 * o.e_del, c3b = 2 * o.o_del + 2 * o.e_del + o.o_ins + 2 * o.e_ins;
                 int okd = packed && n_amb == 0 && loss <= 2 * o.a + (c3a < c3b ? c3a : c3b);
-                int g0 = 1;
-                while (okd && o.o_ins + o.o_del + g0 * (o.e_ins + o.e_del + o.a) < loss) { if (++g0 > 5) okd = 0; }
-                if (okd && g0 > 3) okd = 0;   // (shifts of one and two bases are checked below: enough for every loss the bound of (1) admits with BWA's usual penalties)
-                if (okd) {
-                    // shifts 1 and 2, both directions, in one sweep from the first to the last mismatch of the main diagonal (outside, every gain is
-                    // zero or falling): sixteen bases of read and text per step in two 64-bit words, the shifted diagonals are shifts of those
-                    const i64 qp0 = off + qb;
-                    int K[4] = {0, 0, 0, 0};   // running maxima: (g = 1, insertion first), (1, deletion first), (2, ins), (2, del)
-                    const int e_beg = (t_first - 1 > 0 ? t_first - 1 : 0) & ~7;
-                    for (int e8 = e_beg; e8 <= t_last + 1 && okd; e8 += 8) {
-                        const u64 qq = (u64)dev_nib8(q4, qp0 + e8) | (u64)dev_nib8(q4, qp0 + e8 + 8) << 32;
-                        const u64 tt = (u64)dev_nib8(ix.tn, rb + e8) | (u64)dev_nib8(ix.tn, rb + e8 + 8) << 32;
-                        const u64 xm = qq ^ tt;   // (nibbles past the spans are never looked at: see the limits below)
-                        const u64 xs[4] = {(qq >> 4) ^ tt, qq ^ (tt >> 4), (qq >> 8) ^ tt, qq ^ (tt >> 8)};
-                        for (int u = 0; u < 8; ++u) {
-                            const int e = e8 + u;
-                            if (e > t_last + 1) break;
-                            const int m0 = ((xm >> (4 * u)) & 0xf) != 0, m1 = ((xm >> (4 * u + 4)) & 0xf) != 0;
+                if (!DEEP) {
+                    int g0 = 1;
+                    while (okd && o.o_ins + o.o_del + g0 * (o.e_ins + o.e_del + o.a) < loss) { if (++g0 > 5) okd = 0; }
+                    if (okd && g0 > 3) okd = 0;   // (shifts of one and two bases are checked below: enough for every loss the bound of (1) admits with BWA's usual penalties)
+                    if (okd) {
+                        // shifts 1 and 2, both directions, in one sweep from the first to the last mismatch of the main diagonal (outside, every gain is
+                        // zero or falling): sixteen bases of read and text per step in two 64-bit words, the shifted diagonals are shifts of those
+                        const i64 qp0 = off + qb;
+                        int K[4] = {0, 0, 0, 0};   // running maxima: (g = 1, insertion first), (1, deletion first), (2, ins), (2, del)
+                        const int e_beg = (t_first - 1 > 0 ? t_first - 1 : 0) & ~7;
+                        for (int e8 = e_beg; e8 <= t_last + 1 && okd; e8 += 8) {
+                            const u64 qq = (u64)dev_nib8(q4, qp0 + e8) | (u64)dev_nib8(q4, qp0 + e8 + 8) << 32;
+                            const u64 tt = (u64)dev_nib8(ix.tn, rb + e8) | (u64)dev_nib8(ix.tn, rb + e8 + 8) << 32;
+                            const u64 xm = qq ^ tt;   // (nibbles past the spans are never looked at: see the limits below)
+                            const u64 xs[4] = {(qq >> 4) ^ tt, qq ^ (tt >> 4), (qq >> 8) ^ tt, qq ^ (tt >> 8)};
+                            for (int u = 0; u < 8; ++u) {
+                                const int e = e8 + u;
+                                if (e > t_last + 1) break;
+                                const int m0 = ((xm >> (4 * u)) & 0xf) != 0, m1 = ((xm >> (4 * u + 4)) & 0xf) != 0;
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                const int g = 1 + (v >> 1);
-                                if (g >= g0 || e + g > lq) continue;
-                                const int lim = g * o.a + o.o_ins + o.o_del + g * (o.e_ins + o.e_del);   // g a + c(g)
-                                const int tail = m0 + (g == 2 ? m1 : 0);
-                                if ((o.a + o.b) * (K[v] + tail) > lim) okd = 0;
-                                const int mb = ((xs[v] >> (4 * u)) & 0xf) != 0;
-                                K[v] += m0 - mb;
-                                K[v] = K[v] > 0 ? K[v] : 0;
+                                for (int v = 0; v < 4; ++v) {
+                                    const int g = 1 + (v >> 1);
+                                    if (g >= g0 || e + g > lq) continue;
+                                    const int lim = g * o.a + o.o_ins + o.o_del + g * (o.e_ins + o.e_del);   // g a + c(g)
+                                    const int tail = m0 + (g == 2 ? m1 : 0);
+                                    if ((o.a + o.b) * (K[v] + tail) > lim) okd = 0;
+                                    const int mb = ((xs[v] >> (4 * u)) & 0xf) != 0;
+                                    K[v] += m0 - mb;
+                                    K[v] = K[v] > 0 ? K[v] : 0;
+                                }
                             }
                         }
                     }
-                }
+                } else okd = aln_deep_check(ix, o, q4, off + qb, rb, lq, loss, nmm, t_first, t_last, packed && n_amb == 0);
                 if (!okd) return 1;   // a gapped path could win: run the DP (k_aln)
             }
             // the DP cells mem_reg2aln would have evaluated (telemetry stays comparable with the reference's work)
@@ -495,7 +571,7 @@ __global__ void __launch_bounds__(256) k_aln_flat(DIndex ix, DOpts o, i64 n_cand
         if (l_query > LH_MAXLEN) l_query = 0;
         ci = (int)(c - R.cand_off[r]);
         const DReg ar = regs[reg_off[r] + ci];
-        slow = aln_fast_cand(ix, o, R, seq + off, q4, off, l_query, ar, c, best_r[r], &status[r], &proven_cells);
+        slow = aln_fast_cand<0>(ix, o, R, seq + off, q4, off, l_query, ar, c, best_r[r], &status[r], &proven_cells);
     }
     if (ctr) {
         u64 tot = (u64)(uint32_t)wave_sum_i32((int)(proven_cells >> 16)) << 16;
@@ -505,9 +581,43 @@ __global__ void __launch_bounds__(256) k_aln_flat(DIndex ix, DOpts o, i64 n_cand
     const u64 sb = __ballot(slow);   // the wave reserves list space once (same-address atomics are slow)
     if (sb) {
         int basep = 0;
-        if (lane == 0) basep = atomicAdd(slow_count, (int)__popcll(sb));
+        if (lane == 0) { basep = atomicAdd(slow_count, (int)__popcll(sb)); if (ctr) atomicAdd(&LH_CTR(ctr)->n_glob_listed, (u64)__popcll(sb)); }
         basep = wave_readlane(basep, 0) + lanes_below(sb, lane);
         if (slow) { slow_r[basep] = r; slow_ci[basep] = ci; }
+    }
+}
+
+// (r06) the listed candidates once more, a lane each, with aln_deep_check: what it settles is written as k_aln_flat would have, the others are listed again
+__global__ void __launch_bounds__(256) k_aln_flat2(DIndex ix, DOpts o, const uint8_t* __restrict__ seq, const i64* __restrict__ seq_off, const i64* __restrict__ reg_off,
+                                                    const DReg* __restrict__ regs, DCand R, int32_t* __restrict__ status, const int32_t* __restrict__ in_r, const int32_t* __restrict__ in_ci,
+                                                    const int32_t* __restrict__ in_count, int32_t* __restrict__ slow_r, int32_t* __restrict__ slow_ci, int32_t* __restrict__ slow_count,
+                                                    DCounters* __restrict__ ctr, const uint32_t* __restrict__ q4, const int32_t* __restrict__ best_r) {
+    const int lane = LANE();
+    const int n_items = *in_count;
+    for (int base = blockIdx.x * blockDim.x; base < n_items; base += gridDim.x * blockDim.x) {
+        const int item = base + (int)threadIdx.x;
+        unsigned proven_cells = 0;
+        int slow = 0, r = -1, ci = 0;
+        if (item < n_items) {
+            r = in_r[item]; ci = in_ci[item];
+            const i64 off = seq_off[r];
+            int l_query = (int)(seq_off[r + 1] - off);
+            if (l_query > LH_MAXLEN) l_query = 0;
+            const DReg ar = regs[reg_off[r] + ci];
+            slow = aln_fast_cand<1>(ix, o, R, seq + off, q4, off, l_query, ar, R.cand_off[r] + ci, best_r[r], &status[r], &proven_cells);
+        }
+        if (ctr) {
+            u64 tot = (u64)(uint32_t)wave_sum_i32((int)(proven_cells >> 16)) << 16;
+            tot += (u64)(uint32_t)wave_sum_i32((int)(proven_cells & 0xffff));
+            if (lane == 0 && tot) atomicAdd(&LH_CTR(ctr)->glob_cells, tot);
+        }
+        const u64 sb = __ballot(slow);
+        if (sb) {
+            int basep = 0;
+            if (lane == 0) { basep = atomicAdd(slow_count, (int)__popcll(sb)); if (ctr) atomicAdd(&LH_CTR(ctr)->n_glob_exec, (u64)__popcll(sb)); }
+            basep = wave_readlane(basep, 0) + lanes_below(sb, lane);
+            if (slow) { slow_r[basep] = r; slow_ci[basep] = ci; }
+        }
     }
 }
 

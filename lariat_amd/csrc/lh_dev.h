@@ -150,7 +150,7 @@ struct DReg {   // mem_alnreg_t
 // telemetry counters: LH_CTR_SLOTS copies on separate 128-B lines, indexed by blockIdx, summed by the host
 // (same-address atomics serialize at ~12 ns each: one shared copy cost k_extend ~70 ms per 2M waves)
 #define LH_CTR_SLOTS 64
-struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells, n_ext_exec[3], n_ktree[3], n_bt, rescue_cells_exec; };   // n_ext_exec: bwt_extend calls K1 really executed on the occurrence table, per pass; n_ktree: those it read from the k-mer tree table
+struct DCounters { u64 n_ext, n_lf, n_sa, win_bases, n_chain_ext, ext_cells, glob_cells, n_rescue, rescue_cells, n_ext_exec[3], n_ktree[3], n_bt, rescue_cells_exec, n_glob_listed, n_glob_exec; };   // n_ext_exec: bwt_extend calls K1 really executed on the occurrence table, per pass; n_ktree: those it read from the k-mer tree table
 #define LH_CTR(ctr) ((ctr) + (blockIdx.x & (LH_CTR_SLOTS - 1)))
 
 // ------------------------------------------------------------------ lane helpers

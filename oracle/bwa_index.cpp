@@ -14,7 +14,7 @@ namespace orc {
 
 void Counters::add(const Counters& o) {
     n_ext += o.n_ext; n_lf += o.n_lf; n_sa += o.n_sa; win_bases += o.win_bases; n_chain_ext += o.n_chain_ext;
-    ext_cells += o.ext_cells; glob_cells += o.glob_cells; n_rescue += o.n_rescue; rescue_cells += o.rescue_cells;
+    ext_cells += o.ext_cells; glob_cells += o.glob_cells; n_rescue += o.n_rescue; rescue_cells += o.rescue_cells; n_glob += o.n_glob;
     n_reads += o.n_reads; read_bases += o.read_bases; n_cand += o.n_cand;
 }
 

@@ -1423,6 +1423,7 @@ Aln mem_reg2aln(const MemOpt& o, const Index& b, int l_query, const uint8_t* que
     w2 = w2 > tmp ? w2 : tmp;
     if (w2 > o.w) w2 = w2 < ar.w ? w2 : ar.w;
     i = 0;
+    if (cn && !(qe - qb == re - rb && (w2 < o.w << 2 ? w2 : o.w << 2) == 0)) cn->n_glob++;
     do {
         w2 = w2 < o.w << 2 ? w2 : o.w << 2;
         bwa_gen_cigar2(o, w2, b, qe - qb, &query[qb], rb, re, &score, &a.cigar, &NM, cn);

@@ -39,6 +39,7 @@ struct Counters {
     uint64_t glob_cells = 0;  // ksw_global2 DP cells
     uint64_t n_rescue = 0;    // mem_matesw SW attempts
     uint64_t rescue_cells = 0;
+    uint64_t n_glob = 0;      // candidates mem_reg2aln ran ksw_global2 for (every one but bwa_gen_cigar2's "no gap; no need to do DP")
     uint64_t n_reads = 0;
     uint64_t read_bases = 0;
     uint64_t n_cand = 0;

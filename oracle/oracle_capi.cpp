@@ -294,7 +294,7 @@ int lo_align_barcodes(const Index* idx, const lh_opts* opts, const lh_batch* b, 
     Counters tot;
     for (auto& c : cnts) tot.add(c);
     r.n_ext = tot.n_ext; r.n_lf = tot.n_lf; r.n_sa = tot.n_sa; r.win_bases = tot.win_bases; r.n_chain_ext = tot.n_chain_ext;
-    r.ext_cells = tot.ext_cells; r.glob_cells = tot.glob_cells; r.n_rescue = tot.n_rescue; r.rescue_cells = tot.rescue_cells; r.rescue_cells_exec = tot.rescue_cells;   // (the oracle runs every cell)
+    r.ext_cells = tot.ext_cells; r.glob_cells = tot.glob_cells; r.n_rescue = tot.n_rescue; r.rescue_cells = tot.rescue_cells; r.rescue_cells_exec = tot.rescue_cells; r.n_glob_listed = r.n_glob_exec = tot.n_glob;   // (the oracle runs every cell)
     r.arena_ = A;
     *out = &A->r;
     return LH_OK;

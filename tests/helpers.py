@@ -273,6 +273,76 @@ def k7_band_case(g, ins_first):
     return ["chrB"], [contig], capi.Batch([r1, r2], [0, 1]), p
 
 
+def _k7_low_complexity(rng, n):
+    kind = int(rng.integers(0, 4))
+    if kind == 0:      # a homopolymer with interruptions
+        s = np.full(n, int(rng.integers(0, 4)), dtype=np.uint8)
+    elif kind == 1:    # a short tandem repeat
+        s = np.tile(rng.integers(0, 4, size=int(rng.integers(2, 8))).astype(np.uint8), n)[:n]
+    elif kind == 2:    # two homopolymers
+        s = np.concatenate([np.full(n // 2, int(rng.integers(0, 4))), np.full(n - n // 2, int(rng.integers(0, 4)))]).astype(np.uint8)
+    else:              # a repeat of a longer unit with a homopolymer inside
+        u = rng.integers(0, 4, size=int(rng.integers(8, 14))).astype(np.uint8); u[2:6] = u[2]
+        s = np.tile(u, n)[:n]
+    for _ in range(int(rng.integers(0, 5))):
+        k = int(rng.integers(0, n)); s[k] = (s[k] + int(rng.integers(1, 4))) & 3
+    return s
+
+
+def _k7_deep_case(rng):
+    """one locus and a read 1 on it whose middle is an excursion of two or three gap runs through low-complexity sequence (equal spans), plus substitutions"""
+    lc = _k7_low_complexity(rng, int(rng.integers(24, 70)))
+    left, right = rng.integers(0, 4, size=400).astype(np.uint8), rng.integers(0, 4, size=700).astype(np.uint8)
+    locus = np.concatenate([left, lc, right])
+    p = len(left)
+    ref = locus[p - 50:p + 100].copy()
+    a = 50 + int(rng.integers(0, max(1, len(lc) // 3)))
+    runs = int(rng.choice([2, 2, 3, 3, 4]))
+    total = int(rng.integers(1, 6)) if runs == 2 else int(rng.integers(2, 5))
+    read = list(ref)
+    # deletions of reference bases first or insertions first; the later runs give the bases back
+    first_del = bool(rng.integers(0, 2))
+    cuts = sorted(int(x) for x in rng.choice(np.arange(a, min(a + len(lc), 140)), size=runs, replace=False))
+    if runs == 2:
+        sizes_a, sizes_b = [total], [total]
+        pos_a, pos_b = cuts[:1], cuts[1:]
+    elif runs == 3:
+        k = int(rng.integers(1, total))
+        if rng.integers(0, 2): sizes_a, sizes_b, pos_a, pos_b = [k, total - k], [total], cuts[:2], cuts[2:]
+        else: sizes_a, sizes_b, pos_a, pos_b = [total], [k, total - k], cuts[:1], cuts[1:]
+    else:
+        k, k2 = int(rng.integers(1, total)), int(rng.integers(1, total))
+        sizes_a, sizes_b, pos_a, pos_b = [k, total - k], [k2, total - k2], cuts[:2], cuts[2:]
+    ops = [(q, "d" if first_del else "i", n) for q, n in zip(pos_a, sizes_a)] + [(q, "i" if first_del else "d", n) for q, n in zip(pos_b, sizes_b)]
+    out, at = [], 0
+    for q, kind, n in sorted(ops):
+        out += list(ref[at:q]); at = q
+        if kind == "d": at = min(len(ref), q + n)
+        else: out += [int(ref[max(0, q - 1 - j)]) if rng.random() < 0.7 else int(rng.integers(0, 4)) for j in range(n)]
+    out += list(ref[at:])
+    read = np.array(out[:150], dtype=np.uint8)
+    if len(read) < 150:
+        read = np.concatenate([read, locus[p + 100:p + 100 + 150 - len(read)]])
+    for _ in range(int(rng.integers(0, 4))):
+        k = int(rng.integers(5, 145)); read[k] = (read[k] + int(rng.integers(1, 4))) & 3
+    mate = locus[p + 300:p + 450]
+    return locus, read, (3 - mate[::-1]).astype(np.uint8), int((read != ref).sum())
+
+
+def k7_deep_batch(seed, n):
+    """n read pairs for K7's second look (k_aln.h, aln_deep_check): read 1 of each has five to seven mismatches on its diagonal and an excursion of two to four gap runs
+    through low-complexity sequence beside it; which of the two wins is the DP's to say — or the proof's.  Returns (names, contigs, reads)."""
+    rng = np.random.default_rng(seed)
+    loci, reads, at = [], [], 0
+    while len(loci) < n:
+        locus, r1, r2, mm = _k7_deep_case(rng)
+        if not 5 <= mm <= 7:
+            continue
+        loci.append(locus); reads += [r1, r2]
+    contig = np.concatenate(loci)
+    return ["chrD"], [contig], reads
+
+
 def repeat_family_case(seed, n_barcodes, pairs=30):
     """a 600-kb genome with a family of 12 copies x 3 kb (0.2-1.2 % off the consensus, indels), one of 30 copies x 300 bp (2-8 %) and five tandem copies
     of 1.2 kb; every read pair drawn on and around the copies: tens of chains, regions and rescue attempts per read — the regime of BASELINE

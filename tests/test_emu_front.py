@@ -403,6 +403,62 @@ def test_emu_k7_narrow_band_and_its_proof(emu, oracle, g, ins_first):
     assert int(ores.indels[c]) == 2 and int(ores.pos[c]) == p
 
 
+def _k7_differing_reads(res, ref):
+    """reads whose candidates differ in place, score, counts or CIGAR"""
+    bad = []
+    for r in range(ref.n_reads):
+        ca, cb = list(res.cands_of_read(r)), list(ref.cands_of_read(r))
+        same = len(ca) == len(cb)
+        for x, y in zip(ca, cb):
+            same = same and all(int(getattr(res, f)[x]) == int(getattr(ref, f)[y]) for f in ("pos", "aend", "mismatches", "indels", "nm", "score")) \
+                and np.array_equal(res.cigar_of(x), ref.cigar_of(y))
+        if not same:
+            bad.append(r)
+    return bad
+
+
+def test_emu_k7_second_look_and_its_two_checks(emu, oracle):
+    """K7's second look (k_aln.h, aln_deep_check; r06): a candidate with equal spans and five or six mismatches is settled without the DP when no excursion from
+    the diagonal gains — two gap runs of up to g0 - 1 bases by an exact running maximum over the shifted diagonals (C1), three or more by the largest saving B of
+    any stretch of those diagonals (C2).
+    (1) Reads with 3.5-5 % substitutions on unique sequence: every field equal to the oracle's, and the second look settles most of what the first listed.
+    (2) The adversarial batch (helpers.k7_deep_batch): five to seven mismatches beside an excursion of two to four gap runs through low-complexity sequence,
+    where the DP's answer is a CIGAR with gaps about as often as not.  The product equals the oracle on every read; the SAME kernels built with C1 cut down to
+    shifts of one and two bases (`weak1`) or with C2's B taken as zero (`weak2`) report plain diagonals where the reference has gaps — each check carries cases
+    of its own."""
+    from lariat_amd import synth
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = synth.make_reads(contigs, names, n_barcodes=2, pairs_per_barcode=60, seed=31, sub_lo=0.035, sub_hi=0.05, indel_rate=0.0, mol_min=3, mol_max=5)
+    b = helpers.batch_of(rs)
+    ref = oidx.align_barcodes(b, threads=8)
+    res = emu.index_from_arrays(oidx.arrays()).context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, ref, inference=True)
+    ok = ref.rid >= 0
+    n57 = int(((ref.indels[ok] == 0) & (ref.mismatches[ok] >= 5) & (ref.mismatches[ok] <= 6)).sum())
+    listed, left = res.counters["n_glob_listed"], res.counters["n_glob_exec"]
+    assert n57 > 40 and listed <= ref.counters["n_glob_exec"] and listed - left > 0.7 * n57, (n57, listed, left, ref.counters["n_glob_exec"])
+
+    subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "hipemu"), "weak1", "weak2"])
+    names, contigs, reads = helpers.k7_deep_batch(1, 192)
+    oidx = oracle.index_build_naive(names, contigs)
+    b = capi.Batch(reads, [0, len(reads) // 2])
+    ref = oidx.align_barcodes(b, oracle.opts(run_inference=0), threads=8)
+    ok = ref.rid >= 0
+    assert int((ref.indels[ok] > 0).sum()) > 60 and int(((ref.indels[ok] == 0) & (ref.mismatches[ok] >= 5)).sum()) > 60   # both answers are there
+    res = emu.index_from_arrays(oidx.arrays()).context(len(reads) // 2).align_barcodes(b, emu.opts(run_inference=0))
+    helpers.assert_same_result(res, ref, inference=False)
+    assert res.counters["n_glob_exec"] < res.counters["n_glob_listed"]
+    for weak in ("weak1", "weak2"):
+        wl = capi.Library(os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu_%s.so" % weak))
+        wres = wl.index_from_arrays(oidx.arrays()).context(len(reads) // 2).align_barcodes(b, wl.opts(run_inference=0))
+        bad = _k7_differing_reads(wres, ref)
+        assert len(bad) >= 2, (weak, bad)
+        for r in bad:   # what goes wrong is what the check is there to stop: a diagonal reported where the reference's alignment has gaps
+            c = list(ref.cands_of_read(r))
+            assert any(int(ref.indels[x]) > 0 for x in c) and all(int(wres.indels[x]) <= int(ref.indels[y]) for x, y in zip(wres.cands_of_read(r), c)), (weak, r)
+
+
 @pytest.mark.parametrize("build", ["default", "small"])
 def test_emu_repeat_families(emu, oracle, build):
     """reads on the copies of repeat families (helpers.repeat_family_case: 6-7 candidates per read, 800-3,000 rescue attempts per batch), the paths r04 built

@@ -211,6 +211,32 @@ def test_k7_narrow_band_and_its_proof(lib, oracle, g, ins_first):
     assert int(res.indels[c]) == 2 and int(res.pos[c]) == p
 
 
+def test_k7_second_look(lib, oracle):
+    """K7's second look on the device (k_aln.h, aln_deep_check; the argument and the builds with one check left out: tests/test_emu_front.py): four adversarial
+    batches of helpers.k7_deep_batch — five to seven mismatches beside an excursion of two to four gap runs through low-complexity sequence — and reads with
+    3.5-5 % substitutions on unique sequence, every field against the oracle; the second look settles most candidates with five or six mismatches there"""
+    from lariat_amd import capi, synth
+    for seed in (1, 2, 3, 4):
+        names, contigs, reads = helpers.k7_deep_batch(seed, 192)
+        oidx = oracle.index_build_naive(names, contigs)
+        b = capi.Batch(reads, [0, len(reads) // 2])
+        ref = oidx.align_barcodes(b, oracle.opts(run_inference=0), threads=8)
+        res = lib.index_from_arrays(oidx.arrays()).context(len(reads) // 2).align_barcodes(b, lib.opts(run_inference=0))
+        helpers.assert_same_result(res, ref, inference=False)
+        ok = ref.rid >= 0
+        assert int((ref.indels[ok] > 0).sum()) > 60 and res.counters["n_glob_exec"] < res.counters["n_glob_listed"] <= ref.counters["n_glob_exec"]
+    names, contigs = helpers.small_genome()
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = synth.make_reads(contigs, names, n_barcodes=8, pairs_per_barcode=100, seed=31, sub_lo=0.035, sub_hi=0.05, indel_rate=0.0, mol_min=3, mol_max=5)
+    b = helpers.batch_of(rs)
+    ref = oidx.align_barcodes(b, threads=8)
+    res = lib.index_from_arrays(oidx.arrays()).context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, ref, inference=True)
+    ok = ref.rid >= 0
+    n56 = int(((ref.indels[ok] == 0) & (ref.mismatches[ok] >= 5) & (ref.mismatches[ok] <= 6)).sum())
+    assert n56 > 200 and res.counters["n_glob_listed"] - res.counters["n_glob_exec"] > 0.7 * n56, (n56, res.counters["n_glob_listed"], res.counters["n_glob_exec"])
+
+
 def test_context_moves_between_regimes(lib, oracle):
     """K4's choice of path for the wave-chained reads follows the context's previous batch (tests/test_emu_front.py has the argument): repeat families,
     unique sequence, repeat families twice — every result equal to the oracle's"""

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--rfa-slab-kb", type=int, default=0)
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--no-download", action="store_true", help="timings only (a library of another ABI minor for an A/B)")
     ap.add_argument("--big", type=int, default=0, help="one more barcode of this many pairs (1,200 molecules)")
     a = ap.parse_args()
     lib = capi.load_library(a.lib)
@@ -54,6 +55,8 @@ def main():
         print("step %d: %.1f ms  (%.0f pairs/s)" % (s, dt * 1e3, n_pairs / dt))
         for name, ms in ctx.timings():
             print("   %-28s %10.3f ms" % (name, ms))
+    if a.no_download:
+        return
     res = ctx.download()
     nc = np.diff(res.cand_off)
     print("candidates per read: mean %.1f median %d p90 %d p99 %d max %d" % (nc.mean(), np.median(nc), np.percentile(nc, 90), np.percentile(nc, 99), nc.max()))
