@@ -85,10 +85,10 @@ __global__ void __launch_bounds__(256) k_diag_digest(const uint8_t* __restrict__
 
 // Go's sort.Sort as K8 runs it (lh_sort.h): `n_sorts` index spaces of keys[] sorted (a) one sort per lane by the serial restatement,
 // into perm_serial, (b) all at once by the wave-wide one, into perm_wave.  Both must issue Go's Less / Swap sequence per range: equal
-// keys end up where Go leaves them.  q*: the wave-wide sort's queue of ranges (n ints each).
+// keys end up where Go leaves them.  q*: the wave-wide sort's queue of ranges (n ints each); sa / sb: the places a whole-wave doPivot swaps (n / 2 each).
 __global__ void __launch_bounds__(64) k_diag_gosort(int n_sorts, const int32_t* __restrict__ first, i64* __restrict__ keys_a, int32_t* __restrict__ perm_serial,
                                                     i64* __restrict__ keys_b, int32_t* __restrict__ perm_wave, int32_t* __restrict__ qa, int32_t* __restrict__ qb,
-                                                    int32_t* __restrict__ qd) {
+                                                    int32_t* __restrict__ qd, int32_t* __restrict__ sa, int32_t* __restrict__ sb) {
     const int lane = LANE();
     for (int k = lane; k < n_sorts; k += 64) {
         i64* kp = keys_a + first[k];
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(64) k_diag_gosort(int n_sorts, const int32_t* 
     }
     WAVE_SYNC();
     wave_gosort(n_sorts, first, [&](int i, int j) { return keys_b[i] < keys_b[j]; },
-                [&](int i, int j) { i64 t = keys_b[i]; keys_b[i] = keys_b[j]; keys_b[j] = t; int u = perm_wave[i]; perm_wave[i] = perm_wave[j]; perm_wave[j] = u; }, qa, qb, qd);
+                [&](int i, int j) { i64 t = keys_b[i]; keys_b[i] = keys_b[j]; keys_b[j] = t; int u = perm_wave[i]; perm_wave[i] = perm_wave[j]; perm_wave[j] = u; }, qa, qb, qd, sa, sb);
 }
 
 // klib's introsort as the region sorts run it (lh_sort.h): every index space of keys[] as packed words (key << 11 | index, compared above the index) sorted (a) by one lane

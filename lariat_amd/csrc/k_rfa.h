@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                         if (lane == 0) { shi[6] = 0; shi[7] = n; }
                         WAVE_SYNC();
                         wave_gosort(1, shi + 6, [&](int i, int j) { return (g32[i] >> 12) < (g32[j] >> 12); },
-                                    [&](int i, int j) { const uint32_t t = g32[i]; g32[i] = g32[j]; g32[j] = t; }, T.molraw, T.rdl, T.firstf);
+                                    [&](int i, int j) { const uint32_t t = g32[i]; g32[i] = g32[j]; g32[j] = t; }, T.molraw, T.rdl, T.firstf, T.molc, T.ppos);   // (molc, ppos: set after the sorts)
                         WAVE_SYNC();
                         for (int e = lane; e < n; e += 64) T.molc[b0 + e] = pl[b0 + (int)(g32[e] & 0xfffu)];   // (molc: set after the sorts)
                         WAVE_SYNC();
@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     for (int i = lane; i < n; i += 64) kpg[b0 + i] = R.pos[c_lo + pl[b0 + i]];
                     WAVE_SYNC();
                     wave_gosort(1, T.coff + k, [&](int i, int j) { return kpg[i] < kpg[j]; },
-                                [&](int i, int j) { i64 t = kpg[i]; kpg[i] = kpg[j]; kpg[j] = t; int u = pl[i]; pl[i] = pl[j]; pl[j] = u; }, T.molraw, T.rdl, T.firstf);
+                                [&](int i, int j) { i64 t = kpg[i]; kpg[i] = kpg[j]; kpg[j] = t; int u = pl[i]; pl[i] = pl[j]; pl[j] = u; }, T.molraw, T.rdl, T.firstf, T.molc, T.ppos);
                     WAVE_SYNC();
                     continue;
                 }
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     if (lane == 0) { shi[6] = 0; shi[7] = n; }
                     WAVE_SYNC();
                     wave_gosort(1, shi + 6, [&](int i, int j) { return spos[i] < spos[j]; },
-                                [&](int i, int j) { i64 t = spos[i]; spos[i] = spos[j]; spos[j] = t; int u = sidx[i]; sidx[i] = sidx[j]; sidx[j] = u; }, T.molraw, T.rdl, T.firstf);
+                                [&](int i, int j) { i64 t = spos[i]; spos[i] = spos[j]; spos[j] = t; int u = sidx[i]; sidx[i] = sidx[j]; sidx[j] = u; }, T.molraw, T.rdl, T.firstf, T.molc, T.ppos);
                     WAVE_SYNC();
                     for (int e = lane; e < n; e += 64) pl[b0 + e] = sidx[e];
                 }

@@ -315,8 +315,80 @@ template <class L, class S> __device__ inline void dev_gosort(int n, L less, S s
 // included) is the same.  Ranges wait in a queue (qa / qb / qd: first, end, remaining depth; at most one entry per doPivot call, i.e.
 // fewer than the number of elements); each turn the lanes take one range each and make ONE step of quickSort on it: a doPivot (the
 // two sides are queued, or finished at once if they are short), or the heap sort of a range whose depth is used up.
-// Called by all lanes of the wave; `nsort` sorts over [first[k], first[k + 1]) with Go's depth limit for their sizes.
-template <class L, class S> __device__ inline void wave_gosort(int nsort, const int32_t* first, L less, S swp, int32_t* qa, int32_t* qb, int32_t* qd) {
+// Called by all lanes of the wave; `nsort` sorts over [first[k], first[k + 1]) with Go's depth limit for their sizes.  With sa / sb (room for half the longest
+// range each) the ranges longer than LH_GOSORT_WAVE_MIN are partitioned by the whole wave (wave_go_pivot) before the lanes take one range each.
+// (r06) ONE doPivot by the whole wave, for a long range: the partition loops of gs_pivot move two pointers towards each other, the left one stopping at an element of
+// the class that belongs right, the right one at an element that belongs left, and swap what they stop at.  Whatever the data, the k-th stop of the left pointer
+// meets the k-th stop of the right one, until they cross at the boundary bd = first + (elements that belong left): the swaps are those of the misplaced elements
+// left of bd, in ascending order, with the misplaced ones right of it, in descending order — disjoint pairs, all known after one counting pass, done at once.  The
+// pointers both end at bd.  Less and Swap calls per range are those of the serial loop (in another order, on disjoint pairs), so the result is the same array.
+// right(p): the element at p belongs right of the boundary.  sa / sb: room for (c - a) / 2 places each.  Returns bd; called by all lanes with a, c uniform.
+template <class P, class S> __device__ inline int wave_go_partition(int a, int c, P right, S& swp, int32_t* sa, int32_t* sb) {
+    const int lane = LANE();
+    int n_left = 0;
+    for (int base = a; base < c; base += 64) {
+        const int p = base + lane;
+        n_left += __popcll(__ballot(p < c && !right(p)));
+    }
+    const int bd = a + n_left;
+    int na = 0, nb = 0;   // misplaced elements left of bd so far (ascending places), right of it (ascending as well: read backwards below)
+    for (int base = a; base < c; base += 64) {
+        const int p = base + lane;
+        const int r = p < c && right(p);
+        const int fa = r && p < bd, fb = p < c && !r && p >= bd;
+        const u64 ba = __ballot(fa), bb = __ballot(fb);
+        if (fa) sa[na + lanes_below(ba, lane)] = p;
+        if (fb) sb[nb + lanes_below(bb, lane)] = p;
+        na += __popcll(ba); nb += __popcll(bb);
+    }
+    WAVE_SYNC();
+    for (int k = lane; k < na; k += 64) swp(sa[k], sb[nb - 1 - k]);   // (na == nb)
+    WAVE_SYNC();
+    return bd;
+}
+template <class L, class S> __device__ inline void wave_go_pivot(L& less, S& swp, int lo, int hi, int* midlo, int* midhi, int32_t* sa, int32_t* sb) {
+    const int lane = LANE();
+    const int m = (int)((unsigned)(lo + hi) >> 1);
+    if (lane == 0) {
+        if (hi - lo > 40) {
+            const int s = (hi - lo) / 8;
+            gs_median3(less, swp, lo, lo + s, lo + 2 * s);
+            gs_median3(less, swp, m, m - s, m + s);
+            gs_median3(less, swp, hi - 1, hi - 1 - s, hi - 1 - 2 * s);
+        }
+        gs_median3(less, swp, lo, m, hi - 1);
+    }
+    WAVE_SYNC();
+    const int pivot = lo;
+    int a = hi - 1, c = hi - 1;
+    for (int base = lo + 1; base < c; base += 64) {   // for (; a < c && less(a, pivot); a++)
+        const int p = base + lane;
+        const u64 stop = __ballot(p < c && !less(p, pivot));
+        if (stop) { a = base + __ffsll((long long)stop) - 1; break; }
+    }
+    int b = wave_go_partition(a, c, [&](int p) { return less(pivot, p); }, swp, sa, sb);
+    c = b;
+    int protect = hi - c < 5;
+    if (!protect && hi - c < (hi - lo) / 4) {
+        int dups = 0;
+        if (lane == 0) {
+            if (!less(pivot, hi - 1)) { swp(c, hi - 1); c++; dups++; }
+            if (!less(b - 1, pivot)) { b--; dups++; }
+            if (!less(m, pivot)) { swp(m, b - 1); b--; dups++; }
+        }
+        b = wave_readlane(b, 0); c = wave_readlane(c, 0); dups = wave_readlane(dups, 0);
+        WAVE_SYNC();
+        protect = dups > 1;
+    }
+    if (protect) b = wave_go_partition(a, b, [&](int p) { return !less(p, pivot); }, swp, sa, sb);   // (smaller than the pivot | equal to it)
+    if (lane == 0) swp(pivot, b - 1);
+    WAVE_SYNC();
+    *midlo = b - 1; *midhi = c;
+}
+#ifndef LH_GOSORT_WAVE_MIN
+#define LH_GOSORT_WAVE_MIN 96   // ranges longer than this are partitioned by the whole wave (one lane's doPivot: a round trip to LDS or memory per element)
+#endif
+template <class L, class S> __device__ inline void wave_gosort(int nsort, const int32_t* first, L less, S swp, int32_t* qa, int32_t* qb, int32_t* qd, int32_t* sa = nullptr, int32_t* sb = nullptr) {
     const int lane = LANE();
     int head = 0, tail = 0;
     for (int base = 0; base < nsort; base += 64) {
@@ -340,6 +412,21 @@ template <class L, class S> __device__ inline void wave_gosort(int nsort, const 
             gs_insertion(less, swp, a, b);
         }
     };
+    if (sa) {   // (r06) the long ranges first, one at a time by the whole wave; what is left waits in the queue as before (an entry with b - a < 2 is skipped there)
+        for (int q = 0; q < tail;) {
+            const int a = qa[q], b = qb[q], maxDepth = qd[q];
+            if (b - a <= LH_GOSORT_WAVE_MIN || maxDepth == 0) { ++q; continue; }
+            int mlo, mhi;
+            WAVE_SYNC();
+            wave_go_pivot(less, swp, a, b, &mlo, &mhi, sa, sb);
+            if (lane == 0) {
+                qb[q] = mlo; qd[q] = maxDepth - 1;
+                qa[tail] = mhi; qb[tail] = b; qd[tail] = maxDepth - 1;
+            }
+            ++tail;
+            WAVE_SYNC();
+        }
+    }
     while (head < tail) {
         const int take = tail - head < 64 ? tail - head : 64;
         int c0a = 0, c0b = 0, c1a = 0, c1b = 0, cd = 0, n0 = 0, n1 = 0;

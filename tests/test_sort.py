@@ -40,6 +40,21 @@ def cases():
         out.append((first, keys))
     n = 3000   # runs already sorted, reversed, and a sawtooth: the patterns that drive quickSort towards its depth limit
     out.append((np.array([0, n, 2 * n, 3 * n], dtype=np.int32), np.concatenate([np.arange(n), np.arange(n)[::-1], np.arange(n) % 7])))
+    # (r06) ranges longer than LH_GOSORT_WAVE_MIN (96) are partitioned by the whole wave (wave_go_pivot): sizes around that limit and around multiples of 64, keys all
+    # equal, two values, mostly distinct with a few equal pairs (a contig's positions in K8: the case the product meets), organ pipe
+    sizes = [95, 96, 97, 98, 127, 128, 129, 160, 191, 192, 193, 257, 1153, 2304]
+    first = np.concatenate([[0], np.cumsum(sizes * 4)]).astype(np.int32)
+    parts = []
+    for rep in range(4):
+        for sz in sizes:
+            if rep == 0: k = np.zeros(sz, dtype=np.int64)
+            elif rep == 1: k = rng.integers(0, 2, size=sz)
+            elif rep == 2:
+                k = rng.permutation(sz).astype(np.int64) * 7
+                for _ in range(1 + sz // 100): k[int(rng.integers(0, sz))] = k[int(rng.integers(0, sz))]
+            else: k = np.minimum(np.arange(sz), sz - np.arange(sz)) // 3
+            parts.append(k)
+    out.append((first, np.concatenate(parts)))
     return out
 
 
