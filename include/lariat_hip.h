@@ -385,6 +385,12 @@ int lh_synth_reads(const uint8_t* pac, int64_t l_pac, int32_t n_contigs, const i
  * index spaces [first[k], first[k+1]) of keys[] (first[0] = 0) sorted by the serial restatement (one sort per lane) and by the wave-wide one;
  * each returns the permutation of every index space (position -> original index inside its space) */
 int lh_diag_gosort(int device, int32_t n_sorts, const int32_t* first, const int64_t* keys, int32_t* perm_serial, int32_t* perm_wave);
+/* the same sort of ONE index space [0, n) the way K8 sorts a contig list too long for LDS: ranges longer than `limit` (> 12) partitioned by the whole wave, the
+ * ranges left sorted one by one with the depth the long sort has left them.  perm: where Go leaves the elements (equal keys included). */
+int lh_diag_gosort_split(int device, int32_t n, const int64_t* keys, int32_t* perm, int32_t limit);
+/* K8's sorting network for lists of distinct keys (the position sort of a contig's candidates, lariat.go:1546 ByPosition, when no two positions are equal): n words
+ * ascending.  block = 64 or 1024: the places that run in LDS at a time (longer lists: block by block with passes in memory between them); 0: every step in memory. */
+int lh_diag_bitonic(int device, int32_t n, const uint64_t* keys, uint64_t* sorted, int32_t block);
 /* diagnostics: klib's ks_introsort as K5 / K6 restate it for the region sorts of mem_sort_dedup_patch (bwamem.c via gobwa.go:244,253,291,315; its order of equal keys is part
  * of the result): n_sorts index spaces of keys[] (at most 1024 elements each, keys below 2^50) sorted by the one-lane restatement and by the wave-wide one; each returns the
  * permutation of every index space (position -> original index inside its space) */

@@ -373,6 +373,22 @@ class Library:
         self.check(self.L.lh_diag_gosort(device, len(first) - 1, first.ctypes.data_as(c_i32p), keys.ctypes.data_as(c_i64p), ps.ctypes.data_as(c_i32p), pw.ctypes.data_as(c_i32p)))
         return ps, pw
 
+    def diag_gosort_split(self, keys, limit, device=0):
+        """Go's sort.Sort of keys as K8 sorts a long contig list: ranges longer than `limit` by the whole wave, the others with the depth left; returns the permutation"""
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        perm = np.zeros(len(keys), dtype=np.int32)
+        self.L.lh_diag_gosort_split.argtypes = [C.c_int, C.c_int32, c_i64p, c_i32p, C.c_int32]
+        self.check(self.L.lh_diag_gosort_split(device, len(keys), keys.ctypes.data_as(c_i64p), perm.ctypes.data_as(c_i32p), limit))
+        return perm
+
+    def diag_bitonic(self, keys, block, device=0):
+        """keys (distinct u64) ascending by K8's sorting network, `block` places in LDS at a time (64 / 1024; 0: all steps in memory)"""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(len(keys), dtype=np.uint64)
+        self.L.lh_diag_bitonic.argtypes = [C.c_int, C.c_int32, c_u64p, c_u64p, C.c_int32]
+        self.check(self.L.lh_diag_bitonic(device, len(keys), keys.ctypes.data_as(c_u64p), out.ctypes.data_as(c_u64p), block))
+        return out
+
     def diag_introsort(self, first, keys, device=0):
         """(perm_serial, perm_wave): klib's ks_introsort over the index spaces [first[k], first[k+1]) of keys, by the one-lane and the wave-wide restatement"""
         first = np.ascontiguousarray(first, dtype=np.int32)
@@ -909,6 +925,6 @@ EXPORTED_SYMBOLS = [
     "lh_ingest_open", "lh_ingest_next", "lh_ingest_batch_free", "lh_ingest_close", "lh_name_seed",
     "lh_records_text", "lh_records_text_ex", "lh_records_free", "lh_bam_open", "lh_bam_append", "lh_bam_set_flags", "lh_bam_close",
     "lh_index_free", "lh_index_build", "lh_context_create", "lh_context_free", "lh_align_barcodes", "lh_batch_upload", "lh_align_resident",
-    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_introsort", "lh_diag_random_read", "lh_diag_valu_rate", "lh_diag_rescue_sw", "lh_diag_go_rand", "lh_diag_rescue_dedup",
+    "lh_result_download", "lh_result_free", "lh_last_timings", "lh_stage_dump_resident", "lh_stage_dump_free", "lh_get_seq", "lh_device_memory", "lh_diag_gosort", "lh_diag_gosort_split", "lh_diag_bitonic", "lh_diag_introsort", "lh_diag_random_read", "lh_diag_valu_rate", "lh_diag_rescue_sw", "lh_diag_go_rand", "lh_diag_rescue_dedup",
     "lh_index_opts_init", "lh_context_opts_init", "lh_index_build_device", "lh_index_export", "lh_index_save", "lh_synth_genome", "lh_synth_reads", "lh_synth_write_fastq9", "lh_diag_index_check", "lh_batch_upload_slot", "lh_batch_select", "lh_bam_concat", "lh_reference_pack", "lh_index_set_holes", "lh_diag_index_digest", "lh_index_set_alt", "lh_index_alt", "lh_bam_set_level", "lh_bam_timings", "lh_result_download_begin", "lh_result_download_end", "lh_batch_stage_slot", "lh_host_alloc", "lh_host_free",
 ]

@@ -101,6 +101,42 @@ __global__ void __launch_bounds__(64) k_diag_gosort(int n_sorts, const int32_t* 
                 [&](int i, int j) { i64 t = keys_b[i]; keys_b[i] = keys_b[j]; keys_b[j] = t; int u = perm_wave[i]; perm_wave[i] = perm_wave[j]; perm_wave[j] = u; }, qa, qb, qd, sa, sb);
 }
 
+// Go's sort.Sort of ONE index space the way K8 sorts a contig list too long for LDS: the ranges longer than `limit` partitioned by the whole wave (wave_gosort_split),
+// every range left sorted on its own with the depth the long sort has left it (K8 does that from LDS; here where it lies)
+__global__ void __launch_bounds__(64) k_diag_gosort_split(int n, i64* __restrict__ keys, int32_t* __restrict__ perm, int limit, int32_t* __restrict__ qa, int32_t* __restrict__ qb,
+                                                          int32_t* __restrict__ qd, int32_t* __restrict__ sa, int32_t* __restrict__ sb) {
+    __shared__ int32_t fr[2];
+    const int lane = LANE();
+    auto less = [&](int i, int j) { return keys[i] < keys[j]; };
+    auto swp = [&](int i, int j) { i64 t = keys[i]; keys[i] = keys[j]; keys[j] = t; int u = perm[i]; perm[i] = perm[j]; perm[j] = u; };
+    const int nq = wave_gosort_split(0, n, limit, less, swp, qa, qb, qd, sa, sb);
+    const int qo = n / 16 + 64;
+    for (int q = 0; q < nq; ++q) {
+        const int a = qa[q], b = qb[q], d = qd[q];
+        if (b - a < 2) continue;
+        WAVE_SYNC();
+        if (lane == 0) { fr[0] = a; fr[1] = b; }
+        WAVE_SYNC();
+        wave_gosort(1, fr, less, swp, qa + qo, qb + qo, qd + qo, sa, sb, d);
+        WAVE_SYNC();
+    }
+}
+
+// K8's sorting network for distinct keys (lh_sort.h): n words sorted in LDS when they fit a block, otherwise block by block with passes in memory between them
+// (block: 64 or 1,024 places; block 0: the whole list in memory, one pass per step — the form the blocks replace)
+__global__ void __launch_bounds__(64) k_diag_bitonic(int n, u64* __restrict__ a, int block) {
+    __shared__ u64 lk[1024];
+    const int lane = LANE();
+    if (block == 0) wave_bitonic_u64(a, n, lane);
+    else if (n <= block) {
+        for (int i = lane; i < n; i += 64) lk[i] = a[i];
+        WAVE_SYNC();
+        wave_bitonic_u64(lk, n, lane);
+        for (int i = lane; i < n; i += 64) a[i] = lk[i];
+    } else if (block == 64) wave_bitonic_u64_blocks<64>(a, n, lk, lane);
+    else wave_bitonic_u64_blocks<1024>(a, n, lk, lane);
+}
+
 // klib's introsort as the region sorts run it (lh_sort.h): every index space of keys[] as packed words (key << 11 | index, compared above the index) sorted (a) by one lane
 // (dev_introsort), (b) by the wave (wave_introsort_i64); both must leave equal keys where ks_introsort does.  At most LH_DIAG_ISORT_MAX elements per sort.
 #define LH_DIAG_ISORT_MAX 1024

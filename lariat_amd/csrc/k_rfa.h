@@ -185,6 +185,13 @@ static_assert(LH_RFA_LDS_BYTES >= 15 * 64 * (int)sizeof(double), "estimateMapQua
 #define LH_RFA_NCONT_LDS 1024  // contig slots of a barcode kept in LDS while grouping (index with more contigs: slab copy)
 #define LH_RFA_SRC_CHUNK 256   // source-molecule alignments staged per pass of fastScore
 #ifndef LH_RFA_MOL_LDS_MIN
+#ifndef LH_RFA_TIE_LDS
+#define LH_RFA_TIE_LDS (LH_RFA_LDS_BYTES / 4 < 4096 ? LH_RFA_LDS_BYTES / 4 : 4096)   // entries of a contig list with two equal positions that Go's algorithm sorts as 32-bit words in LDS (test builds: 100)
+#endif
+#ifndef LH_RFA_NET_BLOCK
+#define LH_RFA_NET_BLOCK 1024   // places of the position sort's network that run in LDS at a time (a power of two; test builds: 64)
+#endif
+static_assert(LH_RFA_NET_BLOCK >= 64 && (LH_RFA_NET_BLOCK & (LH_RFA_NET_BLOCK - 1)) == 0 && LH_RFA_NET_BLOCK * 8 <= LH_RFA_LDS_BYTES, "the network's block lives in lds_raw");
 #define LH_RFA_MOL_LDS_MIN 24   // entries of a raw molecule from which on markBest's first step scans the molecule from LDS (up to LH_RFA_LDS_BYTES / 24 entries)
 #endif
 
@@ -734,25 +741,41 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     // of its elements: n^2 / 64 steps; 2,000 entries of one contig, common for a 1,000-pair barcode with a twentieth of its pairs on repeat families, were
                     // 62,000 steps a list and the position sorts a third of the kernel).  With all keys different there is only one sorted order, whatever the algorithm;
                     // two equal positions (adjacent after the sort): Go's algorithm on the list as it was, below.
-                    i64 mn = 0x7fffffffffffffffll;
-                    for (int i = lane; i < n; i += 64) { const i64 x = R.pos[c_lo + pl[b0 + i]]; mn = mn < x ? mn : x; }
-                    mn = wave_min_i64(mn);
                     u64* const bk = (u64*)kpg + b0;   // (always in the slab: a pointer that is LDS for short lists and memory for long ones is a flat one — that form faulted on the device, and this one measured faster)
                     WAVE_SYNC();   // the previous contig's keys have been read
-                    if (n <= LH_RFA_LDS_BYTES / 8) {
-                        // up to 1,152 keys: the network runs in LDS (a pass is a round trip to LDS, not to the slab: thirty lists a barcode, 36 - 55 passes each) and its result is
+                    RFA_PROF(1)
+                    // the positions, gathered ONCE (eight independent reads a lane in flight) into the slab next to the list, and the smallest of them
+                    i64 mn = 0x7fffffffffffffffll;
+                    for (int i0 = lane; i0 < n; i0 += 64 * 8) {
+                        int ca[8];
+                        i64 x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) ca[u] = i0 + 64 * u < n ? pl[b0 + i0 + 64 * u] : -1;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) x[u] = ca[u] >= 0 ? R.pos[c_lo + ca[u]] : 0x7fffffffffffffffll;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { if (ca[u] >= 0) bk[i0 + 64 * u] = (u64)x[u]; mn = mn < x[u] ? mn : x[u]; }
+                    }
+                    mn = wave_min_i64(mn);
+                    RFA_PROF(22)
+                    if (n <= LH_RFA_NET_BLOCK) {
+                        // up to 1,024 keys: the network runs in LDS (a pass is a round trip to LDS, not to the slab: thirty lists a barcode, 36 - 55 passes each) and its result is
                         // copied to the slab, where everything that follows reads it — through its own pointer, never one that is LDS for some lists and memory for others
                         u64* const lk = (u64*)lds_raw;
-                        for (int i = lane; i < n; i += 64) lk[i] = (u64)(R.pos[c_lo + pl[b0 + i]] - mn) << 20 | (u64)i;
+                        for (int i = lane; i < n; i += 64) lk[i] = (u64)((i64)bk[i] - mn) << 20 | (u64)i;
                         WAVE_SYNC();
+                        RFA_PROF(23)
                         wave_bitonic_u64(lk, n, lane);
                         for (int i = lane; i < n; i += 64) bk[i] = lk[i];
                         WAVE_SYNC();
                     } else {
-                        for (int i = lane; i < n; i += 64) bk[i] = (u64)(R.pos[c_lo + pl[b0 + i]] - mn) << 20 | (u64)i;
+                        // longer: the network block by block through LDS, a few passes over the list in the slab between them (lh_sort.h)
+                        for (int i = lane; i < n; i += 64) bk[i] = (u64)((i64)bk[i] - mn) << 20 | (u64)i;
                         WAVE_SYNC();
-                        wave_bitonic_u64(bk, n, lane);
+                        RFA_PROF(23)
+                        wave_bitonic_u64_blocks<LH_RFA_NET_BLOCK>(bk, n, (u64*)lds_raw, lane);
                     }
+                    RFA_PROF(19)
                     int tie = 0;
                     for (int e = lane; e < n; e += 64) {
                         const u64 w = bk[e];
@@ -767,9 +790,11 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     if (!tied) {
                         for (int e = lane; e < n; e += 64) pl[b0 + e] = T.molraw[b0 + e];
                         WAVE_SYNC();
+                        RFA_PROF(20)
                         continue;
                     }
-                    if (n <= LH_RFA_LDS_BYTES / 4 && n <= 4096) {
+                    RFA_PROF(20)
+                    if (n <= LH_RFA_TIE_LDS) {
                         // Two equal positions: Go's algorithm (its ranges spread over the lanes) on the list AS IT WAS — but on one word per entry in LDS: Less only asks which of two
                         // positions is smaller, so a position's dense RANK (from the network's order: equal positions share one) answers for it, and (rank << 12 | place) is a
                         // 32-bit word that a Swap moves whole.  Up to 2,304 entries instead of 768 (12 bytes each: position and place), and lists of 800 - 2,300 entries — two reads
@@ -796,6 +821,58 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                         WAVE_SYNC();
                         for (int e = lane; e < n; e += 64) pl[b0 + e] = T.molc[b0 + e];
                         WAVE_SYNC();
+                        RFA_PROF(21)
+                        continue;
+                    }
+                    {
+                        // (r06, late) longer still — several thousand entries on one contig, a 400-pair barcode on repeat families — and two equal positions: Go's algorithm
+                        // on (rank << 20 | place) words in the slab, where the network's keys were: its long ranges are partitioned by the whole wave there (coalesced passes),
+                        // and every range of up to a block's length is sorted in LDS with the depth the long sort has left it.  (It was Go's algorithm on positions and
+                        // places in memory, a lane a range: a sixth of the kernel on such barcodes.)
+                        int carry = 0;
+                        for (int e0 = 0; e0 < n; e0 += 64) {
+                            const int e = e0 + lane;
+                            int fl = 0;
+                            u64 w = 0;
+                            if (e < n) { w = bk[e]; fl = e > 0 && (bk[e - 1] >> 20) != (w >> 20); }
+                            const int rk = carry + wave_scan_add_i32(fl);
+                            if (e < n) T.rdl[b0 + (int)(w & 0xfffffu)] = rk;
+                            carry = wave_readlane(rk, 63);
+                        }
+                        WAVE_SYNC();
+                        for (int i = lane; i < n; i += 64) bk[i] = (u64)(uint32_t)T.rdl[b0 + i] << 20 | (u64)i;
+                        WAVE_SYNC();
+                        auto less_g = [&](int i, int j) { return (bk[i] >> 20) < (bk[j] >> 20); };
+                        auto swp_g = [&](int i, int j) { const u64 t = bk[i]; bk[i] = bk[j]; bk[j] = t; };
+                        const int nq = wave_gosort_split(0, n, LH_RFA_NET_BLOCK, less_g, swp_g, T.molraw, T.rdl, T.firstf, T.molc, T.ppos);
+                        const int qo = n / 16 + 64;   // (the ranges of the sorts in LDS wait behind those of the long one: fewer than n / 25 of the latter, at most a block's length of the former)
+                        u64* const lk = (u64*)lds_raw;
+                        for (int q = 0; q < nq; ++q) {
+                            const int a = T.molraw[q], len = T.rdl[q] - a, d = T.firstf[q];
+                            if (len < 2) continue;
+                            if (len > LH_RFA_NET_BLOCK) {   // (its depth used up before it was short: Go's heap sort, where it lies)
+                                WAVE_SYNC();
+                                if (lane == 0) { shi[6] = a; shi[7] = a + len; }
+                                WAVE_SYNC();
+                                wave_gosort(1, shi + 6, less_g, swp_g, T.molraw + qo, T.rdl + qo, T.firstf + qo, T.molc, T.ppos, d);
+                                WAVE_SYNC();
+                                continue;
+                            }
+                            WAVE_SYNC();
+                            for (int i = lane; i < len; i += 64) lk[i] = bk[a + i];
+                            if (lane == 0) { shi[6] = 0; shi[7] = len; }
+                            WAVE_SYNC();
+                            wave_gosort(1, shi + 6, [&](int i, int j) { return (lk[i] >> 20) < (lk[j] >> 20); }, [&](int i, int j) { const u64 t = lk[i]; lk[i] = lk[j]; lk[j] = t; },
+                                        T.molraw + qo, T.rdl + qo, T.firstf + qo, T.molc, T.ppos, d);
+                            WAVE_SYNC();
+                            for (int i = lane; i < len; i += 64) bk[a + i] = lk[i];
+                        }
+                        WAVE_SYNC();
+                        for (int e = lane; e < n; e += 64) T.molc[b0 + e] = pl[b0 + (int)(bk[e] & 0xfffffu)];
+                        WAVE_SYNC();
+                        for (int e = lane; e < n; e += 64) pl[b0 + e] = T.molc[b0 + e];
+                        WAVE_SYNC();
+                        RFA_PROF(21)
                         continue;
                     }
                 }
@@ -860,6 +937,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             }
             if (lane == 0) T.mstart[Mraw] = NCf;
             WAVE_SYNC();
+            RFA_PROF(16)
 #ifdef LH_RA_HIST
             {
                 int mxs = 0;
@@ -879,35 +957,71 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             // lane scans them for ITS entry: the same set of mate entries, the same expression evaluated in the same order per pair (lariat.go:599-624 with lmp = 0: adding
             // 0.0 to a sum that cannot be -0.0 is left out), the maximum of the same values; "first" = no earlier entry of the read in the molecule, as below.
             {
-                struct MEnt { i64 pos; int32_t rid; uint32_t rd; int16_t mm, id, sc, scl; };
+                struct MEnt { i64 pos; int32_t rid; uint32_t rd; int32_t s2, spare; };   // s2: twice the entry's own part of a pair's score (below)
                 static_assert(sizeof(MEnt) == 24, "24 bytes per staged entry");
                 MEnt* const me = (MEnt*)lds_raw;
+                // (r06, late) next to the records, the entries' read numbers alone, sixteen bits each: a lane looking for its mate's entries (and for earlier ones of its own
+                // read) reads EIGHT of them per round trip to LDS and fetches a 24-byte record only where the low sixteen bits match — one entry in ten on repeat families, where
+                // the scan of whole records, a dependent LDS read per entry, was two fifths of the kernel on large barcodes
+                constexpr int ME_FIT = (LH_RFA_LDS_BYTES / 26) & ~7;
 #ifdef LH_RFA_ME_CAP   // (test builds: tiles short enough for the suite's molecules to need several)
-                constexpr int ME_CAP = LH_RFA_ME_CAP < LH_RFA_LDS_BYTES / 24 ? LH_RFA_ME_CAP : LH_RFA_LDS_BYTES / 24;
+                constexpr int ME_CAP = (LH_RFA_ME_CAP < ME_FIT ? LH_RFA_ME_CAP : ME_FIT) & ~7;
 #else
-                constexpr int ME_CAP = LH_RFA_LDS_BYTES / 24;
+                constexpr int ME_CAP = ME_FIT;
 #endif
+                static_assert(ME_CAP >= 8 && ME_CAP % 8 == 0 && ME_CAP * 26 <= LH_RFA_LDS_BYTES, "records and read numbers of a tile share lds_raw");
+                uint16_t* const mrd = (uint16_t*)(lds_raw + ME_CAP * 24);   // (16-byte aligned: ME_CAP is a multiple of 8)
                 auto load_ent = [&](int i) {
                     const i64 ca = c_lo + T.plist[i];
                     MEnt e;
                     e.pos = R.pos[ca]; e.rid = R.rid[ca]; e.rd = (uint32_t)T.rdl[i] | (uint32_t)(R.reversed[ca] != 0) << 31;
-                    e.mm = (int16_t)R.mismatches[ca]; e.id = (int16_t)R.indels[ca]; e.sc = (int16_t)R.soft_clipped[ca]; e.scl = (int16_t)R.soft_clipped_length[ca];
+                    const int sc = R.soft_clipped[ca];
+                    e.s2 = R.mismatches[ca] * -4 + R.indels[ca] * -6 - (sc > 0 ? 20 * sc + R.soft_clipped_length[ca] : 0);
+                    e.spare = 0;
                     return e;
                 };
                 // (r06) EVERY molecule's entries go through LDS, not only the large ones: the entries of a barcode are cut into tiles of whole molecules (they are contiguous
                 // in position order), a tile is staged once and every lane scans ITS entry's molecule inside it — a handful to a few dozen LDS records where it was as many
                 // dependent reads of ten scattered fields from memory per entry (46 % of the kernel on repeat families, 37 % on 1,000-pair barcodes with a twentieth of their
                 // pairs on them).  A molecule longer than a tile goes through tiles of its own, as in r05.
-                auto score_pair = [&](const MEnt& A, int arev, const MEnt& B) {
-                    double score = 0.0;
-                    score += (double)(A.mm * -2 + A.id * -3);
-                    if (A.sc > 0) { score -= 5.0 * (double)A.sc; score -= (double)A.scl * 0.5; }
-                    score += (double)(B.mm * -2 + B.id * -3);
-                    if (B.sc > 0) { score -= 5.0 * (double)B.sc; score -= (double)B.scl * 0.5; }
+                // (r06, late) a pair's score (lariat.go:599-624 with lmp = 0) is the sum of the two entries' own parts — whole and half numbers (-2 per mismatch, -3 per indel,
+                // -5 per clipped end, -0.5 per clipped base), every partial sum exact in a double whatever the order — plus the improper-pair penalty as the LAST addition
+                // when the pair is not proper.  So the largest score over a set of mates is max(half the largest integer sum over the proper ones, half the largest over the
+                // improper ones + penalty) — the same doubles the expression as written yields (x -> x / 2 + penalty does not decrease in x) — and the loop over the mates is
+                // integer work: it was thirty double-precision operations a pair, most of this step on repeat families.
+                auto pair_proper = [&](const MEnt& A, int arev, const MEnt& B) {
                     int pr = 0;
                     if (arev != (int)(B.rd >> 31) && A.rid == B.rid) { const i64 dist = arev ? A.pos - B.pos : B.pos - A.pos; pr = dist >= -35 && dist < 750; }
-                    if (!pr) score += improper;
-                    return score;
+                    return pr;
+                };
+                constexpr int S2_NONE = -(1 << 30);
+                auto best_of = [&](int bp, int bi) {
+                    double best = -1.7976931348623157e308;
+                    if (bp != S2_NONE) best = (double)bp * 0.5;
+                    if (bi != S2_NONE) { const double x = (double)bi * 0.5 + improper; if (x > best) best = x; }
+                    return best;
+                };
+                // entries [j0, j1) of the staged tile against entry A (read lr, mate lrm); the tile's entry j is the molecule's entry jb + j, A is its entry e
+                auto scan_tile = [&](const MEnt& A, int lr, int lrm, int arev, int j0, int j1, int jb, int e, int& bp, int& bi, int& first) {
+                    const uint32_t km = (uint32_t)lrm & 0xffffu, ko = (uint32_t)lr & 0xffffu;
+                    for (int j8 = j0 & ~7; j8 < j1; j8 += 8) {
+                        const u64* const wp = (const u64*)(mrd + j8);
+                        const u64 ww[2] = {wp[0], wp[1]};
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const uint32_t id = (uint32_t)(ww[u >> 2] >> ((u & 3) * 16)) & 0xffffu;
+                            const int j = j8 + u;
+                            if ((id == km || id == ko) && j >= j0 && j < j1) {
+                                const MEnt B = me[j];
+                                const int lj = (int)(B.rd & 0x7fffffffu);
+                                if (lj == lrm) {
+                                    const int s2 = A.s2 + B.s2;
+                                    if (pair_proper(A, arev, B)) bp = bp > s2 ? bp : s2;
+                                    else bi = bi > s2 ? bi : s2;
+                                } else if (lj == lr && jb + j < e) first = 0;
+                            }
+                        }
+                    }
                 };
                 for (int i0 = 0; i0 < NCf;) {
                     const int m0 = T.molraw[i0];
@@ -919,7 +1033,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                         for (int t0 = 0; t0 < msz; t0 += ME_CAP) {
                             const int tn = msz - t0 < ME_CAP ? msz - t0 : ME_CAP;
                             WAVE_SYNC();   // the previous tile's entries have been read
-                            for (int j = lane; j < tn; j += 64) me[j] = load_ent(ms0 + t0 + j);
+                            for (int j = lane; j < tn; j += 64) { const MEnt E = load_ent(ms0 + t0 + j); me[j] = E; mrd[j] = (uint16_t)(E.rd & 0xffffu); }
                             WAVE_SYNC();
                             for (int e0 = 0; e0 < msz; e0 += 64) {
                                 const int e = e0 + lane;
@@ -928,17 +1042,10 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                                     const MEnt A = (e >= t0 && e < t0 + tn) ? me[e - t0] : load_ent(i);
                                     const int lr = (int)(A.rd & 0x7fffffffu), lrm = lr ^ 1, arev = (int)(A.rd >> 31);
                                     double best = -1.7976931348623157e308;
-                                    int found = 0, first = 1;
+                                    int found = 0, first = 1, bp = S2_NONE, bi = S2_NONE;
                                     if (t0 > 0) { best = T.sval[i]; found = T.psum[i]; first = T.firstf[i]; }
-                                    for (int j = 0; j < tn; ++j) {
-                                        const MEnt B = me[j];
-                                        const int lj = (int)(B.rd & 0x7fffffffu);
-                                        if (lj == lrm) {
-                                            found = 1;
-                                            const double score = score_pair(A, arev, B);
-                                            if (score > best) best = score;
-                                        } else if (lj == lr && t0 + j < e) first = 0;
-                                    }
+                                    scan_tile(A, lr, lrm, arev, 0, tn, t0, e, bp, bi, first);
+                                    if (bp != S2_NONE || bi != S2_NONE) { found = 1; const double x = best_of(bp, bi); if (x > best) best = x; }
                                     if (t0 + tn >= msz) { T.sval[i] = found ? best : R.lap[c_lo + T.plist[i]]; T.firstf[i] = first; }
                                     else { T.sval[i] = best; T.psum[i] = found; T.firstf[i] = first; }
                                 }
@@ -952,8 +1059,9 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     if (i0 + ME_CAP < NCf) i1 = T.mstart[T.molraw[i0 + ME_CAP]];
                     const int tn = i1 - i0;
                     WAVE_SYNC();   // the previous tile's entries have been read
-                    for (int j = lane; j < tn; j += 64) me[j] = load_ent(i0 + j);
+                    for (int j = lane; j < tn; j += 64) { const MEnt E = load_ent(i0 + j); me[j] = E; mrd[j] = (uint16_t)(E.rd & 0xffffu); }
                     WAVE_SYNC();
+                    RFA_PROF(17)
                     for (int e0 = 0; e0 < tn; e0 += 64) {
                         const int e = e0 + lane;
                         if (e < tn) {
@@ -961,21 +1069,13 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                             const int j0 = T.mstart[m] - i0, j1 = T.mstart[m + 1] - i0;
                             const MEnt A = me[e];
                             const int lr = (int)(A.rd & 0x7fffffffu), lrm = lr ^ 1, arev = (int)(A.rd >> 31);
-                            double best = -1.7976931348623157e308;
-                            int found = 0, first = 1;
-                            for (int j = j0; j < j1; ++j) {
-                                const MEnt B = me[j];
-                                const int lj = (int)(B.rd & 0x7fffffffu);
-                                if (lj == lrm) {
-                                    found = 1;
-                                    const double score = score_pair(A, arev, B);
-                                    if (score > best) best = score;
-                                } else if (lj == lr && j < e) first = 0;
-                            }
-                            T.sval[i] = found ? best : R.lap[c_lo + T.plist[i]];
+                            int first = 1, bp = S2_NONE, bi = S2_NONE;
+                            scan_tile(A, lr, lrm, arev, j0, j1, 0, e, bp, bi, first);
+                            T.sval[i] = bp != S2_NONE || bi != S2_NONE ? best_of(bp, bi) : R.lap[c_lo + T.plist[i]];
                             T.firstf[i] = first;
                         }
                     }
+                    RFA_PROF(18)
                     i0 = i1;
                 }
                 WAVE_SYNC();

@@ -388,7 +388,34 @@ template <class L, class S> __device__ inline void wave_go_pivot(L& less, S& swp
 #ifndef LH_GOSORT_WAVE_MIN
 #define LH_GOSORT_WAVE_MIN 96   // ranges longer than this are partitioned by the whole wave (one lane's doPivot: a round trip to LDS or memory per element)
 #endif
-template <class L, class S> __device__ inline void wave_gosort(int nsort, const int32_t* first, L less, S swp, int32_t* qa, int32_t* qb, int32_t* qd, int32_t* sa = nullptr, int32_t* sb = nullptr) {
+// (r06, late) the first part alone, for a list too long for LDS: quickSort(a0, b0) with Go's depth limit for its size, the ranges longer than `limit` partitioned by
+// the whole wave until none is left (a range whose depth is used up stays, whatever its length).  Returns the number of ranges now waiting in qa / qb / qd (first,
+// end, remaining depth); the caller sorts each of them with that depth (wave_gosort with depth0), e.g. from LDS.
+template <class L, class S> __device__ inline int wave_gosort_split(int a0, int b0, int limit, L less, S swp, int32_t* qa, int32_t* qb, int32_t* qd, int32_t* sa, int32_t* sb) {
+    const int lane = LANE();
+    int tail = 1;
+    if (lane == 0) {
+        int depth = 0;
+        for (int i = b0 - a0; i > 0; i >>= 1) depth++;
+        qa[0] = a0; qb[0] = b0; qd[0] = depth * 2;
+    }
+    WAVE_SYNC();
+    for (int q = 0; q < tail;) {
+        const int a = qa[q], b = qb[q], maxDepth = qd[q];
+        if (b - a <= limit || maxDepth == 0) { ++q; continue; }
+        int mlo, mhi;
+        WAVE_SYNC();
+        wave_go_pivot(less, swp, a, b, &mlo, &mhi, sa, sb);
+        if (lane == 0) {
+            qb[q] = mlo; qd[q] = maxDepth - 1;
+            qa[tail] = mhi; qb[tail] = b; qd[tail] = maxDepth - 1;
+        }
+        ++tail;
+        WAVE_SYNC();
+    }
+    return tail;
+}
+template <class L, class S> __device__ inline void wave_gosort(int nsort, const int32_t* first, L less, S swp, int32_t* qa, int32_t* qb, int32_t* qd, int32_t* sa = nullptr, int32_t* sb = nullptr, int depth0 = -1) {
     const int lane = LANE();
     int head = 0, tail = 0;
     for (int base = 0; base < nsort; base += 64) {
@@ -400,7 +427,7 @@ template <class L, class S> __device__ inline void wave_gosort(int nsort, const 
         if (want) {
             int depth = 0;
             for (int i = b - a; i > 0; i >>= 1) depth++;
-            qa[at] = a; qb[at] = b; qd[at] = depth * 2;
+            qa[at] = a; qb[at] = b; qd[at] = depth0 >= 0 ? depth0 : depth * 2;   // (depth0: a range of a longer sort, with what that sort has left it)
         }
         tail += __popcll(__ballot(want));
     }
@@ -458,23 +485,82 @@ template <class L, class S> __device__ inline void wave_gosort(int nsort, const 
 // ---- (r06) a sorting network by the whole wave, for lists whose keys are all different (then there is only one sorted order and no contract about equal keys):
 // the bitonic merge sort with every comparator pointing the same way (the first step of a merge mirrors the second half), so that the list needs no padding —
 // places from n on stand for +infinity and a comparator that reaches one does nothing.  a[0 .. n) in LDS or in memory, ascending; n log^2 n / 128 steps per lane.
-__device__ __forceinline__ void wave_bitonic_u64(u64* a, int n, int lane) {
-    int np = 64;
-    while (np < n) np <<= 1;
-    for (int k = 2; k <= np; k <<= 1) {
-        const int half = k >> 1;
-        for (int c = lane; c < (np >> 1); c += 64) {   // the flip: place p of the first half of a block of k against place k - 1 - p of the block
-            const int blk = c / half, p = c - blk * half;
-            const int lo = blk * k + p, hi = blk * k + k - 1 - p;
-            if (hi < n) { const u64 x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
-        }
-        WAVE_SYNC();
-        for (int j = half >> 1; j >= 1; j >>= 1) {
-            for (int c = lane; c < (np >> 1); c += 64) {
-                const int lo = (c / j) * 2 * j + (c % j), hi = lo + j;
-                if (hi < n) { const u64 x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
+// one pass of comparators: U of a lane's comparators at a time, all their reads issued before the first write (the comparators of a pass touch disjoint places; a read
+// per comparator waiting for the previous one's write was a round trip each)
+template <int U, class IDX> __device__ __forceinline__ void wave_ce_pass(u64* a, int ncmp, int n, int lane, IDX idx) {
+    for (int c0 = lane; c0 < ncmp; c0 += 64 * U) {
+        u64 x[U], y[U];
+        int lo[U], hi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 64 * u;
+            lo[u] = -1; hi[u] = 0; x[u] = 0; y[u] = 0;
+            if (c < ncmp) {
+                int l, h;
+                idx(c, l, h);
+                if (h < n) { lo[u] = l; hi[u] = h; x[u] = a[l]; y[u] = a[h]; }
             }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lo[u] >= 0 && x[u] > y[u]) { a[lo[u]] = y[u]; a[hi[u]] = x[u]; }
+    }
+}
+// (distances and block sizes are powers of two: lk / lj are their logarithms, so that a comparator's places come from shifts, not divisions)
+#define LH_NET_FLIP(lk_) [&](int c, int& lo, int& hi) { const int blk = c >> ((lk_) - 1), p = c & ((1 << ((lk_) - 1)) - 1); lo = (blk << (lk_)) + p; hi = (blk << (lk_)) + (1 << (lk_)) - 1 - p; }
+#define LH_NET_STEP(lj_) [&](int c, int& lo, int& hi) { lo = ((c >> (lj_)) << ((lj_) + 1)) + (c & ((1 << (lj_)) - 1)); hi = lo + (1 << (lj_)); }
+__device__ __forceinline__ void wave_bitonic_u64(u64* a, int n, int lane) {
+    int lnp = 6;
+    while ((1 << lnp) < n) ++lnp;
+    const int ncmp = 1 << (lnp - 1);
+    for (int lk = 1; lk <= lnp; ++lk) {
+        // the flip: place p of the first half of a block of k = 2^lk against place k - 1 - p of the block
+        wave_ce_pass<4>(a, ncmp, n, lane, LH_NET_FLIP(lk));
+        WAVE_SYNC();
+        for (int lj = lk - 2; lj >= 0; --lj) {
+            wave_ce_pass<4>(a, ncmp, n, lane, LH_NET_STEP(lj));
             WAVE_SYNC();
         }
     }
 }
+
+// (r06, late) the same network for a list longer than the LDS buffer: BL places (a power of two) at a time.  Comparators of the steps with k <= BL, and those of the later
+// steps at distances below BL, stay inside BL-aligned blocks: a block is loaded once, taken through all of them in LDS and stored — only the flips of the steps k > BL
+// and their distances >= BL run on the list in memory (one pass for up to 2 BL places, three for 4 BL; a pass per step in memory was 66 round trips for 2,048 places,
+// a third of K8 on 400-pair barcodes).  g[0 .. n) in memory, lds: BL words.
+template <int BL> __device__ __forceinline__ void wave_bitonic_u64_blocks(u64* g, int n, u64* lds, int lane) {
+    int lbl = 0;
+    while ((1 << lbl) < BL) ++lbl;
+    int lnp = lbl;
+    while ((1 << lnp) < n) ++lnp;
+    const int ncmp = 1 << (lnp - 1);
+    for (int b0 = 0; b0 < n; b0 += BL) {   // every block in order (the steps k = 2 .. BL)
+        const int cnt = n - b0 < BL ? n - b0 : BL;
+        for (int i = lane; i < cnt; i += 64) lds[i] = g[b0 + i];
+        WAVE_SYNC();
+        wave_bitonic_u64(lds, cnt, lane);
+        for (int i = lane; i < cnt; i += 64) g[b0 + i] = lds[i];
+        WAVE_SYNC();
+    }
+    for (int lk = lbl + 1; lk <= lnp; ++lk) {
+        wave_ce_pass<8>(g, ncmp, n, lane, LH_NET_FLIP(lk));
+        WAVE_SYNC();
+        for (int lj = lk - 2; lj >= lbl; --lj) {
+            wave_ce_pass<8>(g, ncmp, n, lane, LH_NET_STEP(lj));
+            WAVE_SYNC();
+        }
+        for (int b0 = 0; b0 < n; b0 += BL) {   // distances BL / 2 .. 1, block by block
+            const int cnt = n - b0 < BL ? n - b0 : BL;
+            for (int i = lane; i < cnt; i += 64) lds[i] = g[b0 + i];
+            WAVE_SYNC();
+            for (int lj = lbl - 1; lj >= 0; --lj) {
+                wave_ce_pass<4>(lds, BL >> 1, cnt, lane, LH_NET_STEP(lj));
+                WAVE_SYNC();
+            }
+            for (int i = lane; i < cnt; i += 64) g[b0 + i] = lds[i];
+            WAVE_SYNC();
+        }
+    }
+}
+#undef LH_NET_FLIP
+#undef LH_NET_STEP

@@ -101,6 +101,36 @@ def test_emu_inference_slab_tiers(emu, oracle):
     helpers.assert_same_result(idx.context(both.n_pairs, rfa_slab_kb=4, rfa_tier_kb=(-1, 256)).align_barcodes(bb), oidx.align_barcodes(bb), inference=True)
 
 
+@pytest.mark.parametrize("build", ["default", "small"])
+def test_emu_position_sort_long_lists_with_equal_positions(emu, oracle, build):
+    """K8's position sort of a large barcode (k_rfa.h; lariat.go:1545-1547 sort.Sort(ByPosition), whose order of EQUAL positions is part of the result): one barcode
+    of 480 pairs on two contigs, forty of the pairs present twice — contig lists of several hundred candidates, dozens of equal positions in each.  The default build
+    sorts such a list by the network in one LDS block and, for the ties, Go's algorithm on (rank, place) words in LDS with its long ranges partitioned by the whole
+    wave (lh_sort.h wave_go_pivot); the `small` build runs the network 64 places at a time with passes in the slab between the blocks, and Go's algorithm split
+    between the slab (long ranges, by the wave) and LDS (ranges of up to 64, with the depth the long sort has left them) — the forms a 400-pair barcode on repeat
+    families takes on the device.  Every field against the oracle."""
+    from lariat_amd import synth
+    lib = emu
+    if build == "small":
+        subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "hipemu"), "small"])
+        lib = capi.Library(os.path.join(helpers.ROOT, "tests", "_build", "liblariat_emu_small.so"))
+    rng = np.random.default_rng(3)
+    names, contigs = ["chrP", "chrQ"], [rng.integers(0, 4, size=150000).astype(np.uint8), rng.integers(0, 4, size=90000).astype(np.uint8)]
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = synth.make_reads(contigs, names, n_barcodes=1, pairs_per_barcode=440, seed=9, junk_frac=0.02, mol_min=6, mol_max=9)
+    n_dup = 40   # the first forty pairs once more, at the end of the barcode
+    cut = int(rs.seq_off[2 * n_dup])
+    seq = np.concatenate([rs.seq, rs.seq[:cut]])
+    seq_off = np.concatenate([rs.seq_off, rs.seq_off[1:2 * n_dup + 1] + rs.seq_off[-1]])
+    name_seed = np.concatenate([rs.name_seed, rs.name_seed[:n_dup] + np.uint64(12345)])
+    b = capi.Batch.from_arrays(seq, seq_off, np.array([0, rs.n_pairs + n_dup], dtype=np.int32), name_seed)
+    ref = oidx.align_barcodes(b, threads=8)
+    ok = ref.rid >= 0
+    assert int(ok.sum()) > 900   # (more candidates than the barcode-wide LDS sort holds: contig by contig)
+    res = lib.index_from_arrays(oidx.arrays()).context(rs.n_pairs + n_dup).align_barcodes(b)
+    helpers.assert_same_result(res, ref, inference=True)
+
+
 def test_emu_long_noisy_reads(emu, oracle):
     """240-bp reads with substitutions and indels: the 128/256-column classes of the lane-per-read extension, deferred reads,
     gapped global alignments"""

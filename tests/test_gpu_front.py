@@ -74,6 +74,18 @@ def test_gosort_serial_and_wave(lib, oracle):
     test_sort.check(lib, oracle)
 
 
+def test_gosort_split(lib, oracle):
+    """Go's sort of a list too long for LDS, split between the whole wave (long ranges) and per-range sorts with the depth left — on the GPU"""
+    import test_sort
+    test_sort.check_split(lib, oracle)
+
+
+def test_bitonic_network(lib):
+    """K8's sorting network for contig lists without equal positions: one LDS block, block by block, all in memory — on the GPU"""
+    import test_sort
+    test_sort.check_bitonic(lib)
+
+
 def test_introsort_one_lane_and_wave(lib, oracle):
     """K5 / K6's two restatements of klib's ks_introsort (equal keys end up where klib leaves them) against the oracle's, on the GPU"""
     import test_sort

@@ -68,8 +68,41 @@ def check(lib, oracle):
             assert np.array_equal(np.asarray(keys[a:b])[want[a:b]], sorted_keys[a:b]) and np.all(np.diff(sorted_keys[a:b]) >= 0)
 
 
+def check_split(lib, oracle):
+    """a long list as K8 sorts it when it does not fit LDS (k_rfa.h): wave_gosort_split down to ranges of `limit`, those with the depth left (lh_sort.h)"""
+    rng = np.random.default_rng(44)
+    for n, hi, limit in ((3000, 1 << 40, 1024), (3000, 1 << 40, 64), (5000, 40, 1024), (5000, 3, 64), (2500, 1, 64), (4097, 900, 256), (700, 50, 64)):
+        keys = rng.integers(0, hi, size=n)
+        if hi > 1 << 30:   # mostly distinct, a few equal pairs: a contig's positions
+            for _ in range(30): keys[int(rng.integers(0, n))] = keys[int(rng.integers(0, n))]
+        want, _ = oracle_perm(oracle, np.array([0, n], dtype=np.int32), keys)
+        assert np.array_equal(lib.diag_gosort_split(keys, limit), want), (n, hi, limit)
+    n = 3000   # sorted, reversed, sawtooth: towards the depth limit (a range whose depth is used up before it is short stays whole: heap sort)
+    for keys in (np.arange(n), np.arange(n)[::-1], np.arange(n) % 7, np.minimum(np.arange(n), n - np.arange(n)) // 3):
+        want, _ = oracle_perm(oracle, np.array([0, n], dtype=np.int32), keys)
+        assert np.array_equal(lib.diag_gosort_split(keys, 64), want)
+
+
+def test_emu_gosort_split(emu, oracle):
+    check_split(emu, oracle)
+
+
 def test_emu_gosort_serial_and_wave(emu, oracle):
     check(emu, oracle)
+
+
+def check_bitonic(lib):
+    """K8's network for lists without equal keys (lh_sort.h wave_bitonic_u64, wave_bitonic_u64_blocks): any length, in one LDS block, block by block, all in memory"""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 200, 1000, 1023, 1024, 1025, 1153, 2047, 2048, 2049, 3000, 4097, 9000):
+        keys = rng.permutation(n * 3)[:n].astype(np.uint64) << np.uint64(20) | np.arange(n, dtype=np.uint64)
+        want = np.sort(keys)
+        for block in (64, 1024, 0):
+            assert np.array_equal(lib.diag_bitonic(keys, block), want), (n, block)
+
+
+def test_emu_bitonic_network(emu):
+    check_bitonic(emu)
 
 
 # ---- klib's ks_introsort (the region sorts of mem_sort_dedup_patch, reached from gobwa.go:244,253,291,315): K5 / K6 run it by one lane (dev_introsort) and, when a rescue
