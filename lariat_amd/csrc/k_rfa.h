@@ -220,21 +220,31 @@ __device__ __forceinline__ double dev_fast_score_w(const DCand& R, const DInf& S
         }
         WAVE_SYNC();
         if (snk >= 0) {
-            for (int s = 0; s < cn; ++s) {
-                int lr = sLr[s];
-                int tq = T.bestT[(size_t)lr * M + snk];
-                if (tq >= 0) {
-                    int t = tq & RFA_T_MASK, fl = sFl[s];
-                    int hm = fl & 1, hp = fl >> 1;
-                    int skp = (tq & RFA_T_PAIR) && hm;                    // sink_has_mate_pair
-                    if (!hp || (hm && skp)) {
-                        if (record) { T.tdel[nm] = lr; T.tset[nm] = t; }
-                        nm++;
+            // (r06, late) four of the source's reads at a time: their table entries, then the log probabilities those name, are read before the first sum is touched — the
+            // additions stay in the map's order; a table read and a dependent gather per read, one after the other, were the step of this loop on large barcodes
+            for (int s0 = 0; s0 < cn; s0 += 4) {
+                int tq4[4];
+                double lap4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tq4[u] = s0 + u < cn ? T.bestT[(size_t)sLr[s0 + u] * M + snk] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lap4[u] = tq4[u] >= 0 ? R.lap[c_lo + (tq4[u] & RFA_T_MASK)] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tq = tq4[u], s = s0 + u;
+                    if (tq >= 0) {
+                        int t = tq & RFA_T_MASK, fl = sFl[s];
+                        int hm = fl & 1, hp = fl >> 1;
+                        int skp = (tq & RFA_T_PAIR) && hm;                    // sink_has_mate_pair
+                        if (!hp || (hm && skp)) {
+                            if (record) { T.tdel[nm] = sLr[s]; T.tset[nm] = t; }
+                            nm++;
+                        }
+                        alignment_change += lap4[u] - sLap[s];
+                        if (hp && !skp) alignment_change += lup / 2.0;
+                        else if (!hp && skp) alignment_change -= lup / 2.0;
+                        num++;
                     }
-                    alignment_change += R.lap[c_lo + t] - sLap[s];
-                    if (hp && !skp) alignment_change += lup / 2.0;
-                    else if (!hp && skp) alignment_change -= lup / 2.0;
-                    num++;
                 }
             }
         }
@@ -1234,14 +1244,22 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     if (t < M) T.P[t] = t == s ? 0.0 : pow(10.0, sc);
                 }
                 WAVE_SYNC();
+                RFA_PROF(8)
                 for (int k = lane; k < T.alen[s]; k += 64) {
                     int a = T.act_store[T.aoff[s] + k], lr = S.cand_read[c_lo + a] - r0;
                     double sum = S.sum_move[c_lo + a];
-                    for (int t = 0; t < M; ++t)
-                        if (t != s && T.bestT[(size_t)lr * M + t] >= 0) sum += T.P[t];
+                    for (int t0 = 0; t0 < M; t0 += 8) {   // (eight table entries read at a time; the sums in the molecules' order, as written)
+                        int q8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) q8[u] = t0 + u < M ? T.bestT[(size_t)lr * M + t0 + u] : -1;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (t0 + u != s && q8[u] >= 0) sum += T.P[t0 + u];
+                    }
                     S.sum_move[c_lo + a] = sum;
                 }
                 WAVE_SYNC();
+                RFA_PROF(2)
             }
             RFA_PROF(8)
             // ---- updateAlignmentsMoleculeStatus: confidences, differences, active molecules ----
