@@ -986,7 +986,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                     MEnt e;
                     e.pos = R.pos[ca]; e.rid = R.rid[ca]; e.rd = (uint32_t)T.rdl[i] | (uint32_t)(R.reversed[ca] != 0) << 31;
                     const int sc = R.soft_clipped[ca];
-                    e.s2 = R.mismatches[ca] * -4 + R.indels[ca] * -6 - (sc > 0 ? 20 * sc + R.soft_clipped_length[ca] : 0);
+                    e.s2 = R.mismatches[ca] * -4 + R.indels[ca] * -6 - (sc > 0 ? 10 * sc + R.soft_clipped_length[ca] : 0);   // twice (-2 mm - 3 id - 5 sc - 0.5 scl)
                     e.spare = 0;
                     return e;
                 };

@@ -2,6 +2,7 @@
 This is a logic check that works without a GPU; the `-m gpu` tests are the parity tests proper."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -129,6 +130,16 @@ def test_emu_position_sort_long_lists_with_equal_positions(emu, oracle, build):
     assert int(ok.sum()) > 900   # (more candidates than the barcode-wide LDS sort holds: contig by contig)
     res = lib.index_from_arrays(oidx.arrays()).context(rs.n_pairs + n_dup).align_barcodes(b)
     helpers.assert_same_result(res, ref, inference=True)
+
+
+def test_emu_fuzz_regression_clipped_pairs(emu, oracle):
+    """a case the differential fuzzer found on the device (tests/checkers/fuzz_gpu.py, seed 95343; r06): repeat families, reads of 195 and 147 bases, gap-open
+    penalties 3 / 8 — soft-clipped alignments compete inside a molecule.  markBest's first step scores a pair from integers (twice the entries' own parts,
+    k_rfa.h MEnt::s2); with the clip term doubled a read's best alignment in one molecule changed, and a probability sum with it by 3e-8.  The same case through
+    the kernel sources here, every field."""
+    sys.path.insert(0, os.path.join(helpers.ROOT, "tests", "checkers"))
+    import fuzz_gpu
+    fuzz_gpu.run_case(emu, oracle, 95343)
 
 
 def test_emu_long_noisy_reads(emu, oracle):

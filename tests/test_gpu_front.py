@@ -59,12 +59,14 @@ def test_get_seq(lib, oracle):
 
 def test_fuzz_regressions(lib, oracle):
     """cases the differential fuzzer (tests/checkers/fuzz_gpu.py) once found: seed 72337 holds a 235-base read with a candidate of 89
-    mismatch loci — past the 64 slots per candidate, continued in the batch's pool (k_aln.h DCand::mm_x*)"""
+    mismatch loci — past the 64 slots per candidate, continued in the batch's pool (k_aln.h DCand::mm_x*); seed 95343 (r06) a barcode in which
+    soft-clipped alignments compete inside a molecule: markBest's integer pair score had the clip term doubled, one read's best alignment in a
+    molecule changed and with it a probability sum by 3e-8 (k_rfa.h, MEnt::s2)"""
     import os
     import sys
     sys.path.insert(0, os.path.join(helpers.ROOT, "tests", "checkers"))
     import fuzz_gpu
-    for seed in (72337,):
+    for seed in (72337, 95343):
         fuzz_gpu.run_case(lib, oracle, seed)
 
 
