@@ -201,24 +201,29 @@ static_assert(LH_RFA_NET_BLOCK >= 64 && (LH_RFA_NET_BLOCK & (LH_RFA_NET_BLOCK - 
 // source's active alignments in OrderedAlignmentMap order, so each sink's sums keep the reference's order of additions.
 // Returns the score change, *num_out = reads with an alternative in the sink; with `record` the lane also writes the
 // reads that would move (toDelete / toSet) to T.tdel / T.tset and their number to *nmove.
+// (r06, late) `staged`: the source's alignments are in LDS already — the caller has scored another 64 sinks of the SAME source since nothing changed (a source of up to
+// LH_RFA_SRC_CHUNK alignments: longer ones are staged chunk by chunk on every call).  Staging was repeated per 64 sinks: half of a call on a barcode of hundreds of molecules.
 __device__ __forceinline__ double dev_fast_score_w(const DCand& R, const DInf& S, const RfaTab& T, i64 c_lo, int r0, int M, int src, int snk, double lup,
-                                                   int32_t* sLr, int32_t* sFl, double* sLap, int* num_out, int record, int* nmove) {
+                                                   int32_t* sLr, int32_t* sFl, double* sLap, int* num_out, int record, int* nmove, int staged = 0) {
     const int lane = LANE();
     double change = 0, alignment_change = 0;
     int num = 0, nm = 0;
     const int n = T.alen[src], ao = T.aoff[src];
+    const int reuse = staged && n <= LH_RFA_SRC_CHUNK;
     for (int cb = 0; cb < n; cb += LH_RFA_SRC_CHUNK) {
         int cn = n - cb < LH_RFA_SRC_CHUNK ? n - cb : LH_RFA_SRC_CHUNK;
-        EMU_SYNC();   // the previous chunk has been consumed
-        for (int s = lane; s < cn; s += 64) {
-            int a = T.act_store[ao + cb + s];
-            int lr = S.cand_read[c_lo + a] - r0;
-            int sm = T.act_cand[lr ^ 1];
-            int hm = sm >= 0 && S.molecule_id[c_lo + sm] == src;          // source_has_mate
-            int hp = hm && dev_is_pair(R, c_lo + a, c_lo + sm);           // source_has_mate_pair
-            sLr[s] = lr; sFl[s] = hm | hp << 1; sLap[s] = R.lap[c_lo + a];
+        if (!reuse) {
+            EMU_SYNC();   // the previous chunk has been consumed
+            for (int s = lane; s < cn; s += 64) {
+                int a = T.act_store[ao + cb + s];
+                int lr = S.cand_read[c_lo + a] - r0;
+                int sm = T.act_cand[lr ^ 1];
+                int hm = sm >= 0 && S.molecule_id[c_lo + sm] == src;          // source_has_mate
+                int hp = hm && dev_is_pair(R, c_lo + a, c_lo + sm);           // source_has_mate_pair
+                sLr[s] = lr; sFl[s] = hm | hp << 1; sLap[s] = R.lap[c_lo + a];
+            }
+            WAVE_SYNC();
         }
-        WAVE_SYNC();
         if (snk >= 0) {
             // (r06, late) four of the source's reads at a time: their table entries, then the log probabilities those name, are read before the first sum is touched — the
             // additions stay in the map's order; a table read and a dependent gather per read, one after the other, were the step of this loop on large barcodes
@@ -1119,7 +1124,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             WAVE_SYNC();
             if ((size_t)M * (size_t)nR > best_cap) RFA_OVERFLOW()   // molecule table does not fit the slab
             for (size_t x = lane; x < (size_t)M * nR; x += 64) T.bestT[x] = -1;
-            for (int r = lane; r < nR; r += 64) { T.act_cand[r] = -1; T.act_slot[r] = -1; }
+            for (int r = lane; r < nR; r += 64) { T.act_cand[r] = -1; T.act_slot[r] = -1; T.dk0[r] = 0; }   // (dk0: k_rfa_post's; here the read's sink groups, below)
             for (int i = lane; i < NCf; i += 64) S.molecule_id[c_lo + T.plist[i]] = T.newid[T.molraw[i]];
             WAVE_SYNC();
             // step 2: per molecule, reads in first-occurrence order: best alignment (earliest maximum) and the active list
@@ -1156,6 +1161,9 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                         }
                     }
                     T.bestT[(size_t)T.rdl[i] * M + m] = bi;
+                    // (r06, late) which groups of 64 molecules hold an alignment of the read at all (bit (m / 64) mod 64): fastScore is asked about 64 sinks at a time, and a
+                    // group in which none of the source's reads has an alignment cannot hold a sink with a read to move
+                    atomicOr((unsigned long long*)&T.dk0[T.rdl[i]], 1ull << ((m >> 6) & 63));
                 }
                 int hasact = isf && act >= 0;
                 u64 mk = __ballot(hasact);
@@ -1191,16 +1199,32 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             // ---- optimizer.Optimize(opt, 1, 2, 4*M): 8*M greedy molecule moves ----
             // The optimizer is deterministic: once M consecutive turns (every molecule tried once as the source) accept no
             // move, the state can no longer change and the remaining turns are no-ops, so they are not executed.
+            // the source staged once (a call with idle lanes), and the groups of 64 sinks in which one of its reads has an alignment: the union of its reads' group bits
+            auto stage_source = [&](int src) -> u64 {
+                if (M <= 64 || T.alen[src] > LH_RFA_SRC_CHUNK) return ~0ull;
+                int num;
+                dev_fast_score_w(R, S, T, c_lo, r0, M, src, -1, improper, sLr, sFl, sLap, &num, 0, (int*)0);
+                u64 mine = 0;
+                for (int k = lane; k < T.alen[src]; k += 64) mine |= T.dk0[sLr[k]];
+                u64 all = 0;
+                for (int b = 0; b < 64 && b * 64 < M; ++b)
+                    if (__ballot((int)(mine >> b & 1))) all |= 1ull << b;
+                if (M > 64 * 64) all = ~0ull;   // (the bits wrap around: every group may be meant)
+                return all;
+            };
             int source = 0, idle = 0;
             for (int it = 0; it < 8 * M && idle < M; ++it) {
                 ++idle;
                 if (T.alen[source] == 0) { source = (source + 1) % M; continue; }
                 double bs = -1.7976931348623157e308;
                 int bl = -1, bi = 0x7fffffff;
+                const u64 groups = stage_source(source);
+                const int staged = groups != ~0ull;
                 for (int sb = 0; sb < M; sb += 64) {
+                    if (!(groups >> ((sb >> 6) & 63) & 1)) continue;   // (no sink here has a read of the source to move: num = 0 for all of them)
                     int i = sb + lane, num;
                     int snk = (i < M && i != source) ? i : -1;
-                    double sc = dev_fast_score_w(R, S, T, c_lo, r0, M, source, snk, improper, sLr, sFl, sLap, &num, 0, (int*)0);
+                    double sc = dev_fast_score_w(R, S, T, c_lo, r0, M, source, snk, improper, sLr, sFl, sLap, &num, 0, (int*)0, staged);
                     if (snk >= 0 && num > 0 && (sc > bs || (sc == bs && T.alen[i] > bl))) { bs = sc; bl = T.alen[i]; bi = i; }
                 }
                 for (int msk = 32; msk >= 1; msk >>= 1) {   // lexicographic max of (score, sink size), first index on full ties
@@ -1211,7 +1235,7 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 }
                 if (bi != 0x7fffffff && (bs > 0 || (bs == 0 && bl > T.alen[source]))) {
                     int num, nmv;   // acceptMove: recompute the move list (every lane evaluates the winner, lane 0 records), apply in order
-                    dev_fast_score_w(R, S, T, c_lo, r0, M, source, bi, improper, sLr, sFl, sLap, &num, lane == 0, &nmv);
+                    dev_fast_score_w(R, S, T, c_lo, r0, M, source, bi, improper, sLr, sFl, sLap, &num, lane == 0, &nmv, staged);
                     WAVE_SYNC();
                     idle = 0;
                     if (lane == 0) {
@@ -1238,9 +1262,12 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
             RFA_PROF(7)
             // ---- moleculeMapqProbabilitySums ----
             for (int s = 0; s < M; ++s) {
+                const u64 groups = stage_source(s);
+                const int staged = groups != ~0ull;
                 for (int sb = 0; sb < M; sb += 64) {
+                    if (!(groups >> ((sb >> 6) & 63) & 1)) continue;   // (P[t] is read below only where a read of s has an alignment in t: none in this group)
                     int t = sb + lane, num;
-                    double sc = dev_fast_score_w(R, S, T, c_lo, r0, M, s, (t < M && t != s) ? t : -1, improper, sLr, sFl, sLap, &num, 0, (int*)0);
+                    double sc = dev_fast_score_w(R, S, T, c_lo, r0, M, s, (t < M && t != s) ? t : -1, improper, sLr, sFl, sLap, &num, 0, (int*)0, staged);
                     if (t < M) T.P[t] = t == s ? 0.0 : pow(10.0, sc);
                 }
                 WAVE_SYNC();
@@ -1248,7 +1275,9 @@ __global__ void __launch_bounds__(64, LH_RFA_WAVES) k_rfa(DIndex ix, DOpts o, in
                 for (int k = lane; k < T.alen[s]; k += 64) {
                     int a = T.act_store[T.aoff[s] + k], lr = S.cand_read[c_lo + a] - r0;
                     double sum = S.sum_move[c_lo + a];
+                    const u64 mine = M > 64 && M <= 64 * 64 ? T.dk0[lr] : ~0ull;   // (the read's own groups: elsewhere its row of the table is empty)
                     for (int t0 = 0; t0 < M; t0 += 8) {   // (eight table entries read at a time; the sums in the molecules' order, as written)
+                        if (!(mine >> ((t0 >> 6) & 63) & 1)) { t0 = (t0 | 63) - 7; continue; }
                         int q8[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) q8[u] = t0 + u < M ? T.bestT[(size_t)lr * M + t0 + u] : -1;
