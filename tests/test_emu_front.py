@@ -142,6 +142,31 @@ def test_emu_fuzz_regression_clipped_pairs(emu, oracle):
     fuzz_gpu.run_case(emu, oracle, 95343)
 
 
+def test_emu_barcode_with_more_than_64_molecules(emu, oracle):
+    """K8's optimizer and probability sums ask fastScore about 64 sinks at a time (k_rfa.h): with more than 64 molecules in a barcode the source of a turn is staged
+    once for all groups, and a group in which no read of the source has an alignment is skipped (a word of group bits per read, set where the molecule x read table
+    is filled).  One barcode of 300 pairs on 150 contigs of 3 kb, a third of them copies of each other with a few substitutions (reads with alignments in several
+    molecules: moves to score, sums to add up): well over 64 molecules.  Every field against the oracle."""
+    from lariat_amd import synth
+    rng = np.random.default_rng(8)
+    base = [rng.integers(0, 4, size=3000).astype(np.uint8) for _ in range(100)]
+    contigs = list(base)
+    for k in range(50):   # copies of the first 25 contigs, 1 % off
+        c = base[k % 25].copy()
+        m = rng.random(3000) < 0.01
+        c[m] = (c[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+        contigs.append(c)
+    names = ["u%03d" % i for i in range(len(contigs))]
+    oidx = oracle.index_build_naive(names, contigs)
+    rs = synth.make_reads(contigs, names, n_barcodes=1, pairs_per_barcode=300, seed=4, junk_frac=0.02, mol_min=140, mol_max=140)
+    b = helpers.batch_of(rs)
+    ref = oidx.align_barcodes(b, threads=8)
+    n_mol = len(set(int(x) for x in ref.rid[(ref.active != 0) & (ref.rid >= 0)]))   # (a contig with an active alignment holds at least one molecule)
+    assert n_mol >= 80, n_mol
+    res = emu.index_from_arrays(oidx.arrays()).context(rs.n_pairs).align_barcodes(b)
+    helpers.assert_same_result(res, ref, inference=True)
+
+
 def test_emu_long_noisy_reads(emu, oracle):
     """240-bp reads with substitutions and indels: the 128/256-column classes of the lane-per-read extension, deferred reads,
     gapped global alignments"""
